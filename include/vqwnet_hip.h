@@ -1,0 +1,162 @@
+/*
+ * vqwnet_hip.h — C ABI of libvqwnet_hip.so: the MI355X (gfx950) kernels behind the
+ * VQ-W-Net training hot path of Kaz-K/medical-image-editing.
+ *
+ * The reference has no FFI of its own: every operator below replaces a stock
+ * ATen call made from the reference's torch.nn modules (citations are to
+ * /root/reference/src).  The drop-in boundary is therefore this library, bound
+ * with ctypes from the Python host code in medical-image-editing_amd/hipops,
+ * which re-implements the reference's nn.Module classes on top of it.
+ *
+ * Conventions
+ *   - All tensor arguments are DEVICE pointers to dense fp32 in NHWC order
+ *     (PyTorch `channels_last`), ids are int64/int32 as stated.
+ *   - Conv weights are OHWI: w[co][ky][kx][ci] (PyTorch OIHW storage in
+ *     channels_last memory format), i.e. the same bytes a
+ *     `weight.contiguous(memory_format=torch.channels_last)` holds.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     only enqueue work; no call synchronises, allocates or frees device memory
+ *     (safe for hipGraph capture).  Scratch comes in through `ws` arguments whose
+ *     size the matching *_ws_bytes() query returns.
+ *   - Return value: 0 = ok, <0 = error (argument / launch); the message is
+ *     available from vqw_last_error() (thread-local).  The Python binding turns a
+ *     non-zero status into RuntimeError, mirroring the reference's assert /
+ *     torch error behaviour.
+ */
+#ifndef VQWNET_HIP_H
+#define VQWNET_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* vqw_last_error(void);
+int vqw_abi_version(void);
+/* 0 = auto (MFMA kernels when shapes allow), 1 = force the generic VALU kernels. */
+int vqw_set_conv_backend(int mode);
+
+/* ---- convolution: replaces F.conv2d fwd/bwd behind nn.Conv2d in
+ *      networks/blocks.py:5-6,25,45,48,75,79,80,102,108,112,117; networks/aspp.py:19-24;
+ *      networks/unet_decoder.py:105.
+ * The input is the *virtual* channel-concat [src0 (C0 ch, optionally nearest x2
+ * up-sampled from H/2 x W/2), src1 (C1 ch, may be NULL/0)] so that
+ * nn.Upsample + torch.cat (blocks.py:12,16-17,106,123) are never materialised.
+ * ksize in {1,3}; stride 1; padding = dil*(ksize/2) ("same").                      */
+int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* src1, int C1,
+                   const float* w_ohwi, const float* bias, float* y,
+                   int N, int H, int W, int Cout, int ksize, int dil, int relu, void* stream);
+/* dgrad weights: wt[ci][2-ky][2-kx][co] = w[co][ky][kx][ci]; then
+ * dX = vqw_conv2d_fwd(dY, Cout, 0, NULL, 0, wt, NULL, dX, N,H,W, Cin, ksize, dil, 0).
+ * relu=1 fuses nn.ReLU into the epilogue (blocks.py:75-77 mlp_shared).             */
+int vqw_pack_dgrad_weights(const float* w_ohwi, float* wt, int Cout, int Cin, int ksize, void* stream);
+size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, int ksize);
+/* dW[co][ky][kx][ci] (OHWI) and, if dbias != NULL, dbias[co] = sum_p dY. */
+int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float* src1, int C1,
+                     const float* dy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes,
+                     int N, int H, int W, int Cout, int ksize, int dil, void* stream);
+/* Gradient of the virtual input: g_full is [N,H,W,Ctot]; takes channels
+ * [c_off, c_off+C).  up=1: dst[N,H/2,W/2,C] = 2x2 block sums; up=0: plain slice copy.
+ * accumulate=1 adds into dst.                                                      */
+int vqw_input_grad_gather(const float* g_full, int Ctot, int c_off, int C, int up,
+                          float* dst, int accumulate, int N, int H, int W, void* stream);
+
+/* ---- InstanceNorm2d(affine=False) [+ReLU]: blocks.py:26,46-47,49-50,118-119; aspp.py:25-28 */
+size_t vqw_plane_ws_bytes(int N, int C, int HW);
+/* y / gy may be a channel slice [c_off, c_off+C) of a wider NHWC tensor with `cstride` channels
+ * (cstride == C, c_off == 0 for a plain tensor): the ASPP concat (aspp.py:47) is written in place. */
+int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd /*[N][C][2]*/,
+                  void* ws, size_t ws_bytes, int N, int HW, int C, float eps, int relu, void* stream);
+int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
+                  float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
+
+/* ---- StyledDenorm = BatchNorm2d(affine=False)(x)*(1+gamma)+beta [+ReLU]: blocks.py:82-90,126-132.
+ * training=1: batch statistics, running stats updated in place (momentum, unbiased var);
+ * training=0: running stats.  stats_io: training fwd receives per-channel
+ * [sum, sumsq] partial totals via (sum_out) for cross-rank reduction: see vqw_bn_* below.  */
+int vqw_bn_partial_stats(const float* x, double* sums /*[C][2]*/, void* ws, size_t ws_bytes,
+                         int N, int HW, int C, void* stream);
+int vqw_bn_finalize(const double* sums /*[C][2]*/, double count, float* mean_rstd /*[C][2]*/,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    int C, void* stream);
+int vqw_bn_eval_stats(const float* running_mean, const float* running_var, float* mean_rstd,
+                      float eps, int C, void* stream);
+int vqw_spade_fwd(const float* x, const float* mean_rstd /*[C][2]*/, const float* gamma,
+                  const float* beta, float* y, long P, int C, int relu, void* stream);
+/* backward, phase 1: dgamma, dbeta and per-channel sums [sum dxhat, sum dxhat*xhat] */
+int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                         const float* gy, float* dgamma, float* dbeta, double* sums /*[C][2]*/,
+                         void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
+/* phase 2: dx (training: sums/count terms; training=0: dx = dxhat*rstd) */
+int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                        const float* gy, const double* sums, double count, float* gx,
+                        long P, int C, int relu, int training, void* stream);
+
+/* ---- element-wise / pooling: blocks.py:29-30,34-36 (add, ReLU, MaxPool2d(2)), 134; unet_decoder.py:107,159-163 */
+int vqw_add(const float* a, const float* b, float* y, long n, int relu, void* stream);
+int vqw_relu_bwd(const float* y, const float* gy, float* gx, long n, void* stream);
+int vqw_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int vqw_maxpool2_bwd(const float* x, const float* gy, const float* g_skip /*nullable*/, float* gx,
+                     int N, int H, int W, int C, void* stream);
+int vqw_tanh_fwd(const float* x, float* y, long n, void* stream);
+int vqw_tanh_bwd(const float* y, const float* gy, float* gx, long n, void* stream);
+int vqw_affine(const float* x, float* y, float scale, float shift, long n, void* stream); /* utils norm/denorm */
+int vqw_mse_fwd(const float* a, const float* b, float* loss, void* ws, size_t ws_bytes, long n, void* stream);
+int vqw_mse_bwd(const float* a, const float* b, const float* gloss, float* ga, long n, void* stream);
+size_t vqw_reduce_ws_bytes(long n);
+int vqw_weighted_sum(const float* const* terms_dev /*device array of ptrs*/, const float* weights_dev,
+                     int n_terms, float* out, void* stream);
+
+/* ---- vector quantisation: networks/vq/vq_module.py:45-62,159-211; grad_approximation.py:7-29 */
+size_t vqw_vq_ws_bytes(long Npix, int D, int K);
+/* x [Npix][D] (NHWC rows), embed [K][D].  Outputs: ids int64 [Npix], q [Npix][D],
+ * commit = mean((x-q)^2); when stats != NULL also counts[K] and embed_sum[D][K]
+ * (layout of the reference's embed_avg) as double in `stats` = [K + D*K].
+ * ids are written as code + id_base (unet_encoder.py:116 adds 1).                   */
+int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int id_base, float* q, float* commit,
+               double* stats, void* ws, size_t ws_bytes, long Npix, int D, int K, void* stream);
+/* EMA + Laplace-smoothed normalisation (vq_module.py:195-200), in place on the buffers.
+ * sum_scale multiplies embed_sum before the EMA (1/world_size in the reference's quirk mode). */
+int vqw_vq_ema_update(const double* stats, float* embed, float* cluster_size, float* embed_avg,
+                      float momentum, float eps, float sum_scale, int D, int K, void* stream);
+int vqw_vq_lookup(const int64_t* ids, const float* embed, const uint8_t* mask /*nullable*/,
+                  const float* scale_dev /*nullable, 1 float*/, float* out, long Npix, int D, int K,
+                  void* stream);
+/* gx = g_q (straight-through) + g_commit * 2 (x - q) / numel */
+int vqw_vq_bwd(const float* x, const float* q, const float* g_q, const float* g_commit,
+               float* gx, long numel, void* stream);
+/* mask count -> scale = numel / count (run_recon.py:191-192) */
+int vqw_mask_scale(const int64_t* label_map, uint8_t* mask, int64_t* ids0, float* scale_dev,
+                   long n, void* stream);
+
+/* ---- losses: functions/embed_loss.py:22-88, functions/onehot.py:11-20 */
+size_t vqw_cross_ws_bytes(int B, int K, long HW);
+/* labels int32 [B][HW] in [0,K] (0 = out of frame); embed [B][HW][D]; codebook [K][D] (= vq.embed).
+ * loss = mean over present (b,k) of sum_p |e-c_k|^2 / (cnt+1e-6); coef[B][K] saved for backward. */
+int vqw_cross_loss_fwd(const float* embed, const int32_t* labels, const float* codebook_kd,
+                       float* loss, float* coef, void* ws, size_t ws_bytes,
+                       int B, long HW, int D, int K, void* stream);
+int vqw_cross_loss_bwd(const float* embed, const int32_t* labels, const float* codebook_kd,
+                       const float* coef, const float* gloss, float* gembed,
+                       int B, long HW, int D, int K, void* stream);
+/* general (soft / one-hot float r[B][K][HW] NCHW as the reference passes it) */
+int vqw_cross_loss_dense_fwd(const float* embed, const float* r_nchw, const float* codebook_kd,
+                             float* loss, float* coef, void* ws, size_t ws_bytes,
+                             int B, long HW, int D, int K, void* stream);
+int vqw_cross_loss_dense_bwd(const float* embed, const float* r_nchw, const float* codebook_kd,
+                             const float* coef, const float* gloss, float* gembed,
+                             int B, long HW, int D, int K, void* stream);
+int vqw_codebook_losses(const float* codebook_kd, float margin, float* l_dist, float* l_reg,
+                        int D, int K, void* stream);
+int vqw_onehot(const int32_t* labels, float* out_nchw, int B, long HW, int n_classes, void* stream);
+int vqw_flip_labels(const int64_t* ids, int32_t* out, int border, int B, int H, int W, void* stream);
+
+/* ---- optimiser: torch.optim.Adam as built in trainers/base.py:165-175 */
+int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,30 @@
+// Internal declarations shared by the convolution translation units.
+#pragma once
+#include "common.h"
+
+// Virtual conv input: channel-concat of src0 (C0 channels; up0=1 -> nearest x2 up-sampled from H/2 x W/2)
+// and src1 (C1 channels at full resolution; C1 == 0 -> absent).
+struct ConvIn {
+    const float* src0;
+    const float* src1;
+    int C0, C1, up0;
+};
+
+// generic VALU kernels (conv_generic.hip)
+int conv_direct_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks,
+                    int dil, int relu, hipStream_t st);
+int conv_direct_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
+                      hipStream_t st);
+int conv_direct_wgrad_splits(long nout, long P);
+size_t bias_grad_ws_floats(int C);
+int bias_grad(const float* dy, float* dbias, float* ws, long P, int C, hipStream_t st);
+int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st);
+
+// MFMA implicit-GEMM kernels (conv_mfma.hip)
+bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks);
+int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
+                  int relu, hipStream_t st);
+bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
+size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
+int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
+                    hipStream_t st);

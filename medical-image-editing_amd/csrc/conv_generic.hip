@@ -1,0 +1,213 @@
+// Generic direct convolution kernels (any channel count, VALU fp32) + weight packing, bias gradient and the
+// gradient gather for the virtual (up-sampled / concatenated) input.  These are the fallback for shapes the
+// MFMA implicit-GEMM kernels (conv_mfma.hip) do not take (Cin or Cout not a multiple of 16, e.g. the 1-channel
+// stem and the 32->1 head), and the on-device cross-check for them in the tests.
+#include "common.h"
+#include "conv_common.h"
+#include "../../include/vqwnet_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// forward: one thread per output element (pixel, co); adjacent threads = adjacent co (coalesced store).
+__global__ void __launch_bounds__(256) k_conv_direct_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int N, int H, int W, int Cout, int ks, int dil,
+                                                         int relu) {
+    const int Cin = in.C0 + in.C1;
+    const int taps = ks * ks, half = ks >> 1;
+    long total = (long)N * H * W * Cout;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int co = (int)(i % Cout);
+        long p = i / Cout;
+        int x = (int)(p % W);
+        long q = p / W;
+        int yy = (int)(q % H);
+        int n = (int)(q / H);
+        float acc = bias ? bias[co] : 0.f;
+        for (int t = 0; t < taps; ++t) {
+            int hy = yy + (t / ks - half) * dil, wx = x + (t % ks - half) * dil;
+            if (hy < 0 || hy >= H || wx < 0 || wx >= W) continue;
+            const float* wr = w + ((long)co * taps + t) * Cin;
+            const float* s0 = in.up0 ? in.src0 + (((long)n * (H >> 1) + (hy >> 1)) * (W >> 1) + (wx >> 1)) * in.C0
+                                     : in.src0 + (((long)n * H + hy) * W + wx) * in.C0;
+            for (int c = 0; c < in.C0; ++c) acc = fmaf(s0[c], wr[c], acc);
+            if (in.C1 > 0) {
+                const float* s1 = in.src1 + (((long)n * H + hy) * W + wx) * in.C1;
+                for (int c = 0; c < in.C1; ++c) acc = fmaf(s1[c], wr[in.C0 + c], acc);
+            }
+        }
+        y[i] = relu ? fmaxf(acc, 0.f) : acc;
+    }
+}
+
+int conv_direct_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks,
+                    int dil, int relu, hipStream_t st) {
+    long total = (long)N * H * W * Cout;
+    k_conv_direct_fwd<<<stream_grid(total, 256), 256, 0, st>>>(in, w, bias, y, N, H, W, Cout, ks, dil, relu);
+    VQW_LAUNCH_CHECK("conv_direct_fwd");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// wt[ci][2-ky][2-kx][co] = w[co][ky][kx][ci]
+__global__ void k_pack_dgrad(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin, int taps) {
+    long total = (long)Cout * taps * Cin;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int co = (int)(i % Cout);
+        long r = i / Cout;
+        int t = (int)(r % taps);
+        int ci = (int)(r / taps);
+        wt[i] = w[((long)co * taps + (taps - 1 - t)) * Cin + ci];
+    }
+}
+extern "C" int vqw_pack_dgrad_weights(const float* w_ohwi, float* wt, int Cout, int Cin, int ksize, void* stream) {
+    VQW_CHECK(w_ohwi && wt && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "vqw_pack_dgrad_weights: bad arguments");
+    long total = (long)Cout * ksize * ksize * Cin;
+    k_pack_dgrad<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(w_ohwi, wt, Cout, Cin, ksize * ksize);
+    VQW_LAUNCH_CHECK("vqw_pack_dgrad_weights");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic wgrad: block (output element o = (co,t,ci), split s) reduces its pixel range; partials then summed.
+__global__ void __launch_bounds__(256) k_conv_direct_wgrad(ConvIn in, const float* __restrict__ dy, float* __restrict__ part,
+                                                           int N, int H, int W, int Cout, int ks, int dil, int splits) {
+    __shared__ float s_red[4];
+    const int Cin = in.C0 + in.C1;
+    const int taps = ks * ks, half = ks >> 1;
+    const int o = blockIdx.x, s = blockIdx.y;
+    const int ci = o % Cin;
+    const int t = (o / Cin) % taps;
+    const int co = o / (Cin * taps);
+    const int dyy = (t / ks - half) * dil, dxx = (t % ks - half) * dil;
+    const long P = (long)N * H * W;
+    const long per = (P + splits - 1) / splits;
+    const long p0 = s * per, p1 = p0 + per < P ? p0 + per : P;
+    float acc = 0.f;
+    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+        int x = (int)(p % W);
+        long q = p / W;
+        int yy = (int)(q % H);
+        int n = (int)(q / H);
+        int hy = yy + dyy, wx = x + dxx;
+        if (hy < 0 || hy >= H || wx < 0 || wx >= W) continue;
+        float v;
+        if (ci < in.C0) {
+            v = in.up0 ? in.src0[(((long)n * (H >> 1) + (hy >> 1)) * (W >> 1) + (wx >> 1)) * in.C0 + ci]
+                       : in.src0[(((long)n * H + hy) * W + wx) * in.C0 + ci];
+        } else {
+            v = in.src1[(((long)n * H + hy) * W + wx) * in.C1 + (ci - in.C0)];
+        }
+        acc = fmaf(dy[p * Cout + co], v, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)s * gridDim.x + o] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// out[i] = sum_s part[s][i]
+__global__ void k_reduce_rows(const float* __restrict__ part, float* __restrict__ out, long n, int rows) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += part[(long)r * n + i];
+        out[i] = a;
+    }
+}
+
+int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st) {
+    k_reduce_rows<<<stream_grid(n, 256), 256, 0, st>>>(part, out, n, rows);
+    VQW_LAUNCH_CHECK("reduce_rows");
+    return VQW_OK;
+}
+
+int conv_direct_wgrad_splits(long nout, long P) {
+    int s = ceil_div(4096, nout);
+    long cap = P / 1024 > 1 ? P / 1024 : 1;
+    if (s > cap) s = (int)cap;
+    if (s > 256) s = 256;
+    return s < 1 ? 1 : s;
+}
+
+int conv_direct_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
+                      hipStream_t st) {
+    const int Cin = in.C0 + in.C1;
+    long nout = (long)Cout * ks * ks * Cin;
+    int splits = conv_direct_wgrad_splits(nout, (long)N * H * W);
+    k_conv_direct_wgrad<<<dim3((unsigned)nout, splits), 256, 0, st>>>(in, dy, ws, N, H, W, Cout, ks, dil, splits);
+    VQW_LAUNCH_CHECK("conv_direct_wgrad");
+    return reduce_rows(ws, dw, nout, splits, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dbias[co] = sum_p dy[p][co]; two-stage, deterministic
+#define BG_ROWS 512
+__global__ void __launch_bounds__(256) k_bias_grad_partial(const float* __restrict__ dy, float* __restrict__ part, long P, int C) {
+    __shared__ float sa[256];
+    const int tcn = C < 256 ? C : 256;
+    const int rows = 256 / tcn;
+    const int t = threadIdx.x, tc = t % tcn, tr = t / tcn;
+    const long per = (P + gridDim.x - 1) / gridDim.x;
+    const long p0 = blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
+    for (int cb = 0; cb < C; cb += tcn) {
+        int c = cb + tc;
+        float a = 0.f;
+        if (tr < rows && c < C)
+            for (long p = p0 + tr; p < p1; p += rows) a += dy[p * C + c];
+        sa[t] = a;
+        __syncthreads();
+        if (tr == 0 && c < C) {
+            for (int r = 1; r < rows; ++r) a += sa[r * tcn + tc];
+            part[(long)blockIdx.x * C + c] = a;
+        }
+        __syncthreads();
+    }
+}
+size_t bias_grad_ws_floats(int C) { return (size_t)BG_ROWS * C; }
+int bias_grad(const float* dy, float* dbias, float* ws, long P, int C, hipStream_t st) {
+    int rows = (int)imin(BG_ROWS, imax(1, (int)(P / 256)));
+    k_bias_grad_partial<<<rows, 256, 0, st>>>(dy, ws, P, C);
+    VQW_LAUNCH_CHECK("bias_grad");
+    return reduce_rows(ws, dbias, C, rows, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int UP, int ACC>
+__global__ void k_input_grad_gather(const float* __restrict__ g, int Ctot, int c_off, int C, float* __restrict__ dst, int N,
+                                    int H, int W) {
+    const int Ho = UP ? H >> 1 : H, Wo = UP ? W >> 1 : W;
+    long total = (long)N * Ho * Wo * C;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int x = (int)(p % Wo);
+        long q = p / Wo;
+        int y = (int)(q % Ho);
+        int n = (int)(q / Ho);
+        float v;
+        if (UP) {
+            const float* b = g + (((long)n * H + 2 * y) * W + 2 * x) * Ctot + c_off + c;
+            v = (b[0] + b[Ctot]) + (b[(long)W * Ctot] + b[(long)W * Ctot + Ctot]);
+        } else {
+            v = g[(((long)n * H + y) * W + x) * Ctot + c_off + c];
+        }
+        dst[i] = ACC ? dst[i] + v : v;
+    }
+}
+extern "C" int vqw_input_grad_gather(const float* g_full, int Ctot, int c_off, int C, int up, float* dst, int accumulate,
+                                     int N, int H, int W, void* stream) {
+    VQW_CHECK(g_full && dst && N > 0 && H > 0 && W > 0 && C > 0 && c_off >= 0 && c_off + C <= Ctot,
+              "vqw_input_grad_gather: bad arguments");
+    VQW_CHECK(!up || ((H % 2 == 0) && (W % 2 == 0)), "vqw_input_grad_gather: up-sampled source needs even H, W");
+    hipStream_t st = (hipStream_t)stream;
+    long total = (long)N * (up ? H / 2 : H) * (up ? W / 2 : W) * C;
+    int gr = stream_grid(total, 256);
+    if (up && accumulate) k_input_grad_gather<1, 1><<<gr, 256, 0, st>>>(g_full, Ctot, c_off, C, dst, N, H, W);
+    else if (up) k_input_grad_gather<1, 0><<<gr, 256, 0, st>>>(g_full, Ctot, c_off, C, dst, N, H, W);
+    else if (accumulate) k_input_grad_gather<0, 1><<<gr, 256, 0, st>>>(g_full, Ctot, c_off, C, dst, N, H, W);
+    else k_input_grad_gather<0, 0><<<gr, 256, 0, st>>>(g_full, Ctot, c_off, C, dst, N, H, W);
+    VQW_LAUNCH_CHECK("vqw_input_grad_gather");
+    return VQW_OK;
+}

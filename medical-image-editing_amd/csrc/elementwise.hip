@@ -1,0 +1,253 @@
+// Element-wise, pooling, scalar-loss and optimiser kernels (HBM-bound; float4 streams).
+#include "common.h"
+#include "../../include/vqwnet_hip.h"
+
+static thread_local char g_err[512] = "";
+extern "C" void vqw_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* vqw_last_error(void) { return g_err; }
+extern "C" int vqw_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------
+template <int RELU>
+__global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n) {
+    long n4 = n >> 2;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i], r;
+        r.x = u.x + v.x; r.y = u.y + v.y; r.z = u.z + v.z; r.w = u.w + v.w;
+        if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        ((float4*)y)[i] = r;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float r = a[i] + b[i];
+        y[i] = RELU ? fmaxf(r, 0.f) : r;
+    }
+}
+
+extern "C" int vqw_add(const float* a, const float* b, float* y, long n, int relu, void* stream) {
+    VQW_CHECK(a && b && y && n > 0, "vqw_add: bad arguments");
+    VQW_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) == 0, "vqw_add: pointers must be 16-byte aligned");
+    int g = stream_grid((n + 3) / 4, 256);
+    if (relu) k_add<1><<<g, 256, 0, (hipStream_t)stream>>>(a, b, y, n);
+    else k_add<0><<<g, 256, 0, (hipStream_t)stream>>>(a, b, y, n);
+    VQW_LAUNCH_CHECK("vqw_add");
+    return VQW_OK;
+}
+
+__global__ void k_relu_bwd(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, long n) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        gx[i] = y[i] > 0.f ? gy[i] : 0.f;
+}
+extern "C" int vqw_relu_bwd(const float* y, const float* gy, float* gx, long n, void* stream) {
+    VQW_CHECK(y && gy && gx && n > 0, "vqw_relu_bwd: bad arguments");
+    k_relu_bwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(y, gy, gx, n);
+    VQW_LAUNCH_CHECK("vqw_relu_bwd");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool2d(2), NHWC.  Ties resolve to the first maximum in row-major window order, as ATen does.
+__global__ void k_maxpool2_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+    int Ho = H >> 1, Wo = W >> 1;
+    long total = (long)N * Ho * Wo * C;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int wo = (int)(p % Wo);
+        long q = p / Wo;
+        int ho = (int)(q % Ho);
+        int n = (int)(q / Ho);
+        const float* b = x + (((long)n * H + 2 * ho) * W + 2 * wo) * C + c;
+        float m = b[0];
+        float v = b[C];
+        m = v > m ? v : m;
+        v = b[(long)W * C];
+        m = v > m ? v : m;
+        v = b[(long)W * C + C];
+        m = v > m ? v : m;
+        y[i] = m;
+    }
+}
+extern "C" int vqw_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    VQW_CHECK(x && y && N > 0 && C > 0 && H >= 2 && W >= 2, "vqw_maxpool2_fwd: bad arguments (N=%d H=%d W=%d C=%d)", N, H, W, C);
+    long total = (long)N * (H / 2) * (W / 2) * C;
+    k_maxpool2_fwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, C);
+    VQW_LAUNCH_CHECK("vqw_maxpool2_fwd");
+    return VQW_OK;
+}
+
+// gx (full resolution) = g_skip (optional) + gy routed to the arg-max of each 2x2 window.
+// Rows/columns beyond 2*(H/2) (odd sizes) only receive g_skip.
+__global__ void k_maxpool2_bwd(const float* __restrict__ x, const float* __restrict__ gy,
+                               const float* __restrict__ gs, float* __restrict__ gx, int N, int H, int W, int C) {
+    int Ho = H >> 1, Wo = W >> 1;
+    long total = (long)N * H * W * C;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int w = (int)(p % W);
+        long q = p / W;
+        int h = (int)(q % H);
+        int n = (int)(q / H);
+        float g = gs ? gs[i] : 0.f;
+        int ho = h >> 1, wo = w >> 1;
+        if (ho < Ho && wo < Wo) {
+            const float* b = x + (((long)n * H + 2 * ho) * W + 2 * wo) * C + c;
+            float m = b[0];
+            int am = 0;
+            float v = b[C];
+            if (v > m) { m = v; am = 1; }
+            v = b[(long)W * C];
+            if (v > m) { m = v; am = 2; }
+            v = b[(long)W * C + C];
+            if (v > m) { m = v; am = 3; }
+            int me = ((h & 1) << 1) | (w & 1);
+            if (am == me) g += gy[(((long)n * Ho + ho) * Wo + wo) * C + c];
+        }
+        gx[i] = g;
+    }
+}
+extern "C" int vqw_maxpool2_bwd(const float* x, const float* gy, const float* g_skip, float* gx,
+                                int N, int H, int W, int C, void* stream) {
+    VQW_CHECK(x && gy && gx && N > 0 && C > 0 && H >= 2 && W >= 2, "vqw_maxpool2_bwd: bad arguments");
+    long total = (long)N * H * W * C;
+    k_maxpool2_bwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, gy, g_skip, gx, N, H, W, C);
+    VQW_LAUNCH_CHECK("vqw_maxpool2_bwd");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void k_tanh_fwd(const float* __restrict__ x, float* __restrict__ y, long n) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = tanhf(x[i]);
+}
+__global__ void k_tanh_bwd(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, long n) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float t = y[i];
+        gx[i] = gy[i] * (1.f - t * t);
+    }
+}
+__global__ void k_affine(const float* __restrict__ x, float* __restrict__ y, float a, float b, long n) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = x[i] * a + b;
+}
+extern "C" int vqw_tanh_fwd(const float* x, float* y, long n, void* stream) {
+    VQW_CHECK(x && y && n > 0, "vqw_tanh_fwd: bad arguments");
+    k_tanh_fwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(x, y, n);
+    VQW_LAUNCH_CHECK("vqw_tanh_fwd");
+    return VQW_OK;
+}
+extern "C" int vqw_tanh_bwd(const float* y, const float* gy, float* gx, long n, void* stream) {
+    VQW_CHECK(y && gy && gx && n > 0, "vqw_tanh_bwd: bad arguments");
+    k_tanh_bwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(y, gy, gx, n);
+    VQW_LAUNCH_CHECK("vqw_tanh_bwd");
+    return VQW_OK;
+}
+extern "C" int vqw_affine(const float* x, float* y, float scale, float shift, long n, void* stream) {
+    VQW_CHECK(x && y && n > 0, "vqw_affine: bad arguments");
+    k_affine<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(x, y, scale, shift, n);
+    VQW_LAUNCH_CHECK("vqw_affine");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mean squared error, deterministic two-stage reduction (double partials)
+#define RED_BLOCKS 1024
+extern "C" size_t vqw_reduce_ws_bytes(long n) { (void)n; return RED_BLOCKS * sizeof(double); }
+
+__global__ void k_mse_partial(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ part, long n) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float d = a[i] - b[i];
+        acc += (double)(d * d);
+    }
+    acc = wave_sum_d(acc);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void k_sum_finalize(const double* __restrict__ part, int nparts, double scale, float* __restrict__ out) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc += part[i];
+    acc = wave_sum_d(acc);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((sm[0] + sm[1] + sm[2] + sm[3]) * scale);
+}
+extern "C" int vqw_mse_fwd(const float* a, const float* b, float* loss, void* ws, size_t ws_bytes, long n, void* stream) {
+    VQW_CHECK(a && b && loss && ws && n > 0, "vqw_mse_fwd: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_reduce_ws_bytes(n), "vqw_mse_fwd: workspace too small");
+    int g = imin(RED_BLOCKS, stream_grid(n, 256));
+    k_mse_partial<<<g, 256, 0, (hipStream_t)stream>>>(a, b, (double*)ws, n);
+    k_sum_finalize<<<1, 256, 0, (hipStream_t)stream>>>((const double*)ws, g, 1.0 / (double)n, loss);
+    VQW_LAUNCH_CHECK("vqw_mse_fwd");
+    return VQW_OK;
+}
+__global__ void k_mse_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gl,
+                          float* __restrict__ ga, long n, float inv_n2) {
+    float s = gl[0] * inv_n2;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) ga[i] = (a[i] - b[i]) * s;
+}
+extern "C" int vqw_mse_bwd(const float* a, const float* b, const float* gloss, float* ga, long n, void* stream) {
+    VQW_CHECK(a && b && gloss && ga && n > 0, "vqw_mse_bwd: bad arguments");
+    k_mse_bwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, gloss, ga, n, 2.0f / (float)n);
+    VQW_LAUNCH_CHECK("vqw_mse_bwd");
+    return VQW_OK;
+}
+
+__global__ void k_weighted_sum(const float* const* __restrict__ terms, const float* __restrict__ w, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += w[i] * terms[i][0];
+        out[0] = s;
+    }
+}
+extern "C" int vqw_weighted_sum(const float* const* terms_dev, const float* weights_dev, int n_terms, float* out, void* stream) {
+    VQW_CHECK(terms_dev && weights_dev && out && n_terms > 0 && n_terms <= 64, "vqw_weighted_sum: bad arguments");
+    k_weighted_sum<<<1, 64, 0, (hipStream_t)stream>>>(terms_dev, weights_dev, n_terms, out);
+    VQW_LAUNCH_CHECK("vqw_weighted_sum");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics: L2 decay folded into the gradient; eps added after the
+// bias-corrected sqrt).  28 B/param of HBM traffic: read p,g,m,v; write p,m,v.
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+    long stride = (long)gridDim.x * blockDim.x;
+    float step = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gi = g[i], pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        float mi = m[i] * b1 + (1.f - b1) * gi;
+        float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - step * (mi / denom);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+extern "C" int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, float bias_corr1, float bias_corr2, void* stream) {
+    VQW_CHECK(p && g && m && v && n > 0, "vqw_adam_step: bad arguments");
+    VQW_CHECK(bias_corr1 > 0.f && bias_corr2 > 0.f, "vqw_adam_step: bias corrections must be positive");
+    k_adam<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                                                                 bias_corr1, sqrtf(bias_corr2));
+    VQW_LAUNCH_CHECK("vqw_adam_step");
+    return VQW_OK;
+}

@@ -1,0 +1,276 @@
+// Embedding (cross-view cluster consistency) loss, codebook margin / norm losses, one-hot and label flip.
+// Replaces functions/embed_loss.py:22-88 and functions/onehot.py:11-20 of the reference without ever building
+// the (b, D, K, n_loc) broadcast or the N x (K+1) one-hot.
+#include "common.h"
+#include "../../include/vqwnet_hip.h"
+
+#define CL_BLOCK 256
+#define CL_MAX_SPLITS 64
+#define CL_EPS 1e-6f  // EmbeddingLoss.epsilon (embed_loss.py:8)
+
+static inline int cl_splits(int B, long HW) {
+    int s = ceil_div(1024, B);
+    long cap = HW / 512 > 1 ? HW / 512 : 1;
+    if (s > cap) s = (int)cap;
+    if (s > CL_MAX_SPLITS) s = CL_MAX_SPLITS;
+    return s < 1 ? 1 : s;
+}
+extern "C" size_t vqw_cross_ws_bytes(int B, int K, long HW) {
+    (void)HW;
+    return (size_t)B * CL_MAX_SPLITS * K * 2 * sizeof(float);
+}
+
+// labels variant.  part[b][split][k][2] = (sum of squared distances, count)
+__global__ void __launch_bounds__(CL_BLOCK) k_cross_partial(const float* __restrict__ embed, const int32_t* __restrict__ labels,
+                                                            const float* __restrict__ cb, float* __restrict__ part, long HW,
+                                                            int D, int K, int splits) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_acc = smem;  // [K][2]
+    const int b = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < 2 * K; i += CL_BLOCK) s_acc[i] = 0.f;
+    __syncthreads();
+    long per = (HW + splits - 1) / splits;
+    long p0 = s * per, p1 = p0 + per < HW ? p0 + per : HW;
+    for (long p = p0 + t; p < p1; p += CL_BLOCK) {
+        int l = labels[(long)b * HW + p];
+        if (l >= 1 && l <= K) {
+            const float* e = embed + ((long)b * HW + p) * D;
+            const float* c = cb + (long)(l - 1) * D;
+            float d2 = 0.f;
+            for (int d = 0; d < D; ++d) { float a = e[d] - c[d]; d2 = fmaf(a, a, d2); }
+            atomicAdd(&s_acc[2 * (l - 1)], d2);
+            atomicAdd(&s_acc[2 * (l - 1) + 1], 1.f);
+        }
+    }
+    __syncthreads();
+    float* o = part + ((long)b * splits + s) * K * 2;
+    for (int i = t; i < 2 * K; i += CL_BLOCK) o[i] = s_acc[i];
+}
+
+// dense variant: r[b][k][p] (NCHW float weights)
+__global__ void __launch_bounds__(CL_BLOCK) k_cross_partial_dense(const float* __restrict__ embed, const float* __restrict__ r,
+                                                                  const float* __restrict__ cb, float* __restrict__ part,
+                                                                  long HW, int D, int K, int splits) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_acc = smem;
+    const int b = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < 2 * K; i += CL_BLOCK) s_acc[i] = 0.f;
+    __syncthreads();
+    long per = (HW + splits - 1) / splits;
+    long p0 = s * per, p1 = p0 + per < HW ? p0 + per : HW;
+    for (long p = p0 + t; p < p1; p += CL_BLOCK) {
+        const float* e = embed + ((long)b * HW + p) * D;
+        for (int k = 0; k < K; ++k) {
+            float w = r[((long)b * K + k) * HW + p];
+            if (w != 0.f) {
+                const float* c = cb + (long)k * D;
+                float d2 = 0.f;
+                for (int d = 0; d < D; ++d) { float a = e[d] - c[d]; d2 = fmaf(a, a, d2); }
+                atomicAdd(&s_acc[2 * k], d2 * w);
+                atomicAdd(&s_acc[2 * k + 1], w);
+            }
+        }
+    }
+    __syncthreads();
+    float* o = part + ((long)b * splits + s) * K * 2;
+    for (int i = t; i < 2 * K; i += CL_BLOCK) o[i] = s_acc[i];
+}
+
+// loss = mean over (b,k) with cnt != 0 of num/(cnt+eps); coef[b][k] = 1/((cnt+eps) * n_present) or 0.
+__global__ void k_cross_finalize(const float* __restrict__ part, float* __restrict__ loss, float* __restrict__ coef, int BK,
+                                 int K, int splits) {
+    __shared__ double s_l[4];
+    __shared__ int s_c[4];
+    __shared__ int s_np;
+    double lsum = 0.0;
+    int np = 0;
+    for (int i = threadIdx.x; i < BK; i += blockDim.x) {
+        int b = i / K, k = i % K;
+        double num = 0.0, cnt = 0.0;
+        for (int s = 0; s < splits; ++s) {
+            const float* o = part + (((long)b * splits + s) * K + k) * 2;
+            num += (double)o[0];
+            cnt += (double)o[1];
+        }
+        if (cnt != 0.0) {
+            float per = (float)num / ((float)cnt + CL_EPS);
+            lsum += (double)per;
+            np += 1;
+            coef[i] = 1.f / ((float)cnt + CL_EPS);
+        } else {
+            coef[i] = 0.f;
+        }
+    }
+    lsum = wave_sum_d(lsum);
+    for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o, 64);
+    if ((threadIdx.x & 63) == 0) { s_l[threadIdx.x >> 6] = lsum; s_c[threadIdx.x >> 6] = np; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        s_np = n;
+        // torch: mean of an empty selection is NaN
+        loss[0] = n > 0 ? (float)((s_l[0] + s_l[1] + s_l[2] + s_l[3]) / (double)n) : __builtin_nanf("");
+    }
+    __syncthreads();
+    float inv = s_np > 0 ? 1.f / (float)s_np : 0.f;
+    for (int i = threadIdx.x; i < BK; i += blockDim.x) coef[i] *= inv;
+}
+
+extern "C" int vqw_cross_loss_fwd(const float* embed, const int32_t* labels, const float* codebook_kd, float* loss, float* coef,
+                                  void* ws, size_t ws_bytes, int B, long HW, int D, int K, void* stream) {
+    VQW_CHECK(embed && labels && codebook_kd && loss && coef && ws && B > 0 && HW > 0 && D > 0 && K > 0,
+              "vqw_cross_loss_fwd: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_cross_ws_bytes(B, K, HW), "vqw_cross_loss_fwd: workspace too small");
+    VQW_CHECK(K <= 8192, "vqw_cross_loss_fwd: K too large");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = cl_splits(B, HW);
+    k_cross_partial<<<dim3(splits, B), CL_BLOCK, 2 * K * sizeof(float), st>>>(embed, labels, codebook_kd, (float*)ws, HW, D, K, splits);
+    k_cross_finalize<<<1, 256, 0, st>>>((const float*)ws, loss, coef, B * K, K, splits);
+    VQW_LAUNCH_CHECK("vqw_cross_loss_fwd");
+    return VQW_OK;
+}
+extern "C" int vqw_cross_loss_dense_fwd(const float* embed, const float* r_nchw, const float* codebook_kd, float* loss,
+                                        float* coef, void* ws, size_t ws_bytes, int B, long HW, int D, int K, void* stream) {
+    VQW_CHECK(embed && r_nchw && codebook_kd && loss && coef && ws && B > 0 && HW > 0 && D > 0 && K > 0,
+              "vqw_cross_loss_dense_fwd: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_cross_ws_bytes(B, K, HW), "vqw_cross_loss_dense_fwd: workspace too small");
+    VQW_CHECK(K <= 8192, "vqw_cross_loss_dense_fwd: K too large");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = cl_splits(B, HW);
+    k_cross_partial_dense<<<dim3(splits, B), CL_BLOCK, 2 * K * sizeof(float), st>>>(embed, r_nchw, codebook_kd, (float*)ws, HW, D, K, splits);
+    k_cross_finalize<<<1, 256, 0, st>>>((const float*)ws, loss, coef, B * K, K, splits);
+    VQW_LAUNCH_CHECK("vqw_cross_loss_dense_fwd");
+    return VQW_OK;
+}
+
+__global__ void k_cross_bwd(const float* __restrict__ embed, const int32_t* __restrict__ labels, const float* __restrict__ cb,
+                            const float* __restrict__ coef, const float* __restrict__ gl, float* __restrict__ ge, long total,
+                            long HW, int D, int K) {
+    float g2 = 2.f * gl[0];
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long p = i / D;
+        int d = (int)(i % D);
+        int l = labels[p];
+        float v = 0.f;
+        if (l >= 1 && l <= K) {
+            int b = (int)(p / HW);
+            v = g2 * coef[b * K + (l - 1)] * (embed[i] - cb[(long)(l - 1) * D + d]);
+        }
+        ge[i] = v;
+    }
+}
+extern "C" int vqw_cross_loss_bwd(const float* embed, const int32_t* labels, const float* codebook_kd, const float* coef,
+                                  const float* gloss, float* gembed, int B, long HW, int D, int K, void* stream) {
+    VQW_CHECK(embed && labels && codebook_kd && coef && gloss && gembed && B > 0 && HW > 0 && D > 0 && K > 0,
+              "vqw_cross_loss_bwd: bad arguments");
+    long total = (long)B * HW * D;
+    k_cross_bwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(embed, labels, codebook_kd, coef, gloss, gembed, total, HW, D, K);
+    VQW_LAUNCH_CHECK("vqw_cross_loss_bwd");
+    return VQW_OK;
+}
+__global__ void k_cross_bwd_dense(const float* __restrict__ embed, const float* __restrict__ r, const float* __restrict__ cb,
+                                  const float* __restrict__ coef, const float* __restrict__ gl, float* __restrict__ ge,
+                                  long total, long HW, int D, int K) {
+    float g2 = 2.f * gl[0];
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long p = i / D;
+        int d = (int)(i % D);
+        int b = (int)(p / HW);
+        long pp = p % HW;
+        float e = embed[i];
+        float v = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float w = r[((long)b * K + k) * HW + pp];
+            if (w != 0.f) v += w * coef[b * K + k] * (e - cb[(long)k * D + d]);
+        }
+        ge[i] = g2 * v;
+    }
+}
+extern "C" int vqw_cross_loss_dense_bwd(const float* embed, const float* r_nchw, const float* codebook_kd, const float* coef,
+                                        const float* gloss, float* gembed, int B, long HW, int D, int K, void* stream) {
+    VQW_CHECK(embed && r_nchw && codebook_kd && coef && gloss && gembed && B > 0 && HW > 0 && D > 0 && K > 0,
+              "vqw_cross_loss_dense_bwd: bad arguments");
+    long total = (long)B * HW * D;
+    k_cross_bwd_dense<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(embed, r_nchw, codebook_kd, coef, gloss, gembed, total, HW, D, K);
+    VQW_LAUNCH_CHECK("vqw_cross_loss_dense_bwd");
+    return VQW_OK;
+}
+
+// embed_loss.py:68-88.  Single block; K^2 pairs (i == j included, each contributing (2*margin)^2).
+__global__ void k_codebook_losses(const float* __restrict__ cb, float margin, float* __restrict__ l_dist,
+                                  float* __restrict__ l_reg, int D, int K) {
+    __shared__ double s_a[16], s_b[16];
+    double dsum = 0.0, rsum = 0.0;
+    long pairs = (long)K * K;
+    for (long ij = threadIdx.x; ij < pairs; ij += blockDim.x) {
+        int i = (int)(ij / K), j = (int)(ij % K);
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) { float a = cb[(long)i * D + d] - cb[(long)j * D + d]; s = fmaf(a, a, s); }
+        float h = 2.f * margin - sqrtf(s);
+        h = h > 0.f ? h : 0.f;
+        dsum += (double)(h * h);
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) { float a = cb[(long)k * D + d]; s = fmaf(a, a, s); }
+        rsum += (double)sqrtf(s);
+    }
+    dsum = wave_sum_d(dsum);
+    rsum = wave_sum_d(rsum);
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = dsum; s_b[threadIdx.x >> 6] = rsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += s_a[w]; b += s_b[w]; }
+        l_dist[0] = (float)(a / (2.0 * K * (K - 1)));
+        l_reg[0] = (float)(b / K);
+    }
+}
+extern "C" int vqw_codebook_losses(const float* codebook_kd, float margin, float* l_dist, float* l_reg, int D, int K, void* stream) {
+    VQW_CHECK(codebook_kd && l_dist && l_reg && D > 0 && K > 1, "vqw_codebook_losses: bad arguments (K must be > 1)");
+    k_codebook_losses<<<1, 1024, 0, (hipStream_t)stream>>>(codebook_kd, margin, l_dist, l_reg, D, K);
+    VQW_LAUNCH_CHECK("vqw_codebook_losses");
+    return VQW_OK;
+}
+
+// onehot.py:11-20: labels [B][HW] -> out[B][n_classes][HW] float (NCHW, as the reference returns it)
+__global__ void k_onehot(const int32_t* __restrict__ labels, float* __restrict__ out, long total, long HW, int nc) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long p = i % HW;
+        long bc = i / HW;
+        int c = (int)(bc % nc);
+        long b = bc / nc;
+        out[i] = labels[b * HW + p] == c ? 1.f : 0.f;
+    }
+}
+extern "C" int vqw_onehot(const int32_t* labels, float* out_nchw, int B, long HW, int n_classes, void* stream) {
+    VQW_CHECK(labels && out_nchw && B > 0 && HW > 0 && n_classes > 0, "vqw_onehot: bad arguments");
+    long total = (long)B * n_classes * HW;
+    k_onehot<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(labels, out_nchw, total, HW, n_classes);
+    VQW_LAUNCH_CHECK("vqw_onehot");
+    return VQW_OK;
+}
+
+// Exact-integer cross-view id map for identity / horizontal-flip views (single_window_trainer.py:91-96 with
+// flip transforms): out[b][h][w] = ids[b][h][W-1-w], zero inside `border` pixels of the frame.
+__global__ void k_flip_labels(const int64_t* __restrict__ ids, int32_t* __restrict__ out, int border, long total, int H, int W) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int w = (int)(i % W);
+        long r = i / W;
+        int h = (int)(r % H);
+        int v = (int)ids[r * W + (W - 1 - w)];
+        if (h < border || h >= H - border || w < border || w >= W - border) v = 0;
+        out[i] = v;
+    }
+}
+extern "C" int vqw_flip_labels(const int64_t* ids, int32_t* out, int border, int B, int H, int W, void* stream) {
+    VQW_CHECK(ids && out && B > 0 && H > 0 && W > 0 && border >= 0, "vqw_flip_labels: bad arguments");
+    long total = (long)B * H * W;
+    k_flip_labels<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(ids, out, border, total, H, W);
+    VQW_LAUNCH_CHECK("vqw_flip_labels");
+    return VQW_OK;
+}

@@ -1,0 +1,371 @@
+// InstanceNorm2d(+ReLU) and StyledDenorm (BatchNorm2d(affine=False) * (1+gamma) + beta) kernels, NHWC fp32.
+//
+// All statistics use a deterministic two-stage reduction: stage 1 writes double partials
+// part[n][split][c][2] (fixed pixel ranges per block, fixed tree inside the block), stage 2 sums the
+// partials in index order.  No float atomics -> bitwise reproducible run to run.
+#include "common.h"
+#include "../../include/vqwnet_hip.h"
+
+#define PLANE_MAX_SPLITS 64
+
+static inline int plane_splits(int N, int HW) {
+    // enough blocks to fill 256 CUs a few times over, but >= 256 pixels per block
+    int s = ceil_div(2048, N);
+    int cap = imax(1, HW / 256);
+    s = imin(imin(s, cap), PLANE_MAX_SPLITS);
+    return imax(s, 1);
+}
+
+static inline size_t plane_part_bytes(int N, int C) { return (size_t)N * PLANE_MAX_SPLITS * C * 2 * sizeof(double); }
+// partial sums [N][MAX_SPLITS][C][2] doubles, followed by [N][C][2] floats of finalised means
+extern "C" size_t vqw_plane_ws_bytes(int N, int C, int HW) {
+    (void)HW;
+    return plane_part_bytes(N, C) + (size_t)N * C * 2 * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic per-(n,c) two-quantity plane reduction.  Functor F: (x-element index i, n, c) -> (a, b).
+// Block layout: tc = threads along channels (min(C,256)), rows = 256/tc pixel rows per pass.
+template <class F>
+__global__ void __launch_bounds__(256) k_plane_reduce(F f, double* __restrict__ part, int HW, int C, int splits) {
+    __shared__ double sa[256], sb[256];
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int tcn = C < 256 ? C : 256;
+    const int rows = 256 / tcn;
+    const int t = threadIdx.x;
+    const int tc = t % tcn, tr = t / tcn;
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = s * per;
+    const int p1 = (p0 + per < HW) ? p0 + per : HW;
+    const bool active = tr < rows;
+    for (int cb = 0; cb < C; cb += tcn) {
+        const int c = cb + tc;
+        double a = 0.0, b = 0.0;
+        if (active && c < C) {
+            for (int p = p0 + tr; p < p1; p += rows) {
+                long i = ((long)n * HW + p) * C + c;
+                float va, vb;
+                f(i, n, c, va, vb);
+                a += (double)va;
+                b += (double)vb;
+            }
+        }
+        sa[t] = a;
+        sb[t] = b;
+        __syncthreads();
+        if (tr == 0 && c < C) {
+            for (int r = 1; r < rows; ++r) { a += sa[r * tcn + tc]; b += sb[r * tcn + tc]; }
+            double* o = part + (((long)n * splits + s) * C + c) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// InstanceNorm
+struct FStats {
+    const float* x;
+    __device__ void operator()(long i, int, int, float& a, float& b) const { float v = x[i]; a = v; b = v * v; }
+};
+
+__global__ void k_inorm_finalize(const double* __restrict__ part, float* __restrict__ mr, int NC, int C, int splits,
+                                 double inv_hw, float eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    int n = i / C, c = i % C;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < splits; ++s) {
+        const double* o = part + (((long)n * splits + s) * C + c) * 2;
+        a += o[0];
+        b += o[1];
+    }
+    double mean = a * inv_hw;
+    double var = b * inv_hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <int RELU>
+__global__ void k_inorm_apply(const float* __restrict__ x, const float* __restrict__ mr, float* __restrict__ y,
+                              long total, int HW, int C, int ycs, int yco) {
+    long stride = (long)gridDim.x * blockDim.x;
+    long plane = (long)HW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        int n = (int)(i / plane);
+        const float* m = mr + 2 * ((long)n * C + c);
+        float v = (x[i] - m[0]) * m[1];
+        y[(i / C) * ycs + yco + c] = RELU ? fmaxf(v, 0.f) : v;
+    }
+}
+
+extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, void* ws,
+                             size_t ws_bytes, int N, int HW, int C, float eps, int relu, void* stream) {
+    VQW_CHECK(x && y && mean_rstd && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd: bad arguments");
+    VQW_CHECK(y_coff >= 0 && y_coff + C <= y_cstride, "vqw_inorm_fwd: output channel slice [%d,%d) outside stride %d", y_coff, y_coff + C, y_cstride);
+    VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_inorm_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = plane_splits(N, HW);
+    FStats f{x};
+    k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    k_inorm_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>((const double*)ws, mean_rstd, N * C, C, splits,
+                                                                 1.0 / (double)HW, eps);
+    long total = (long)N * HW * C;
+    if (relu) k_inorm_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
+    else k_inorm_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
+    VQW_LAUNCH_CHECK("vqw_inorm_fwd");
+    return VQW_OK;
+}
+
+// backward: ghat = gy * [xhat > 0] (relu) ; dx = rstd * (ghat - mean(ghat) - xhat * mean(ghat*xhat))
+template <int RELU>
+struct FInBwd {
+    const float* x;
+    const float* mr;
+    const float* gy;
+    int C, gcs, gco;
+    __device__ void operator()(long i, int n, int c, float& a, float& b) const {
+        const float* m = mr + 2 * ((long)n * C + c);
+        float xh = (x[i] - m[0]) * m[1];
+        float g = gy[(i / C) * gcs + gco + c];
+        if (RELU && !(xh > 0.f)) g = 0.f;
+        a = g;
+        b = g * xh;
+    }
+};
+
+__global__ void k_plane_sum_finalize(const double* __restrict__ part, float* __restrict__ out, int NC, int C, int splits,
+                                     double scale) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    int n = i / C, c = i % C;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < splits; ++s) {
+        const double* o = part + (((long)n * splits + s) * C + c) * 2;
+        a += o[0];
+        b += o[1];
+    }
+    out[2 * i] = (float)(a * scale);
+    out[2 * i + 1] = (float)(b * scale);
+}
+
+template <int RELU>
+__global__ void k_inorm_bwd_apply(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gy,
+                                  const float* __restrict__ means, float* __restrict__ gx, long total, int HW, int C,
+                                  int gcs, int gco) {
+    long stride = (long)gridDim.x * blockDim.x;
+    long plane = (long)HW * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        int n = (int)(i / plane);
+        long k = 2 * ((long)n * C + c);
+        float r = mr[k + 1];
+        float xh = (x[i] - mr[k]) * r;
+        float g = gy[(i / C) * gcs + gco + c];
+        if (RELU && !(xh > 0.f)) g = 0.f;
+        gx[i] = r * (g - means[k] - xh * means[k + 1]);
+    }
+}
+
+extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
+                             float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream) {
+    VQW_CHECK(x && mean_rstd && gy && gx && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_bwd: bad arguments");
+    VQW_CHECK(gy_coff >= 0 && gy_coff + C <= gy_cstride, "vqw_inorm_bwd: gradient channel slice outside stride");
+    size_t need = vqw_plane_ws_bytes(N, C, HW);
+    VQW_CHECK(ws_bytes >= need, "vqw_inorm_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = plane_splits(N, HW);
+    double* part = (double*)ws;
+    float* means = (float*)((char*)ws + plane_part_bytes(N, C));
+    long total = (long)N * HW * C;
+    if (relu) {
+        FInBwd<1> f{x, mean_rstd, gy, C, gy_cstride, gy_coff};
+        k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
+    } else {
+        FInBwd<0> f{x, mean_rstd, gy, C, gy_cstride, gy_coff};
+        k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
+    }
+    k_plane_sum_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, means, N * C, C, splits, 1.0 / (double)HW);
+    if (relu) k_inorm_bwd_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
+    else k_inorm_bwd_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
+    VQW_LAUNCH_CHECK("vqw_inorm_bwd");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm statistics (per channel over N*H*W) -> double sums[C][2] so ranks can be summed (SyncBN).
+__global__ void k_channel_sum_finalize(const double* __restrict__ part, double* __restrict__ sums, int C, int rows) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < rows; ++r) {
+        const double* o = part + ((long)r * C + c) * 2;
+        a += o[0];
+        b += o[1];
+    }
+    sums[2 * c] = a;
+    sums[2 * c + 1] = b;
+}
+
+extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size_t ws_bytes, int N, int HW, int C,
+                                    void* stream) {
+    VQW_CHECK(x && sums && ws && N > 0 && HW > 0 && C > 0, "vqw_bn_partial_stats: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_bn_partial_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = plane_splits(N, HW);
+    FStats f{x};
+    k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    k_channel_sum_finalize<<<ceil_div(C, 256), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    VQW_LAUNCH_CHECK("vqw_bn_partial_stats");
+    return VQW_OK;
+}
+
+__global__ void k_bn_finalize(const double* __restrict__ sums, double count, float* __restrict__ mr, float* __restrict__ rm,
+                              float* __restrict__ rv, float momentum, float eps, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double mean = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[2 * c] = (float)mean;
+    mr[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) {
+        double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+        rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+    }
+}
+extern "C" int vqw_bn_finalize(const double* sums, double count, float* mean_rstd, float* running_mean,
+                               float* running_var, float momentum, float eps, int C, void* stream) {
+    VQW_CHECK(sums && mean_rstd && count > 0 && C > 0, "vqw_bn_finalize: bad arguments");
+    VQW_CHECK((running_mean == nullptr) == (running_var == nullptr), "vqw_bn_finalize: running stats must both be set or both NULL");
+    k_bn_finalize<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, count, mean_rstd, running_mean, running_var,
+                                                                     momentum, eps, C);
+    VQW_LAUNCH_CHECK("vqw_bn_finalize");
+    return VQW_OK;
+}
+__global__ void k_bn_eval_stats(const float* __restrict__ rm, const float* __restrict__ rv, float* __restrict__ mr, float eps, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mr[2 * c] = rm[c];
+    mr[2 * c + 1] = 1.f / sqrtf(rv[c] + eps);
+}
+extern "C" int vqw_bn_eval_stats(const float* running_mean, const float* running_var, float* mean_rstd, float eps,
+                                 int C, void* stream) {
+    VQW_CHECK(running_mean && running_var && mean_rstd && C > 0, "vqw_bn_eval_stats: bad arguments");
+    k_bn_eval_stats<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(running_mean, running_var, mean_rstd, eps, C);
+    VQW_LAUNCH_CHECK("vqw_bn_eval_stats");
+    return VQW_OK;
+}
+
+template <int RELU>
+__global__ void k_spade_fwd(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float* __restrict__ y, long total, int C) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        float xh = (x[i] - mr[2 * c]) * mr[2 * c + 1];
+        float v = xh * (1.f + gamma[i]) + beta[i];
+        y[i] = RELU ? fmaxf(v, 0.f) : v;
+    }
+}
+extern "C" int vqw_spade_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, float* y,
+                             long P, int C, int relu, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && y && P > 0 && C > 0, "vqw_spade_fwd: bad arguments");
+    long total = P * C;
+    if (relu) k_spade_fwd<1><<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, mean_rstd, gamma, beta, y, total, C);
+    else k_spade_fwd<0><<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, mean_rstd, gamma, beta, y, total, C);
+    VQW_LAUNCH_CHECK("vqw_spade_fwd");
+    return VQW_OK;
+}
+
+// backward phase 1: g = gy * [out>0]; dgamma = g*xhat; dbeta = g; dxhat = g*(1+gamma);
+// per-channel sums of (dxhat, dxhat*xhat).  dgamma/dbeta are written as a side effect of the reduction.
+template <int RELU>
+struct FSpadeBwd {
+    const float* x;
+    const float* mr;
+    const float* gamma;
+    const float* beta;
+    const float* gy;
+    float* dgamma;
+    float* dbeta;
+    __device__ void operator()(long i, int, int c, float& a, float& b) const {
+        float xh = (x[i] - mr[2 * c]) * mr[2 * c + 1];
+        float ga = 1.f + gamma[i];
+        float g = gy[i];
+        if (RELU) {
+            float out = xh * ga + beta[i];
+            if (!(out > 0.f)) g = 0.f;
+        }
+        dgamma[i] = g * xh;
+        dbeta[i] = g;
+        float dxh = g * ga;
+        a = dxh;
+        b = dxh * xh;
+    }
+};
+extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                                    const float* gy, float* dgamma, float* dbeta, double* sums, void* ws,
+                                    size_t ws_bytes, int N, int HW, int C, int relu, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && gy && dgamma && dbeta && sums && ws && N > 0 && HW > 0 && C > 0,
+              "vqw_spade_bwd_reduce: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_spade_bwd_reduce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = plane_splits(N, HW);
+    if (relu) {
+        FSpadeBwd<1> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta};
+        k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    } else {
+        FSpadeBwd<0> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta};
+        k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    }
+    k_channel_sum_finalize<<<ceil_div(C, 256), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    VQW_LAUNCH_CHECK("vqw_spade_bwd_reduce");
+    return VQW_OK;
+}
+
+template <int RELU, int TRAIN>
+__global__ void k_spade_bwd_apply(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const float* __restrict__ gy, const double* __restrict__ sums,
+                                  double inv_count, float* __restrict__ gx, long total, int C) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        float r = mr[2 * c + 1];
+        float xh = (x[i] - mr[2 * c]) * r;
+        float ga = 1.f + gamma[i];
+        float g = gy[i];
+        if (RELU) {
+            float out = xh * ga + beta[i];
+            if (!(out > 0.f)) g = 0.f;
+        }
+        float dxh = g * ga;
+        if (TRAIN) {
+            float m1 = (float)(sums[2 * c] * inv_count);
+            float m2 = (float)(sums[2 * c + 1] * inv_count);
+            gx[i] = r * (dxh - m1 - xh * m2);
+        } else {
+            gx[i] = r * dxh;
+        }
+    }
+}
+extern "C" int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                                   const float* gy, const double* sums, double count, float* gx, long P, int C,
+                                   int relu, int training, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && gy && gx && P > 0 && C > 0, "vqw_spade_bwd_apply: bad arguments");
+    VQW_CHECK(!training || (sums && count > 0), "vqw_spade_bwd_apply: training needs sums and count");
+    long total = P * C;
+    hipStream_t st = (hipStream_t)stream;
+    int g = stream_grid(total, 256);
+    double ic = training ? 1.0 / count : 0.0;
+    if (relu && training) k_spade_bwd_apply<1, 1><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
+    else if (relu) k_spade_bwd_apply<1, 0><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
+    else if (training) k_spade_bwd_apply<0, 1><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
+    else k_spade_bwd_apply<0, 0><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
+    VQW_LAUNCH_CHECK("vqw_spade_bwd_apply");
+    return VQW_OK;
+}

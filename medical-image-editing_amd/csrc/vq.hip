@@ -1,0 +1,286 @@
+// Vector-quantisation kernels: nearest-codebook search, gather, commitment loss, EMA statistics.
+// Replaces networks/vq/vq_module.py:45-62 (_torch_knn), :168-202 (_quantize), :204-207 (lookup) and
+// networks/vq/grad_approximation.py:7-29 of the reference.  Rows are NHWC pixels: x[Npix][D].
+//
+// Score (same association order as the reference): s_k = ((2 * (e_k . x)) - |e_k|^2) - |x|^2, fp32 FMA
+// chain over d ascending; arg-max over k with ties to the LOWEST index.  The K x N score matrix, the N x K
+// one-hot and the D x N x K "embed_sum" GEMM of the reference are never materialised.
+#include "common.h"
+#include "../../include/vqwnet_hip.h"
+
+#define VQ_BLOCK 256
+#define VQ_LDS_FLOATS 15360  // 60 KiB of LDS for codebook + norms (+ privatised stats)
+
+static inline int vq_blocks(long Npix) { return (int)imin(2048, ceil_div(Npix, VQ_BLOCK)); }
+
+static inline bool vq_lds_codebook(int D, int K) { return (long)K * D + K <= VQ_LDS_FLOATS; }
+static inline bool vq_lds_stats(int D, int K) { return (long)K * D + K + (long)K * (D + 1) <= VQ_LDS_FLOATS; }
+
+extern "C" size_t vqw_vq_ws_bytes(long Npix, int D, int K) {
+    size_t nb = (size_t)vq_blocks(Npix);
+    // per-block commit partial (double) + per-block stats partials (float) or ONE global float accumulator
+    size_t rows = vq_lds_stats(D, K) ? nb : 1;
+    return ((nb * sizeof(double) + 255) / 256) * 256 + rows * (size_t)K * (D + 1) * sizeof(float) + 256;
+}
+
+// DT > 0: query row held in DT registers.  DT == 0: generic D (row re-read from global/L1).
+// LDS_CB: codebook + norms staged in LDS.  LDS_ST: EMA statistics privatised in LDS (per-block partials).
+template <int DT, bool LDS_CB, bool LDS_ST>
+__global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x, const float* __restrict__ embed,
+                                                     int64_t* __restrict__ ids, float* __restrict__ q,
+                                                     double* __restrict__ commit_part, float* __restrict__ stat_part,
+                                                     float* __restrict__ stat_global, long Npix, int D, int K, int want_stats,
+                                                     int id_base) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_cb = smem;                                   // [K][D] if LDS_CB
+    float* s_nrm = smem + (LDS_CB ? K * D : 0);           // [K]
+    float* s_st = s_nrm + K;                              // [K*(D+1)] if LDS_ST: counts[K] then sum[d][k]
+    __shared__ double s_red[VQ_BLOCK / 64];
+    const int t = threadIdx.x;
+    if (LDS_CB)
+        for (int i = t; i < K * D; i += VQ_BLOCK) s_cb[i] = embed[i];
+    if (LDS_ST && want_stats)
+        for (int i = t; i < K * (D + 1); i += VQ_BLOCK) s_st[i] = 0.f;
+    for (int k = t; k < K; k += VQ_BLOCK) {
+        float n2 = 0.f;
+        for (int d = 0; d < D; ++d) { float e = embed[k * D + d]; n2 = fmaf(e, e, n2); }
+        s_nrm[k] = n2;
+    }
+    __syncthreads();
+    const float* cb = LDS_CB ? s_cb : embed;
+    double csum = 0.0;
+    for (long p = (long)blockIdx.x * VQ_BLOCK + t; p < Npix; p += (long)gridDim.x * VQ_BLOCK) {
+        const float* xr = x + p * D;
+        float xv[DT > 0 ? DT : 1];
+        float x2 = 0.f;
+        if (DT > 0) {
+#pragma unroll
+            for (int d4 = 0; d4 < DT / 4; ++d4) {
+                float4 v = ((const float4*)xr)[d4];
+                xv[4 * d4] = v.x; xv[4 * d4 + 1] = v.y; xv[4 * d4 + 2] = v.z; xv[4 * d4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int d = 0; d < DT; ++d) x2 = fmaf(xv[d], xv[d], x2);
+        } else {
+            for (int d = 0; d < D; ++d) { float v = xr[d]; x2 = fmaf(v, v, x2); }
+        }
+        float best = -INFINITY;
+        int bi = 0;
+        for (int k = 0; k < K; ++k) {
+            const float* e = cb + k * D;
+            float dot = 0.f;
+            if (DT > 0) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d) dot = fmaf(e[d], xv[d], dot);
+            } else {
+                for (int d = 0; d < D; ++d) dot = fmaf(e[d], xr[d], dot);
+            }
+            float s = (2.f * dot - s_nrm[k]) - x2;
+            if (s > best) { best = s; bi = k; }
+        }
+        ids[p] = (int64_t)(bi + id_base);
+        const float* e = cb + bi * D;
+        float* qr = q + p * D;
+        float c = 0.f;
+        if (DT > 0) {
+#pragma unroll
+            for (int d4 = 0; d4 < DT / 4; ++d4) {
+                float4 o;
+                o.x = e[4 * d4]; o.y = e[4 * d4 + 1]; o.z = e[4 * d4 + 2]; o.w = e[4 * d4 + 3];
+                ((float4*)qr)[d4] = o;
+                float a0 = xv[4 * d4] - o.x, a1 = xv[4 * d4 + 1] - o.y, a2 = xv[4 * d4 + 2] - o.z, a3 = xv[4 * d4 + 3] - o.w;
+                c = fmaf(a0, a0, c); c = fmaf(a1, a1, c); c = fmaf(a2, a2, c); c = fmaf(a3, a3, c);
+            }
+        } else {
+            for (int d = 0; d < D; ++d) { float ev = e[d]; qr[d] = ev; float a = xr[d] - ev; c = fmaf(a, a, c); }
+        }
+        csum += (double)c;
+        if (want_stats) {
+            float* st = LDS_ST ? s_st : stat_global;
+            atomicAdd(st + bi, 1.f);
+            if (DT > 0) {
+#pragma unroll
+                for (int d = 0; d < DT; ++d) atomicAdd(st + K + d * K + bi, xv[d]);
+            } else {
+                for (int d = 0; d < D; ++d) atomicAdd(st + K + d * K + bi, xr[d]);
+            }
+        }
+    }
+    csum = wave_sum_d(csum);
+    if ((t & 63) == 0) s_red[t >> 6] = csum;
+    __syncthreads();
+    if (t == 0) {
+        double a = 0.0;
+        for (int w = 0; w < VQ_BLOCK / 64; ++w) a += s_red[w];
+        commit_part[blockIdx.x] = a;
+    }
+    if (LDS_ST && want_stats) {
+        float* o = stat_part + (long)blockIdx.x * K * (D + 1);
+        for (int i = t; i < K * (D + 1); i += VQ_BLOCK) o[i] = s_st[i];
+    }
+}
+
+__global__ void k_vq_finalize(const double* __restrict__ commit_part, const float* __restrict__ stat_part, int nblocks,
+                              int nstat_rows, float* __restrict__ commit, double* __restrict__ stats, int KD1, double inv_numel) {
+    __shared__ double s_red[4];
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0) {
+        double a = 0.0;
+        for (int i = t; i < nblocks; i += blockDim.x) a += commit_part[i];
+        a = wave_sum_d(a);
+        if ((t & 63) == 0) s_red[t >> 6] = a;
+        __syncthreads();
+        if (t == 0) commit[0] = (float)((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_numel);
+    }
+    if (stats) {
+        for (int i = blockIdx.x * blockDim.x + t; i < KD1; i += gridDim.x * blockDim.x) {
+            double a = 0.0;
+            for (int b = 0; b < nstat_rows; ++b) a += (double)stat_part[(long)b * KD1 + i];
+            stats[i] = a;
+        }
+    }
+}
+
+template <int DT>
+static int launch_vq(const float* x, const float* embed, int64_t* ids, float* q, double* cpart, float* spart, float* sglob,
+                     long Npix, int D, int K, int want, int id_base, bool lds_cb, bool lds_st, int nb, size_t lds_bytes,
+                     hipStream_t st) {
+    if (lds_cb && lds_st) k_vq_fwd<DT, true, true><<<nb, VQ_BLOCK, lds_bytes, st>>>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base);
+    else if (lds_cb) k_vq_fwd<DT, true, false><<<nb, VQ_BLOCK, lds_bytes, st>>>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base);
+    else k_vq_fwd<DT, false, false><<<nb, VQ_BLOCK, lds_bytes, st>>>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base);
+    return 0;
+}
+
+extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int id_base, float* q, float* commit, double* stats,
+                          void* ws, size_t ws_bytes, long Npix, int D, int K, void* stream) {
+    VQW_CHECK(x && embed && ids && q && commit && ws && Npix > 0 && D > 0 && K > 0, "vqw_vq_fwd: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_vq_ws_bytes(Npix, D, K), "vqw_vq_fwd: workspace too small");
+    VQW_CHECK(K <= 8192, "vqw_vq_fwd: dict_size %d exceeds the supported 8192", K);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = vq_blocks(Npix);
+    const int KD1 = K * (D + 1);
+    double* cpart = (double*)ws;
+    float* spart = (float*)((char*)ws + (((size_t)nb * sizeof(double) + 255) / 256) * 256);
+    VQW_CHECK((((uintptr_t)x | (uintptr_t)q) & 15) == 0, "vqw_vq_fwd: x and q must be 16-byte aligned");
+    bool lds_cb = vq_lds_codebook(D, K);
+    bool lds_st = vq_lds_stats(D, K);
+    size_t lds_floats = (size_t)K + (lds_cb ? (size_t)K * D : 0) + (lds_st ? (size_t)KD1 : 0);
+    int want = stats != nullptr;
+    float* sglob = spart;  // global accumulator (row 0) when not privatised
+    if (want && !lds_st) {
+        hipError_t e = hipMemsetAsync(sglob, 0, (size_t)KD1 * sizeof(float), st);
+        if (e != hipSuccess) { vqw_set_error("vqw_vq_fwd: memset failed"); return VQW_ERR_HIP; }
+    }
+    size_t lb = lds_floats * sizeof(float);
+    if (D == 16) launch_vq<16>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
+    else if (D == 32) launch_vq<32>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
+    else if (D == 64) launch_vq<64>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
+    else launch_vq<0>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
+    VQW_LAUNCH_CHECK("vqw_vq_fwd");
+    k_vq_finalize<<<imax(1, imin(64, ceil_div(KD1, 256))), 256, 0, st>>>(cpart, spart, nb, lds_st ? nb : 1, commit,
+                                                                         want ? stats : nullptr, KD1,
+                                                                         1.0 / ((double)Npix * D));
+    VQW_LAUNCH_CHECK("vqw_vq_finalize");
+    return VQW_OK;
+}
+
+// EMA (vq_module.py:132-136,195-196) + Laplace-smoothed renormalisation (:198-200); single small block.
+__global__ void k_vq_ema(const double* __restrict__ stats, float* __restrict__ embed, float* __restrict__ cs,
+                         float* __restrict__ ea, float m, float eps, float sum_scale, int D, int K) {
+    __shared__ double s_red[4];
+    __shared__ float s_n;
+    const int t = threadIdx.x;
+    const float om = 1.f - m;
+    double part = 0.0;
+    for (int k = t; k < K; k += blockDim.x) {
+        float c = cs[k] * m + om * (float)stats[k];
+        cs[k] = c;
+        part += (double)c;
+    }
+    for (int i = t; i < D * K; i += blockDim.x) ea[i] = ea[i] * m + om * ((float)stats[K + i] * sum_scale);
+    part = wave_sum_d(part);
+    if ((t & 63) == 0) s_red[t >> 6] = part;
+    __syncthreads();
+    if (t == 0) s_n = (float)(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+    __syncthreads();
+    const float n = s_n;
+    for (int i = t; i < D * K; i += blockDim.x) {
+        int k = i / D, d = i % D;
+        float csn = n * (cs[k] + eps) / (n + (float)K * eps);
+        embed[i] = ea[d * K + k] / csn;
+    }
+}
+extern "C" int vqw_vq_ema_update(const double* stats, float* embed, float* cluster_size, float* embed_avg, float momentum,
+                                 float eps, float sum_scale, int D, int K, void* stream) {
+    VQW_CHECK(stats && embed && cluster_size && embed_avg && D > 0 && K > 0, "vqw_vq_ema_update: bad arguments");
+    k_vq_ema<<<1, 256, 0, (hipStream_t)stream>>>(stats, embed, cluster_size, embed_avg, momentum, eps, sum_scale, D, K);
+    VQW_LAUNCH_CHECK("vqw_vq_ema_update");
+    return VQW_OK;
+}
+
+__global__ void k_vq_lookup(const int64_t* __restrict__ ids, const float* __restrict__ embed, const uint8_t* __restrict__ mask,
+                            const float* __restrict__ scale, float* __restrict__ out, long total, int D, int K) {
+    long stride = (long)gridDim.x * blockDim.x;
+    float sc = scale ? scale[0] : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        long p = i / D;
+        int d = (int)(i % D);
+        int64_t k = ids[p];
+        float v = (k >= 0 && k < K) ? embed[k * D + d] : 0.f;
+        if (mask) v = mask[p] ? v * sc : 0.f;
+        out[i] = v;
+    }
+}
+extern "C" int vqw_vq_lookup(const int64_t* ids, const float* embed, const uint8_t* mask, const float* scale_dev, float* out,
+                             long Npix, int D, int K, void* stream) {
+    VQW_CHECK(ids && embed && out && Npix > 0 && D > 0 && K > 0, "vqw_vq_lookup: bad arguments");
+    long total = Npix * D;
+    k_vq_lookup<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(ids, embed, mask, scale_dev, out, total, D, K);
+    VQW_LAUNCH_CHECK("vqw_vq_lookup");
+    return VQW_OK;
+}
+
+__global__ void k_vq_bwd(const float* __restrict__ x, const float* __restrict__ q, const float* __restrict__ gq,
+                         const float* __restrict__ gc, float* __restrict__ gx, long n, float two_over_n) {
+    float s = gc ? gc[0] * two_over_n : 0.f;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float g = gq ? gq[i] : 0.f;
+        gx[i] = fmaf(s, x[i] - q[i], g);
+    }
+}
+extern "C" int vqw_vq_bwd(const float* x, const float* q, const float* g_q, const float* g_commit, float* gx, long numel,
+                          void* stream) {
+    VQW_CHECK(x && q && gx && numel > 0, "vqw_vq_bwd: bad arguments");
+    k_vq_bwd<<<stream_grid(numel, 256), 256, 0, (hipStream_t)stream>>>(x, q, g_q, g_commit, gx, numel, 2.0f / (float)numel);
+    VQW_LAUNCH_CHECK("vqw_vq_bwd");
+    return VQW_OK;
+}
+
+// run_recon.py:179-192: mask = (map != 0); ids0 = max(map,1)-1; scale = numel / sum(mask).  One block.
+__global__ void k_mask_scale(const int64_t* __restrict__ lab, uint8_t* __restrict__ mask, int64_t* __restrict__ ids0,
+                             float* __restrict__ scale, long n) {
+    __shared__ unsigned long long s_red[16];
+    unsigned long long cnt = 0;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+        int64_t l = lab[i];
+        uint8_t m = l != 0;
+        mask[i] = m;
+        ids0[i] = (l > 1 ? l : 1) - 1;
+        cnt += m;
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += s_red[w];
+        scale[0] = (float)n / (float)a;
+    }
+}
+extern "C" int vqw_mask_scale(const int64_t* label_map, uint8_t* mask, int64_t* ids0, float* scale_dev, long n, void* stream) {
+    VQW_CHECK(label_map && mask && ids0 && scale_dev && n > 0, "vqw_mask_scale: bad arguments");
+    k_mask_scale<<<1, 1024, 0, (hipStream_t)stream>>>(label_map, mask, ids0, scale_dev, n);
+    VQW_LAUNCH_CHECK("vqw_mask_scale");
+    return VQW_OK;
+}

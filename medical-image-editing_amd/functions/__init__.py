@@ -1,0 +1,3 @@
+"""Drop-in `functions` package (reference: functions/__init__.py): losses of the first training step."""
+from .embed_loss import EmbeddingLoss  # noqa: F401
+from .onehot import OneHotEncoder  # noqa: F401

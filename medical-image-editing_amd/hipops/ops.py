@@ -1,0 +1,610 @@
+"""Differentiable operators over the C ABI of libvqwnet_hip.so.
+
+Every function takes / returns torch tensors that live on a ROCm device; PyTorch is
+used only for device memory (caching allocator), the current stream and the
+autograd tape.  All arithmetic happens in the hand-written HIP kernels; a missing
+library or a CPU tensor raises (no eager fallback).
+
+4-D activations are logically NCHW and physically NHWC (torch.channels_last).
+Conv weights are logically OIHW and physically OHWI (channels_last too).
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+CL = torch.channels_last
+
+
+def _L():
+    return _lib.load()
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("hipops operators need tensors on a ROCm device (got %s); "
+                               "there is no CPU fallback" % t.device)
+
+
+def nhwc(x):
+    """Dense fp32 NHWC view of a 4-D tensor (no copy when it already is)."""
+    if x.dtype != torch.float32:
+        raise RuntimeError("hipops operators are fp32 (got %s)" % x.dtype)
+    if x.dim() != 4:
+        raise RuntimeError("expected a 4-D (N,C,H,W) tensor, got shape %s" % (tuple(x.shape),))
+    if not x.is_contiguous(memory_format=CL):
+        x = x.contiguous(memory_format=CL)
+    # size-1 dims make PyTorch's stride check ambiguous; normalise the strides we rely on
+    N, C, H, W = x.shape
+    if x.stride() != (H * W * C, 1, W * C, C):
+        x = x.as_strided((N, C, H, W), (H * W * C, 1, W * C, C))
+    return x
+
+
+def empty_nhwc(N, C, H, W, like):
+    return torch.empty((N, C, H, W), dtype=torch.float32, device=like.device, memory_format=CL)
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+def _flat(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected fp32")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+def _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dil, relu=False):
+    y = empty_nhwc(N, Cout, H, W, x0)
+    _lib.check(_L().vqw_conv2d_fwd(_p(x0), x0.shape[1], int(up0), _p(x1), 0 if x1 is None else x1.shape[1],
+                                   _p(w), _p(bias), _p(y), N, H, W, Cout, ks, dil, int(relu), _st()), "vqw_conv2d_fwd")
+    return y
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, dilation, up0, relu):
+        _dev(x0, x1, weight, bias)
+        x0 = nhwc(x0)
+        x1 = nhwc(x1) if x1 is not None else None
+        w = nhwc(weight)
+        Cout, Cin, ks, _ = weight.shape
+        N = x0.shape[0]
+        H, W = (x0.shape[2] * 2, x0.shape[3] * 2) if up0 else (x0.shape[2], x0.shape[3])
+        c1 = 0 if x1 is None else x1.shape[1]
+        if x0.shape[1] + c1 != Cin:
+            raise RuntimeError("conv2d: input channels %d+%d do not match weight %s" % (x0.shape[1], c1, tuple(weight.shape)))
+        if x1 is not None and (x1.shape[0] != N or x1.shape[2] != H or x1.shape[3] != W):
+            raise RuntimeError("conv2d: concat source shape %s does not match %s" % (tuple(x1.shape), (N, c1, H, W)))
+        if bias is not None:
+            bias = _flat(bias)
+        y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
+        ctx.save_for_backward(x0, x1, w, y if relu else None)
+        ctx.cfg = (dilation, up0, ks, N, H, W, Cout, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x0, x1, w, y_relu = ctx.saved_tensors
+        dilation, up0, ks, N, H, W, Cout, has_bias = ctx.cfg
+        L = _L()
+        gy = nhwc(gy)
+        if y_relu is not None:   # fused ReLU epilogue: mask the incoming gradient first
+            gm = torch.empty_like(y_relu, memory_format=CL)
+            _lib.check(L.vqw_relu_bwd(_p(y_relu), _p(gy), _p(gm), gy.numel(), _st()), "vqw_relu_bwd")
+            gy = gm
+        C0 = x0.shape[1]
+        C1 = 0 if x1 is None else x1.shape[1]
+        Cin = C0 + C1
+        g0 = g1 = gw = gb = None
+        need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        if need0 or (need1 and x1 is not None):
+            wt = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
+            _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(wt), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
+            g_full = empty_nhwc(N, Cin, H, W, gy)
+            _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
+                       "vqw_conv2d_fwd(dgrad)")
+            if not up0 and x1 is None:
+                g0 = g_full
+            else:
+                if need0:
+                    g0 = torch.empty_like(x0, memory_format=CL)
+                    _lib.check(L.vqw_input_grad_gather(_p(g_full), Cin, 0, C0, int(up0), _p(g0), 0, N, H, W, _st()),
+                               "vqw_input_grad_gather")
+                if need1 and x1 is not None:
+                    g1 = torch.empty_like(x1, memory_format=CL)
+                    _lib.check(L.vqw_input_grad_gather(_p(g_full), Cin, C0, C1, 0, _p(g1), 0, N, H, W, _st()),
+                               "vqw_input_grad_gather")
+        if needw or (needb and has_bias):
+            nb = L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks)
+            ws = _ws(nb, gy)
+            gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+            gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
+            _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
+                                          N, H, W, Cout, ks, dilation, _st()), "vqw_conv2d_wgrad")
+        return g0, g1, gw, gb, None, None, None
+
+
+def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False):
+    """'same' conv (k in {1,3}, stride 1) of the virtual input [up2x(x) | skip] (channel concat);
+    relu=True fuses nn.ReLU into the epilogue."""
+    return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu))
+
+
+# ----------------------------------------------------------------------------------------------
+# InstanceNorm (+ReLU)
+# ----------------------------------------------------------------------------------------------
+class _InstanceNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, relu, eps):
+        _dev(x)
+        x = nhwc(x)
+        N, C, H, W = x.shape
+        L = _L()
+        y = torch.empty_like(x, memory_format=CL)
+        mr = torch.empty(N * C * 2, dtype=torch.float32, device=x.device)
+        ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+        _lib.check(L.vqw_inorm_fwd(_p(x), _p(y), C, 0, _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, int(relu), _st()), "vqw_inorm_fwd")
+        ctx.save_for_backward(x, mr)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mr = ctx.saved_tensors
+        N, C, H, W = x.shape
+        L = _L()
+        gy = nhwc(gy)
+        gx = torch.empty_like(x, memory_format=CL)
+        ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+        _lib.check(L.vqw_inorm_bwd(_p(x), _p(mr), _p(gy), C, 0, _p(gx), _p(ws), ws.numel(), N, H * W, C, int(ctx.relu), _st()),
+                   "vqw_inorm_bwd")
+        return gx, None, None
+
+
+def instance_norm(x, relu=False, eps=1e-5):
+    return _InstanceNorm.apply(x, bool(relu), float(eps))
+
+
+class _InstanceNormCat(torch.autograd.Function):
+    """InstanceNorm(+ReLU) of several tensors written straight into the channel slices of ONE output
+    (the torch.cat of aspp.py:47 is never materialised as a separate pass)."""
+
+    @staticmethod
+    def forward(ctx, relu, eps, *xs):
+        _dev(*xs)
+        xs = [nhwc(x) for x in xs]
+        N, _, H, W = xs[0].shape
+        Ct = sum(x.shape[1] for x in xs)
+        L = _L()
+        y = empty_nhwc(N, Ct, H, W, xs[0])
+        mrs, off = [], 0
+        for x in xs:
+            C = x.shape[1]
+            if x.shape[0] != N or x.shape[2] != H or x.shape[3] != W:
+                raise RuntimeError("instance_norm_cat: shape mismatch")
+            mr = torch.empty(N * C * 2, dtype=torch.float32, device=x.device)
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+            _lib.check(L.vqw_inorm_fwd(_p(x), _p(y), Ct, off, _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, int(relu), _st()),
+                       "vqw_inorm_fwd")
+            mrs.append(mr)
+            off += C
+        ctx.save_for_backward(*xs, *mrs)
+        ctx.relu, ctx.n = relu, len(xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        xs, mrs = saved[:ctx.n], saved[ctx.n:]
+        gy = nhwc(gy)
+        N, Ct, H, W = gy.shape
+        L = _L()
+        outs, off = [], 0
+        for x, mr in zip(xs, mrs):
+            C = x.shape[1]
+            gx = torch.empty_like(x, memory_format=CL)
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+            _lib.check(L.vqw_inorm_bwd(_p(x), _p(mr), _p(gy), Ct, off, _p(gx), _p(ws), ws.numel(), N, H * W, C, int(ctx.relu), _st()),
+                       "vqw_inorm_bwd")
+            outs.append(gx)
+            off += C
+        return (None, None, *outs)
+
+
+def instance_norm_cat(xs, relu=True, eps=1e-5):
+    return _InstanceNormCat.apply(bool(relu), float(eps), *xs)
+
+
+# ----------------------------------------------------------------------------------------------
+# StyledDenorm core: BatchNorm2d(affine=False)(x) * (1 + gamma) + beta (+ReLU)
+# ----------------------------------------------------------------------------------------------
+def _dist_on():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _Spade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync):
+        _dev(x, gamma, beta)
+        x, gamma, beta = nhwc(x), nhwc(gamma), nhwc(beta)
+        N, C, H, W = x.shape
+        L = _L()
+        mr = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        count = float(N * H * W)
+        if training:
+            sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+            _lib.check(L.vqw_bn_partial_stats(_p(x), _p(sums), _p(ws), ws.numel(), N, H * W, C, _st()), "vqw_bn_partial_stats")
+            if sync and _dist_on():
+                # SyncBatchNorm semantics (run_vqwnet.py:121): global-batch statistics, one small all-reduce.
+                # Every rank holds the same per-rank batch (weak scaling), so the count needs no exchange.
+                dist.all_reduce(sums)
+                count *= dist.get_world_size()
+            _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
+                       "vqw_bn_finalize")
+        else:
+            _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
+        y = torch.empty_like(x, memory_format=CL)
+        _lib.check(L.vqw_spade_fwd(_p(x), _p(mr), _p(gamma), _p(beta), _p(y), N * H * W, C, int(relu), _st()), "vqw_spade_fwd")
+        ctx.save_for_backward(x, gamma, beta, mr)
+        ctx.cfg = (training, relu, count, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mr = ctx.saved_tensors
+        training, relu, count, sync = ctx.cfg
+        N, C, H, W = x.shape
+        L = _L()
+        gy = nhwc(gy)
+        dgamma = torch.empty_like(x, memory_format=CL)
+        dbeta = torch.empty_like(x, memory_format=CL)
+        gx = torch.empty_like(x, memory_format=CL)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+        _lib.check(L.vqw_spade_bwd_reduce(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(dgamma), _p(dbeta), _p(sums), _p(ws),
+                                          ws.numel(), N, H * W, C, int(relu), _st()), "vqw_spade_bwd_reduce")
+        if training and sync and _dist_on():
+            dist.all_reduce(sums)
+        _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(sums), count, _p(gx), N * H * W, C,
+                                         int(relu), int(training), _st()), "vqw_spade_bwd_apply")
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def spade_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, sync=True):
+    return _Spade.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu),
+                        bool(sync))
+
+
+# ----------------------------------------------------------------------------------------------
+# element-wise / pooling
+# ----------------------------------------------------------------------------------------------
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, relu):
+        _dev(a, b)
+        a, b = nhwc(a), nhwc(b)
+        if a.shape != b.shape:
+            raise RuntimeError("add: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        y = torch.empty_like(a, memory_format=CL)
+        _lib.check(_L().vqw_add(_p(a), _p(b), _p(y), a.numel(), int(relu), _st()), "vqw_add")
+        ctx.relu = relu
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.relu:
+            return gy, gy, None
+        (y,) = ctx.saved_tensors
+        gy = nhwc(gy)
+        gx = torch.empty_like(y, memory_format=CL)
+        _lib.check(_L().vqw_relu_bwd(_p(y), _p(gy), _p(gx), y.numel(), _st()), "vqw_relu_bwd")
+        return gx, gx, None
+
+
+def add(a, b, relu=False):
+    return _Add.apply(a, b, bool(relu))
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = nhwc(x)
+        N, C, H, W = x.shape
+        y = empty_nhwc(N, C, H // 2, W // 2, x)
+        _lib.check(_L().vqw_maxpool2_fwd(_p(x), _p(y), N, H, W, C, _st()), "vqw_maxpool2_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        N, C, H, W = x.shape
+        gy = nhwc(gy)
+        gx = torch.empty_like(x, memory_format=CL)
+        _lib.check(_L().vqw_maxpool2_bwd(_p(x), _p(gy), None, _p(gx), N, H, W, C, _st()), "vqw_maxpool2_bwd")
+        return gx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _Tanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = nhwc(x)
+        y = torch.empty_like(x, memory_format=CL)
+        _lib.check(_L().vqw_tanh_fwd(_p(x), _p(y), x.numel(), _st()), "vqw_tanh_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = nhwc(gy)
+        gx = torch.empty_like(y, memory_format=CL)
+        _lib.check(_L().vqw_tanh_bwd(_p(y), _p(gy), _p(gx), y.numel(), _st()), "vqw_tanh_bwd")
+        return gx
+
+
+def tanh(x):
+    return _Tanh.apply(x)
+
+
+def affine_(x, scale, shift):
+    """In-place x*scale+shift (utils norm/denorm, utils/__init__.py:81-92)."""
+    _dev(x)
+    if not (x.is_contiguous() or x.is_contiguous(memory_format=CL)):
+        raise RuntimeError("affine_: tensor must be dense")
+    _lib.check(_L().vqw_affine(_p(x), _p(x), float(scale), float(shift), x.numel(), _st()), "vqw_affine")
+    return x
+
+
+class _Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _dev(a, b)
+        a, b = nhwc(a), nhwc(b)
+        if a.shape != b.shape:
+            raise RuntimeError("mse_loss: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        L = _L()
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = _ws(L.vqw_reduce_ws_bytes(a.numel()), a)
+        _lib.check(L.vqw_mse_fwd(_p(a), _p(b), _p(out), _p(ws), ws.numel(), a.numel(), _st()), "vqw_mse_fwd")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = torch.empty_like(a, memory_format=CL)
+        _lib.check(_L().vqw_mse_bwd(_p(a), _p(b), _p(g), _p(ga), a.numel(), _st()), "vqw_mse_bwd")
+        return ga, None
+
+
+def mse_loss(a, b):
+    """F.mse_loss(a, b, reduction='mean'); gradient flows to `a` only (targets are data)."""
+    return _Mse.apply(a, b.detach())
+
+
+class _WeightedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        dev = terms[0].device
+        _dev(*terms)
+        terms = [t.reshape(()).contiguous() for t in terms]
+        ptrs = torch.tensor([t.data_ptr() for t in terms], dtype=torch.int64).to(dev, non_blocking=False)
+        w = torch.tensor(list(weights), dtype=torch.float32).to(dev)
+        out = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(_L().vqw_weighted_sum(_p(ptrs), _p(w), len(terms), _p(out), _st()), "vqw_weighted_sum")
+        ctx.weights = list(weights)
+        ctx.keep = terms
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = []
+        for wgt, need in zip(ctx.weights, ctx.needs_input_grad[1:]):
+            if not need:
+                gs.append(None)
+                continue
+            o = torch.empty((), dtype=torch.float32, device=g.device)
+            gc = g.contiguous()
+            _lib.check(_L().vqw_affine(_p(gc), _p(o), float(wgt), 0.0, 1, _st()), "vqw_affine")
+            gs.append(o)
+        return (None, *gs)
+
+
+def weighted_sum(terms, weights):
+    """sum_i weights[i] * terms[i] for 0-dim device tensors (single_window_trainer.py:131-137)."""
+    return _WeightedSum.apply(tuple(float(w) for w in weights), *terms)
+
+
+# ----------------------------------------------------------------------------------------------
+# vector quantisation
+# ----------------------------------------------------------------------------------------------
+class _VQ(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, embed, cluster_size, embed_avg, training, momentum, eps, dist_mode, id_base):
+        _dev(x, embed, cluster_size, embed_avg)
+        x = nhwc(x)
+        N, D, H, W = x.shape
+        K = embed.shape[0]
+        if embed.shape[1] != D:
+            raise RuntimeError("VQ: emb_dim %d does not match input channels %d" % (embed.shape[1], D))
+        L = _L()
+        npix = N * H * W
+        ids = torch.empty((N, H, W), dtype=torch.int64, device=x.device)
+        q = torch.empty_like(x, memory_format=CL)
+        commit = torch.empty((), dtype=torch.float32, device=x.device)
+        stats = torch.empty(K + D * K, dtype=torch.float64, device=x.device) if training else None
+        ws = _ws(L.vqw_vq_ws_bytes(npix, D, K), x)
+        if not (embed.is_contiguous() and cluster_size.is_contiguous() and embed_avg.is_contiguous()):
+            raise RuntimeError("VQ buffers must be contiguous")
+        _lib.check(L.vqw_vq_fwd(_p(x), _p(embed), _p(ids), int(id_base), _p(q), _p(commit), _p(stats), _p(ws), ws.numel(), npix, D, K, _st()),
+                   "vqw_vq_fwd")
+        if training:
+            scale = 1.0
+            if _dist_on() and dist_mode != "local":
+                if dist_mode == "global":
+                    dist.all_reduce(stats)              # counts and sums over the global batch
+                elif dist_mode == "reference":
+                    # vq_module.py:187-193: embed_sum rank-averaged, counts local (C3 quirk; C2's dead
+                    # N x K all-reduce is never reproduced)
+                    dist.all_reduce(stats[K:])
+                    scale = 1.0 / dist.get_world_size()
+                else:
+                    raise RuntimeError("unknown VQ dist_mode %r" % dist_mode)
+            _lib.check(L.vqw_vq_ema_update(_p(stats), _p(embed), _p(cluster_size), _p(embed_avg), momentum, eps, scale, D, K, _st()),
+                       "vqw_vq_ema_update")
+        ctx.save_for_backward(x, q)
+        ctx.mark_non_differentiable(ids)
+        return q, commit, ids
+
+    @staticmethod
+    def backward(ctx, gq, gcommit, _gids):
+        x, q = ctx.saved_tensors
+        gq = nhwc(gq) if gq is not None else None
+        gc = gcommit.contiguous() if gcommit is not None else None
+        gx = torch.empty_like(x, memory_format=CL)
+        _lib.check(_L().vqw_vq_bwd(_p(x), _p(q), _p(gq), _p(gc), _p(gx), x.numel(), _st()), "vqw_vq_bwd")
+        return gx, None, None, None, None, None, None, None, None
+
+
+def vq_quantize(x, embed, cluster_size, embed_avg, training, momentum, eps, dist_mode="global", id_base=0):
+    """-> (quantized with straight-through gradient, commit loss, ids (N,H,W) int64 = code + id_base, per pixel)."""
+    return _VQ.apply(x, embed, cluster_size, embed_avg, bool(training), float(momentum), float(eps), dist_mode, int(id_base))
+
+
+def vq_lookup(ids, embed, mask=None, scale=None):
+    """embed[ids] as (N,D,H,W) NHWC; optional mask (uint8 (N,H,W)) and device scalar scale."""
+    _dev(ids, embed)
+    if ids.dtype != torch.int64:
+        ids = ids.long()
+    ids = ids.contiguous()
+    N, H, W = ids.shape
+    K, D = embed.shape
+    out = empty_nhwc(N, D, H, W, embed)
+    _lib.check(_L().vqw_vq_lookup(_p(ids), _p(embed.contiguous()), _p(mask), _p(scale), _p(out), N * H * W, D, K, _st()),
+               "vqw_vq_lookup")
+    return out
+
+
+def mask_scale(label_map):
+    """run_recon.py:179-192: -> (mask uint8, ids0 int64, scale (1,) float32 = numel/sum(mask))."""
+    _dev(label_map)
+    lab = label_map.long().contiguous()
+    mask = torch.empty(lab.shape, dtype=torch.uint8, device=lab.device)
+    ids0 = torch.empty_like(lab)
+    scale = torch.empty(1, dtype=torch.float32, device=lab.device)
+    _lib.check(_L().vqw_mask_scale(_p(lab), _p(mask), _p(ids0), _p(scale), lab.numel(), _st()), "vqw_mask_scale")
+    return mask, ids0, scale
+
+
+# ----------------------------------------------------------------------------------------------
+# embedding loss
+# ----------------------------------------------------------------------------------------------
+class _CrossLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, embed, labels_or_r, codebook_kd, dense):
+        _dev(embed, labels_or_r, codebook_kd)
+        e = nhwc(embed)
+        B, D, H, W = e.shape
+        K = codebook_kd.shape[0]
+        cb = codebook_kd.detach().contiguous()
+        L = _L()
+        loss = torch.empty((), dtype=torch.float32, device=e.device)
+        coef = torch.empty(B * K, dtype=torch.float32, device=e.device)
+        ws = _ws(L.vqw_cross_ws_bytes(B, K, H * W), e)
+        if dense:
+            r = labels_or_r.contiguous()
+            if tuple(r.shape) != (B, K, H, W) or r.dtype != torch.float32:
+                raise RuntimeError("cross loss: r_ids must be float (B,K,H,W) = %s, got %s" % ((B, K, H, W), tuple(r.shape)))
+            _lib.check(L.vqw_cross_loss_dense_fwd(_p(e), _p(r), _p(cb), _p(loss), _p(coef), _p(ws), ws.numel(), B, H * W, D, K, _st()),
+                       "vqw_cross_loss_dense_fwd")
+        else:
+            r = labels_or_r.contiguous()
+            if tuple(r.shape) != (B, H, W) or r.dtype != torch.int32:
+                raise RuntimeError("cross loss: labels must be int32 (B,H,W)")
+            _lib.check(L.vqw_cross_loss_fwd(_p(e), _p(r), _p(cb), _p(loss), _p(coef), _p(ws), ws.numel(), B, H * W, D, K, _st()),
+                       "vqw_cross_loss_fwd")
+        ctx.save_for_backward(e, r, cb, coef)
+        ctx.dense = dense
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        e, r, cb, coef = ctx.saved_tensors
+        B, D, H, W = e.shape
+        K = cb.shape[0]
+        g = g.contiguous()
+        ge = torch.empty_like(e, memory_format=CL)
+        fn = _L().vqw_cross_loss_dense_bwd if ctx.dense else _L().vqw_cross_loss_bwd
+        _lib.check(fn(_p(e), _p(r), _p(cb), _p(coef), _p(g), _p(ge), B, H * W, D, K, _st()), "vqw_cross_loss_bwd")
+        return ge, None, None, None
+
+
+def cross_loss_labels(embed, labels, codebook_kd):
+    return _CrossLoss.apply(embed, labels, codebook_kd, False)
+
+
+def cross_loss_dense(embed, r, codebook_kd):
+    return _CrossLoss.apply(embed, r, codebook_kd, True)
+
+
+def codebook_losses(codebook_kd, margin):
+    """(l_dist, l_reg) of embed_loss.py:68-88; the codebook is a buffer -> no gradient."""
+    _dev(codebook_kd)
+    cb = codebook_kd.detach().contiguous()
+    K, D = cb.shape
+    ld = torch.empty((), dtype=torch.float32, device=cb.device)
+    lr = torch.empty((), dtype=torch.float32, device=cb.device)
+    _lib.check(_L().vqw_codebook_losses(_p(cb), float(margin), _p(ld), _p(lr), D, K, _st()), "vqw_codebook_losses")
+    return ld, lr
+
+
+def onehot(labels, n_classes):
+    _dev(labels)
+    lab = labels.to(torch.int32).contiguous()
+    B = lab.shape[0]
+    hw = lab.numel() // B
+    out = torch.empty((B, n_classes) + tuple(lab.shape[1:]), dtype=torch.float32, device=lab.device)
+    _lib.check(_L().vqw_onehot(_p(lab), _p(out), B, hw, n_classes, _st()), "vqw_onehot")
+    return out
+
+
+def flip_labels(ids, border=0):
+    """Cross-view id map for identity / h-flip views: int32 (B,H,W), 0 inside `border`."""
+    _dev(ids)
+    ids = ids.long().contiguous()
+    B, H, W = ids.shape
+    out = torch.empty((B, H, W), dtype=torch.int32, device=ids.device)
+    _lib.check(_L().vqw_flip_labels(_p(ids), _p(out), int(border), B, H, W, _st()), "vqw_flip_labels")
+    return out
+
+
+def set_conv_backend(mode):
+    """0 = auto (MFMA kernels where shapes allow), 1 = generic VALU kernels only (testing)."""
+    return _L().vqw_set_conv_backend(int(mode))

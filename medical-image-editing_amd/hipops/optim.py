@@ -1,0 +1,53 @@
+"""Adam over the fused HIP kernel (vqw_adam_step).
+
+Drop-in for the `torch.optim.Adam(params, lr, betas, weight_decay)` instances the
+reference builds in trainers/base.py:165-175: same constructor arguments, same update
+rule, same state_dict layout ('step', 'exp_avg', 'exp_avg_sq' per parameter).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.load()
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("hipops.Adam needs parameters on a ROCm device")
+                g = p.grad
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = 0
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                t = state["step"]
+                # element-wise update: any dense layout works as long as p, g, m, v share it
+                if g.stride() != p.stride():
+                    g = torch.empty_strided(p.size(), p.stride(), dtype=p.dtype, device=p.device).copy_(p.grad)
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                if m.stride() != p.stride() or v.stride() != p.stride():
+                    raise RuntimeError("Adam state layout does not match the parameter layout")
+                _lib.check(L.vqw_adam_step(ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
+                                           ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()), p.numel(),
+                                           group["lr"], b1, b2, group["eps"], group["weight_decay"],
+                                           1.0 - b1 ** t, 1.0 - b2 ** t, st), "vqw_adam_step")
+        return loss

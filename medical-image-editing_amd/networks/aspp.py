@@ -1,0 +1,31 @@
+"""Atrous spatial pyramid (reference: networks/aspp.py:10-47) on the HIP kernels."""
+import torch.nn as nn
+
+from hipops import ops
+from .blocks import Conv2d, InstanceNorm2d, FusedReLU
+
+
+class _ConvBnReLU(nn.Sequential):
+    """conv (no bias) -> InstanceNorm -> ReLU; the member is called 'bn' upstream although it is an InstanceNorm."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride, padding, dilation, relu=True):
+        super().__init__()
+        self.add_module("conv", Conv2d(in_ch, out_ch, kernel_size, stride, padding, dilation, bias=False))
+        self.add_module("bn", InstanceNorm2d(out_ch, relu=relu))
+        self.with_relu = relu
+        if relu:
+            self.add_module("relu", FusedReLU())
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_ch, out_ch, rates):
+        super().__init__()
+        self.stages = nn.Module()
+        self.stages.add_module("c0", _ConvBnReLU(in_ch, out_ch, 1, 1, 0, 1))
+        for i, rate in enumerate(rates):
+            self.stages.add_module("c{}".format(i + 1), _ConvBnReLU(in_ch, out_ch, 3, 1, padding=rate, dilation=rate))
+
+    def forward(self, x):
+        # every branch normalises straight into its channel slice of the concatenated output
+        raw = [stage.conv(x) for stage in self.stages.children()]
+        return ops.instance_norm_cat(raw, relu=True, eps=1e-5)

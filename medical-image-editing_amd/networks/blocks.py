@@ -1,0 +1,173 @@
+"""Building blocks of the VQ-W-Net on the MI355X HIP kernels.
+
+Same classes, constructor signatures, attribute names and state_dict keys as the
+reference's networks/blocks.py (UpBlock :9-18, ResBlock :21-36, DoubleConv :39-61,
+StyledDenorm :64-90, StyledResUpBlock :93-134); the forward passes call
+hipops.ops (hand-written HIP through the C ABI) instead of ATen.  nn.Upsample and
+torch.cat are folded into the consuming convolution's loader; ReLU is fused into
+the InstanceNorm / SPADE / conv-epilogue kernels.
+"""
+import torch
+import torch.nn as nn
+
+from hipops import ops
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d parameter holder (same init, same state_dict entries) whose forward is the HIP
+    implicit-GEMM convolution.  'same' padding, stride 1, kernel 1 or 3 only — all the path uses."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, bias=bias)
+        k, d = self.kernel_size[0], self.dilation[0]
+        if self.kernel_size[0] != self.kernel_size[1] or k not in (1, 3) or self.stride != (1, 1) \
+                or self.padding != (d * (k // 2),) * 2 or self.dilation[0] != self.dilation[1]:
+            raise NotImplementedError("HIP conv supports kernel 1/3, stride 1, padding = dilation*(k//2)")
+        # OHWI storage (channels_last); logical shape / state_dict unchanged
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
+
+    def forward(self, x, up2x=False, skip=None, relu=False):
+        return ops.conv2d(x, self.weight, self.bias, self.dilation[0], up2x=up2x, skip=skip, relu=relu)
+
+
+def conv3x3(in_channels, out_channels, stride=1, padding=1, bias=True):
+    return Conv2d(in_channels, out_channels, 3, stride, padding, bias=bias)
+
+
+class InstanceNorm2d(nn.Module):
+    """InstanceNorm2d(affine=False, track_running_stats=False), optionally with the following ReLU fused."""
+
+    def __init__(self, num_features, relu=False, eps=1e-5):
+        super().__init__()
+        self.num_features, self.relu, self.eps = num_features, relu, eps
+
+    def forward(self, x):
+        return ops.instance_norm(x, relu=self.relu, eps=self.eps)
+
+
+class FusedReLU(nn.Identity):
+    """Placeholder that keeps nn.Sequential indices (and so state_dict keys) equal to the reference's;
+    the ReLU itself runs inside the preceding normalisation kernel."""
+
+
+class UpBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, use_output_act=True):
+        super().__init__()
+        self.up_sample = nn.Upsample(scale_factor=2, mode='nearest')   # folded into the conv loader
+        self.double_conv = DoubleConv(in_channels, out_channels, use_output_act=use_output_act)
+
+    def forward(self, down_input, skip_input):
+        # channels = [up2x(down) | skip]; neither the up-sampled map nor the concat is materialised
+        return self.double_conv(down_input, up2x=True, skip=skip_input)
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.downsample = nn.Sequential(
+            Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False),
+            InstanceNorm2d(out_channels),
+        )
+        self.double_conv = DoubleConv(in_channels, out_channels)
+        self.down_sample = nn.MaxPool2d(2)
+        self.relu = nn.ReLU()
+
+    def forward(self, x):
+        identity = self.downsample(x)
+        out = ops.add(self.double_conv(x), identity, relu=True)
+        return ops.maxpool2(out), out
+
+
+class DoubleConv(nn.Module):
+    def __init__(self, in_channels, out_channels, use_output_act=True):
+        super().__init__()
+        layers = [
+            Conv2d(in_channels, out_channels, kernel_size=3, padding=1),
+            InstanceNorm2d(out_channels, relu=True),
+            FusedReLU(),
+            Conv2d(out_channels, out_channels, kernel_size=3, padding=1),
+        ]
+        if use_output_act:
+            layers += [InstanceNorm2d(out_channels, relu=True), FusedReLU()]
+        self.double_conv = nn.Sequential(*layers)
+
+    def forward(self, x, up2x=False, skip=None):
+        x = self.double_conv[0](x, up2x=up2x, skip=skip)
+        for layer in list(self.double_conv)[1:]:
+            x = layer(x)
+        return x
+
+
+class StyledDenorm(nn.Module):
+    """SPADE-style de-normalisation: BatchNorm2d(affine=False)(x) * (1 + gamma(style)) + beta(style)."""
+
+    def __init__(self, in_channels, style_channels) -> None:
+        super().__init__()
+        # buffer holder only (running_mean / running_var / num_batches_tracked keep their reference keys)
+        self.param_free_norm = nn.BatchNorm2d(in_channels, affine=False)
+        self.mlp_shared = nn.Sequential(
+            conv3x3(style_channels, in_channels),
+            FusedReLU(),
+        )
+        self.mlp_gamma = conv3x3(in_channels, in_channels)
+        self.mlp_beta = conv3x3(in_channels, in_channels)
+
+    def forward(self, x, style, relu=False):
+        bn = self.param_free_norm
+        actv = self.mlp_shared[0](style, relu=True)
+        gamma = self.mlp_gamma(actv)
+        beta = self.mlp_beta(actv)
+        out = ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
+                             momentum=bn.momentum, eps=bn.eps, relu=relu)
+        if self.training:
+            bn.num_batches_tracked += 1
+        return out
+
+
+class PixelShuffle(nn.Module):
+    def __init__(self, r):
+        super().__init__()
+        self.r = r
+
+    def forward(self, x):
+        raise NotImplementedError("pixel-shuffle up-sampling is not built yet (use_pixel_shuffle=False)")
+
+
+class StyledResUpBlock(nn.Module):
+    def __init__(self, in_channels, style_channels, out_channels, use_output_act=True, use_pixel_shuffle=False):
+        super().__init__()
+        self.use_pixel_shuffle = use_pixel_shuffle
+        if use_pixel_shuffle:
+            self.up_sample = nn.Sequential(
+                Conv2d(in_channels, in_channels * 4, kernel_size=3, padding=1),
+                PixelShuffle(2),
+            )
+        else:
+            self.up_sample = nn.Upsample(scale_factor=2, mode='nearest')   # folded into the conv loaders
+
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.norm1 = StyledDenorm(out_channels, style_channels)
+        self.act1 = nn.ReLU(inplace=True)
+
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
+        self.norm2 = StyledDenorm(out_channels, style_channels)
+        self.use_output_act = use_output_act
+        self.act2 = nn.ReLU(inplace=True) if use_output_act else nn.Identity()
+
+        self.conv = nn.Sequential(
+            Conv2d(in_channels, out_channels, kernel_size=3, padding=1),
+            InstanceNorm2d(out_channels, relu=True),
+            FusedReLU(),
+        )
+
+    def forward(self, down_input, skip_input):
+        if self.use_pixel_shuffle:
+            x, up = self.up_sample(down_input), False
+        else:
+            x, up = down_input, True
+        s = self.conv[1](self.conv[0](x, up2x=up))
+        h = self.conv1(x, up2x=up)
+        h = self.norm1(h, skip_input, relu=True)
+        h = self.conv2(h)
+        h = self.norm2(h, skip_input, relu=self.use_output_act)
+        return ops.add(s, h)

@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the upstream reference's own modules.
+
+Runs ONLY in the build container (needs /root/reference; see _refshim.py).  Output:
+tests/golden/*.npz — tensors only (inputs, weights or seeds+checksums, expected
+outputs / gradients / buffers).  No reference source text or pickled modules.
+
+    python tests/golden/make_golden.py
+
+The training-step vectors drive the reference modules with the first-step
+sequence of src/trainers/single_window_trainer.py:68-147 restated here around
+them (Lightning / kornia are absent offline): views = identity and horizontal
+flip (+ noise on the noised copy), r_ids by index flip with an optional zero
+border, MSE reconstruction, torch.optim.Adam x2 as base.py:165-175 builds them.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import _refshim  # noqa: E402
+
+R = _refshim.load_reference()
+torch.set_num_threads(8)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def checksum(t):
+    t = t.detach().double()
+    return np.array([t.sum().item(), t.abs().sum().item(), float(t.numel())])
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print("wrote %-28s %8.1f KB  (%d arrays)" % (name, os.path.getsize(path) / 1024, len(d)))
+
+
+def module_case(tag, mod, inputs, out_dict, train=True, call=None):
+    """Run `mod(*inputs)`, backprop sum(out*Rnd), record everything under tag/."""
+    mod.train(train)
+    ins = [x.clone().requires_grad_(x.is_floating_point()) for x in inputs]
+    for k, v in mod.state_dict().items():
+        out_dict["%s/P.%s" % (tag, k)] = npy(v).copy()
+    out = call(mod, *ins) if call else mod(*ins)
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    rnds = [torch.randn_like(o) for o in outs]
+    loss = sum((o * r).sum() for o, r in zip(outs, rnds))
+    loss.backward()
+    for i, x in enumerate(inputs):
+        out_dict["%s/in.%d" % (tag, i)] = npy(x)
+        if ins[i].grad is not None:
+            out_dict["%s/gin.%d" % (tag, i)] = npy(ins[i].grad)
+    for i, (o, r) in enumerate(zip(outs, rnds)):
+        out_dict["%s/out.%d" % (tag, i)] = npy(o)
+        out_dict["%s/R.%d" % (tag, i)] = npy(r)
+    for k, p in mod.named_parameters():
+        out_dict["%s/gP.%s" % (tag, k)] = npy(p.grad)
+    for k, v in mod.state_dict().items():
+        if "running_" in k or "num_batches" in k:
+            out_dict["%s/after.%s" % (tag, k)] = npy(v).copy()
+
+
+def gen_blocks():
+    d = {}
+    B = R.blocks
+    torch.manual_seed(11)
+    module_case("double_conv", B.DoubleConv(16, 32), [torch.randn(2, 16, 16, 16)], d)
+    module_case("res_block", B.ResBlock(16, 32), [torch.randn(2, 16, 16, 16)], d)
+    module_case("res_block_c1", B.ResBlock(1, 16), [torch.randn(2, 1, 16, 16)], d)
+    module_case("up_block", B.UpBlock(32 + 16, 16),
+                [torch.randn(2, 32, 8, 8), torch.randn(2, 16, 16, 16)], d)
+    module_case("styled_denorm", B.StyledDenorm(16, 32),
+                [torch.randn(3, 16, 8, 8) * 2 + 0.5, torch.randn(3, 32, 8, 8)], d)
+    sd = B.StyledDenorm(16, 16)
+    sd.param_free_norm.running_mean.normal_()
+    sd.param_free_norm.running_var.uniform_(0.5, 2.0)
+    module_case("styled_denorm_eval", sd,
+                [torch.randn(2, 16, 8, 8), torch.randn(2, 16, 8, 8)], d, train=False)
+    module_case("styled_res_up", B.StyledResUpBlock(32, 16, 16, use_pixel_shuffle=False),
+                [torch.randn(2, 32, 8, 8), torch.randn(2, 16, 16, 16)], d)
+    module_case("aspp", R.aspp.ASPP(16, 16, [2, 6, 12, 18]), [torch.randn(2, 16, 24, 24)], d)
+    # odd channel counts -> exercises the generic (non-MFMA) kernels
+    module_case("double_conv_odd", B.DoubleConv(3, 5), [torch.randn(2, 3, 10, 10)], d)
+    save("blocks.npz", d)
+
+
+def gen_vq():
+    d = {}
+    for tag, (Bn, D, K, HW, mom) in {"k10": (2, 16, 10, 16, 0.999), "k64": (2, 32, 64, 8, 0.9),
+                                     "k1024": (1, 64, 1024, 16, 0.99)}.items():
+        torch.manual_seed(5)
+        vq = R.vq_module.VQModule(emb_dim=D, dict_size=K, momentum=mom, eps=1e-5, knn_backend="torch")
+        d[tag + "/embed0"] = npy(vq.embed).copy()
+        d[tag + "/momentum"] = np.array(mom)
+        vq.train()
+        for call in (1, 2):
+            x = (torch.randn(Bn, D, HW, HW) * 1.3).requires_grad_(True)
+            embed_before = vq.embed.clone()
+            q, commit, ids = vq(x)
+            rnd = torch.randn_like(q)
+            ((q * rnd).sum() + 3.0 * commit).backward()
+            flat = x.detach().permute(0, 2, 3, 1).reshape(-1, D)
+            sc, _ = R.vq_module._torch_knn(embed_before, flat, 2, "l2")   # (N,2) best, second
+            d["%s/gap%d" % (tag, call)] = npy((sc[:, 0] - sc[:, 1]).reshape(Bn, HW, HW))
+            d["%s/x%d" % (tag, call)] = npy(x)
+            d["%s/R%d" % (tag, call)] = npy(rnd)
+            d["%s/q%d" % (tag, call)] = npy(q)
+            d["%s/commit%d" % (tag, call)] = npy(commit)
+            # reference returns ids in its transposed (B,W,H) order; store per-pixel (B,H,W)
+            d["%s/ids%d" % (tag, call)] = npy(ids.transpose(1, 2))
+            d["%s/gx%d" % (tag, call)] = npy(x.grad)
+            for b in ("embed", "cluster_size", "embed_avg"):
+                d["%s/%s_after%d" % (tag, b, call)] = npy(getattr(vq, b)).copy()
+        vq.eval()
+        x = torch.randn(Bn, D, HW, HW)
+        q, commit, ids = vq(x)
+        d[tag + "/x_eval"] = npy(x)
+        d[tag + "/q_eval"] = npy(q)
+        d[tag + "/commit_eval"] = npy(commit)
+        d[tag + "/ids_eval"] = npy(ids.transpose(1, 2))
+        look = vq.lookup(ids)
+        d[tag + "/lookup_eval"] = npy(look)
+    save("vq.npz", d)
+
+
+def gen_losses():
+    d = {}
+    torch.manual_seed(21)
+    Bn, D, K, HW = 3, 16, 10, 12
+    for tag, use_d, use_r in (("full", True, True), ("cross_only", None, None)):
+        e1 = torch.randn(Bn, D, HW, HW, requires_grad=True)
+        e2 = torch.randn(Bn, D, HW, HW, requires_grad=True)
+        cb = torch.randn(D, K)
+        ids1 = torch.randint(0, K + 1, (Bn, HW, HW))
+        ids2 = torch.randint(0, K + 1, (Bn, HW, HW))
+        ids2[0][ids2[0] == 3] = 0       # class 3 absent in sample 0
+        ids1[1] = 0                      # a fully out-of-frame sample
+        oh = R.OneHotEncoder(K + 1)
+        r1 = oh(ids1.int())[:, 1:]
+        r2 = oh(ids2.int())[:, 1:]
+        L = R.EmbeddingLoss(K, 0.5, use_d, use_r)
+        lc, ld, lr = L(e1, r1, e2, r2, cb)
+        lc.backward()
+        d[tag + "/e1"], d[tag + "/e2"], d[tag + "/cb"] = npy(e1), npy(e2), npy(cb)
+        d[tag + "/ids1"], d[tag + "/ids2"] = npy(ids1), npy(ids2)
+        d[tag + "/onehot1"] = npy(oh(ids1.int()))
+        d[tag + "/l_cross"] = npy(lc)
+        d[tag + "/l_dist"] = np.array(float(ld))
+        d[tag + "/l_reg"] = np.array(float(lr))
+        d[tag + "/ge1"], d[tag + "/ge2"] = npy(e1.grad), npy(e2.grad)
+    # segmentation losses
+    logits = torch.randn(2, 5, 9, 9, requires_grad=True)
+    tgt = F.one_hot(torch.randint(0, 5, (2, 9, 9)), 5).permute(0, 3, 1, 2).float()
+    for name, mod in (("dice", R.SoftDiceLoss()), ("dice_ign", R.SoftDiceLoss(ignore_index=0)),
+                      ("focal", R.FocalLoss())):
+        logits.grad = None
+        l = mod(logits, tgt)
+        l.backward()
+        d["seg/" + name] = npy(l)
+        d["seg/g_" + name] = npy(logits.grad)
+    d["seg/logits"], d["seg/target"] = npy(logits), npy(tgt)
+    # dropblock deterministic part
+    db = R.dropblock.DropBlock2D(drop_prob=0.3, block_size=4)
+    m = (torch.rand(2, 12, 12) < 0.05).float()
+    d["dropblock/seed4"], d["dropblock/keep4"] = npy(m), npy(db._compute_block_mask(m))
+    db = R.dropblock.DropBlock2D(drop_prob=0.3, block_size=5)
+    d["dropblock/keep5"] = npy(db._compute_block_mask(m))
+    save("losses.npz", d)
+
+
+def ref_first_step(enc, dec, eopt, dopt, image, noise, cfg):
+    """single_window_trainer.py:68-147 around the reference modules."""
+    K, w = cfg["dict_size"], cfg["weights"]
+    oh = R.OneHotEncoder(K + 1)
+    L = R.EmbeddingLoss(K, cfg["margin"], True, True)
+    n1, c1 = image, image
+    c2 = torch.flip(image, dims=[3])
+    n2 = c2 + noise
+    e1, lc1, ids1 = enc(n1, rank=0)
+    e2, lc2, ids2 = enc(n2, rank=0)
+
+    def rid(ids):
+        r = torch.flip(ids, dims=[2]).clone()
+        b = cfg["border"]
+        if b > 0:
+            r[:, :b, :] = 0; r[:, -b:, :] = 0; r[:, :, :b] = 0; r[:, :, -b:] = 0
+        return r.int()
+    r1 = oh(rid(ids1))[:, 1:]
+    r2 = oh(rid(ids2))[:, 1:]
+    codebook = enc.vq.get_codebook()
+    l_cross, l_dist, l_reg = L(e1, r1, e2, r2, codebook)
+    rec1, rec2 = dec(e1), dec(e2)
+    l_recon = F.mse_loss(rec1, c1) + F.mse_loss(rec2, c2)
+    l_commit = lc1 + lc2
+    total = (w["commit"] * l_commit + w["cross"] * l_cross + w["dist"] * l_dist
+             + w["reg"] * l_reg + w["recon"] * l_recon)
+    eopt.zero_grad(); dopt.zero_grad()
+    total.backward()
+    grads = {"enc." + k: p.grad.clone() for k, p in enc.named_parameters()}
+    grads.update({"dec." + k: p.grad.clone() for k, p in dec.named_parameters()})
+    eopt.step(); dopt.step()
+    return dict(total=total, commit=l_commit, cross=l_cross, dist=l_dist, reg=l_reg, recon=l_recon,
+                ids_1=ids1, ids_2=ids2, recon_1=rec1, recon_2=rec2, embed_1=e1, embed_2=e2), grads
+
+
+def sample_idx(numel, n=64, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, numel, (min(n, numel),), generator=g)
+
+
+def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, momentum=0.999, warm=False):
+    from oracle import vqwnet_ref as O
+    d = {}
+    torch.manual_seed(seed)
+    enc = R.UNetEncoder(1, enc_filters, K, momentum, "torch", False, 4, True)
+    dec = R.UNetDecoder(enc_filters[0], 1, dec_filters, use_dropblock=False,
+                        dropped_skip_layers=[], use_styled_up_block=True, use_pixel_shuffle=False)
+    enc.train(); dec.train()
+    cfg = dict(dict_size=K, margin=0.5, border=2, momentum=momentum,
+               weights=dict(commit=1.0, cross=1.0, dist=1.0, reg=1.0, recon=1.0))
+    d["cfg/enc_filters"], d["cfg/dec_filters"] = np.array(enc_filters), np.array(dec_filters)
+    d["cfg/K"], d["cfg/size"], d["cfg/batch"] = np.array(K), np.array(size), np.array(batch)
+    d["cfg/seed"], d["cfg/n_steps"], d["cfg/border"] = np.array(seed), np.array(n_steps), np.array(2)
+    d["cfg/momentum"], d["cfg/margin"] = np.array(momentum), np.array(0.5)
+    d["cfg/lr"], d["cfg/betas"] = np.array(1e-4), np.array([0.5, 0.999])
+    for pre, m in (("enc", enc), ("dec", dec)):
+        for k, v in m.state_dict().items():
+            d["init_sum/%s.%s" % (pre, k)] = checksum(v.float())
+    d["cfg/warm"] = np.array(int(warm))
+    if warm:
+        # checkpoint-like VQ state (as after many updates): no cluster_size==0 blow-up, so gradients are
+        # well conditioned.  Same reference code, different loaded state.
+        with torch.no_grad():
+            enc.vq.embed.mul_(0.7)
+            enc.vq.cluster_size.fill_(batch * size * size / K)
+            enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
+        for b in ("embed", "cluster_size", "embed_avg"):
+            d["warm/vq." + b] = npy(getattr(enc.vq, b)).copy()
+    eopt = torch.optim.Adam(filter(lambda p: p.requires_grad, enc.parameters()), lr=1e-4, betas=(0.5, 0.999), weight_decay=0)
+    dopt = torch.optim.Adam(filter(lambda p: p.requires_grad, dec.parameters()), lr=1e-4, betas=(0.5, 0.999), weight_decay=0)
+    # eval-mode forward + mask-guided reconstruction (run_recon.py:179-194) on the INITIAL state (so both sides hold bit-identical weights;
+    # after an optimiser step two fp32 implementations drift, see tests/test_oracle_golden.py::check_step)
+    enc.eval(); dec.eval()
+    with torch.no_grad():
+        image, _ = O.synthetic_slices(batch, size, 999)
+        e, _, ids = enc(image)
+        d["eval/image"], d["eval/ids"], d["eval/recon"] = npy(image), npy(ids), npy(dec(e))
+        g = torch.Generator().manual_seed(3)
+        lab = torch.randint(0, K + 1, (batch, size, size), generator=g)
+        lab[:, : size // 4, :] = lab[:, :1, :1]   # a constant region, like an edited label map
+        mask = (lab != 0)
+        m = torch.clamp(lab, min=1) - 1
+        emb = enc.get_embed_from_ids(m)
+        emb = emb * mask[:, None]
+        emb = emb * (mask.numel() / mask.sum())
+        d["recon/label_map"], d["recon/embed"], d["recon/recon"] = npy(lab), npy(emb), npy(dec(emb))
+    enc.train(); dec.train()
+    for s in range(n_steps):
+        image, noise = O.synthetic_slices(batch, size, 1234 + s)
+        d["step%d/image" % s], d["step%d/noise" % s] = npy(image), npy(noise)
+        out, grads = ref_first_step(enc, dec, eopt, dopt, image, noise, cfg)
+        for k in ("total", "commit", "cross", "dist", "reg", "recon"):
+            d["step%d/%s" % (s, k)] = np.array(float(out[k]))
+        for k in ("ids_1", "ids_2", "recon_1", "recon_2"):
+            d["step%d/%s" % (s, k)] = npy(out[k])
+        d["step%d/embed_1_sum" % s] = checksum(out["embed_1"])
+        for k, g in grads.items():
+            idx = sample_idx(g.numel())
+            d["step%d/g.%s" % (s, k)] = npy(g.reshape(-1)[idx])
+            d["step%d/gnorm.%s" % (s, k)] = np.array(float(g.norm()))
+        for pre, m in (("enc", enc), ("dec", dec)):
+            for k, v in m.state_dict().items():
+                v = v.float()
+                idx = sample_idx(v.numel())
+                d["step%d/after.%s.%s" % (s, pre, k)] = npy(v.reshape(-1)[idx])
+                d["step%d/after_sum.%s.%s" % (s, pre, k)] = checksum(v)
+    save(name, d)
+
+
+if __name__ == "__main__":
+    gen_blocks()
+    gen_vq()
+    gen_losses()
+    gen_step("step_small.npz", [16, 16, 32, 32, 32], [16, 32, 32, 32, 64], 6, 32, 2, 3, seed=7,
+             momentum=0.9)
+    gen_step("step_rcfg32.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 32, 4, 1, seed=0)
+    gen_step("step_rcfg64_warm.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 64, 2, 1, seed=0, warm=True)

@@ -1,0 +1,242 @@
+"""The CPU oracle (oracle/vqwnet_ref.py) against golden vectors produced by the reference's own modules.
+
+These pin the oracle; the GPU tests then compare the HIP path with the oracle (and with the same vectors).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, build_models, check_init, step_cfg, sample_idx, checksum
+from oracle import vqwnet_ref as O
+
+TOL = 2e-5     # fp32, CPU vs CPU, different summation orders only
+
+
+def _P(g, tag):
+    return {k[2:]: v for k, v in g.group(tag).items() if k.startswith("P.")}
+
+
+def _run_case(g, tag, fn, n_in):
+    P = _P(g, tag)
+    for k in P:
+        if P[k].is_floating_point() and k.endswith((".weight", ".bias")):
+            P[k].requires_grad_(True)
+    ins = [g.t("%s/in.%d" % (tag, i)).requires_grad_(True) for i in range(n_in)]
+    outs = fn(P, *ins)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    loss = sum((o * g.t("%s/R.%d" % (tag, i))).sum() for i, o in enumerate(outs))
+    loss.backward()
+    for i, o in enumerate(outs):
+        assert_close(o, g["%s/out.%d" % (tag, i)], TOL, "%s out.%d" % (tag, i))
+    for i, x in enumerate(ins):
+        key = "%s/gin.%d" % (tag, i)
+        if key in g.files:
+            assert_close(x.grad, g[key], 20 * TOL, key, atol=1e-6)
+    for k, p in P.items():
+        key = "%s/gP.%s" % (tag, k)
+        if key in g.files:
+            assert_close(p.grad, g[key], 20 * TOL, key, atol=2e-5)
+    return P
+
+
+def test_blocks(golden):
+    g = golden("blocks.npz")
+    _run_case(g, "double_conv", lambda P, x: O.double_conv(_pref(P, "m."), "m", x), 1)
+    _run_case(g, "double_conv_odd", lambda P, x: O.double_conv(_pref(P, "m."), "m", x), 1)
+    _run_case(g, "res_block", lambda P, x: _res(P, x), 1)
+    _run_case(g, "res_block_c1", lambda P, x: _res(P, x), 1)
+    _run_case(g, "up_block", lambda P, d, s: O.up_block(_pref(P, "m."), "m", d, s), 2)
+    P = _run_case(g, "styled_denorm", lambda P, x, s: O.styled_denorm(_pref(P, "m."), "m", x, s, True), 2)
+    for k in ("running_mean", "running_var"):
+        assert_close(P["param_free_norm." + k], g["styled_denorm/after.param_free_norm." + k], TOL, k)
+    _run_case(g, "styled_denorm_eval", lambda P, x, s: O.styled_denorm(_pref(P, "m."), "m", x, s, False), 2)
+    _run_case(g, "styled_res_up", lambda P, d, s: O.styled_res_up_block(_pref(P, "m."), "m", d, s, True), 2)
+    _run_case(g, "aspp", lambda P, x: O.aspp(_pref(P, "m."), "m", x), 1)
+
+
+def _pref(P, pre):
+    """View of P under a key prefix that shares tensors (so running stats / grads land in P)."""
+    class V(dict):
+        def __getitem__(s, k):
+            return P[k[len(pre):]]
+
+        def get(s, k, d=None):
+            return P.get(k[len(pre):], d)
+
+        def __contains__(s, k):
+            return k[len(pre):] in P
+    return V()
+
+
+def _res(P, x):
+    return O.res_block(_pref(P, "m."), "m", x)
+
+
+@pytest.mark.parametrize("tag", ["k10", "k64", "k1024"])
+def test_vq(golden, tag):
+    g = golden("vq.npz")
+    V = dict(embed=g.t(tag + "/embed0").clone(), cluster_size=torch.zeros(g[tag + "/embed0"].shape[0]),
+             embed_avg=g.t(tag + "/embed0").t().clone())
+    mom = float(g[tag + "/momentum"])
+    for call in (1, 2):
+        x = g.t("%s/x%d" % (tag, call)).requires_grad_(True)
+        q, commit, ids, gap = O.vq_forward(V, x, True, mom)
+        ((q * g.t("%s/R%d" % (tag, call))).sum() + 3.0 * commit).backward()
+        ref_ids = g["%s/ids%d" % (tag, call)]
+        ref_gap = g["%s/gap%d" % (tag, call)]
+        clear = ref_gap > 1e-4 * (1 + np.abs(ref_gap))
+        assert clear.mean() > 0.99
+        assert np.array_equal(ids.numpy()[clear], ref_ids[clear]), "ids differ on tie-free pixels"
+        assert_close(q, g["%s/q%d" % (tag, call)], TOL, "q")
+        assert_close(commit, g["%s/commit%d" % (tag, call)], TOL, "commit")
+        assert_close(x.grad, g["%s/gx%d" % (tag, call)], TOL, "gx")
+        for b in ("embed", "cluster_size", "embed_avg"):
+            assert_close(V[b], g["%s/%s_after%d" % (tag, b, call)], 5e-5, "%s after call %d" % (b, call))
+    x = g.t(tag + "/x_eval")
+    q, commit, ids, _ = O.vq_forward(V, x, False, mom)
+    assert np.mean(ids.numpy() == g[tag + "/ids_eval"]) > 0.999
+    assert_close(q, g[tag + "/q_eval"], 1e-3, "q eval")
+    assert_close(commit, g[tag + "/commit_eval"], 1e-4, "commit eval")
+
+
+def test_losses(golden):
+    g = golden("losses.npz")
+    for tag, use_d in (("full", True), ("cross_only", False)):
+        e1 = g.t(tag + "/e1").requires_grad_(True)
+        e2 = g.t(tag + "/e2").requires_grad_(True)
+        cb = g.t(tag + "/cb")
+        K = cb.shape[1]
+        r1 = O.one_hot(g.t(tag + "/ids1"), K + 1)[:, 1:]
+        r2 = O.one_hot(g.t(tag + "/ids2"), K + 1)[:, 1:]
+        assert np.array_equal(O.one_hot(g.t(tag + "/ids1"), K + 1).numpy(), g[tag + "/onehot1"])
+        lc, ld, lr = O.embedding_loss(e1, r1, e2, r2, cb, 0.5, use_d, use_d)
+        lc.backward()
+        assert_close(lc, g[tag + "/l_cross"], TOL, "l_cross")
+        assert_close(float(ld), g[tag + "/l_dist"], TOL, "l_dist")
+        assert_close(float(lr), g[tag + "/l_reg"], TOL, "l_reg")
+        assert_close(e1.grad, g[tag + "/ge1"], TOL, "ge1")
+        assert_close(e2.grad, g[tag + "/ge2"], TOL, "ge2")
+    # known-answer: K identical codes -> every pair (i==j included) contributes (2m)^2
+    K, m = 7, 0.5
+    cb = torch.ones(4, K)
+    assert abs(float(O.distance_loss(cb, m)) - K * K * (2 * m) ** 2 / (2 * K * (K - 1))) < 1e-6
+    # segmentation losses + dropblock
+    logits = g.t("seg/logits").requires_grad_(True)
+    tgt = g.t("seg/target")
+    for name, fn in (("dice", lambda: O.soft_dice_loss(logits, tgt)),
+                     ("dice_ign", lambda: O.soft_dice_loss(logits, tgt, ignore_index=0)),
+                     ("focal", lambda: O.focal_loss(logits, tgt))):
+        logits.grad = None
+        l = fn()
+        l.backward()
+        assert_close(l, g["seg/" + name], TOL, name)
+        assert_close(logits.grad, g["seg/g_" + name], 10 * TOL, "g_" + name)
+    assert np.array_equal(O.dropblock_mask(g.t("dropblock/seed4"), 4).numpy(), g["dropblock/keep4"])
+    assert np.array_equal(O.dropblock_mask(g.t("dropblock/seed4"), 5).numpy(), g["dropblock/keep5"])
+
+
+# per-fixture gradient tolerances (relative error of sampled entries / norms vs the reference's gradients):
+#   step_small       cold VQ start, small filters : well conditioned                          -> 2e-3, 2 outliers
+#   step_rcfg64_warm R-cfg filters, checkpoint-like VQ state : well conditioned               -> 5e-2, 6 outliers
+#   step_rcfg32      R-cfg, cold start (BASELINE config 1): cross-loss ~1e5 from the EMA blow-up and 2x2
+#                    InstanceNorm planes make gradients chaotic even CPU-vs-CPU               -> norms only, 0.5
+GRAD_TOL = {"step_small.npz": (2e-3, 2, 0.25), "step_rcfg64_warm.npz": (5e-2, 6, 0.25), "step_rcfg32.npz": (0.5, 60, 1.5)}
+
+
+def apply_warm_state(g, sd_enc):
+    """Load the checkpoint-like VQ buffers a warm fixture was generated with."""
+    if "cfg/warm" in g.files and int(g["cfg/warm"]):
+        for b in ("embed", "cluster_size", "embed_avg"):
+            sd_enc["vq." + b].copy_(g.t("warm/vq." + b))
+
+
+def check_step(g, s, out, PE, PD, lr, tight, tol=2e-4, grad_tol=2e-3, max_loose=2, loose_bound=0.25):
+    """Compare one training step with the golden record.
+
+    Step 0 is the tight gate.  Later steps are inherently chaotic in the REFERENCE itself: (1) cluster_size
+    starts at 0, so after the first EMA update unused codes jump to ~1e5 (vq_module.py:156,198-200) and most
+    pixels sit near score ties; (2) biases of convs feeding an InstanceNorm have analytically zero gradient, and
+    Adam turns their rounding noise into +-lr steps.  Two fp32 implementations therefore drift apart after the
+    first optimiser step; for s > 0 only coarse agreement is asserted."""
+    def val(k):
+        return float(out[k].detach()) if torch.is_tensor(out[k]) else float(out[k])
+    if not tight:
+        assert abs(val("total") - float(g["step%d/total" % s])) <= 0.05 * abs(float(g["step%d/total" % s]))
+        assert abs(val("reg") - float(g["step%d/reg" % s])) <= 0.05 * abs(float(g["step%d/reg" % s]))
+        for v in ("1", "2"):
+            agree = np.mean(out["ids_" + v].cpu().numpy() == g["step%d/ids_%s" % (s, v)])
+            assert agree > 0.5, "ids_%s agreement %.3f at step %d" % (v, agree, s)
+        return
+    for k in ("total", "commit", "cross", "dist", "reg", "recon"):
+        assert_close(val(k), g["step%d/%s" % (s, k)], tol, "step %d %s" % (s, k))
+    for v in ("1", "2"):
+        ids = out["ids_" + v].cpu().numpy()
+        ref = g["step%d/ids_%s" % (s, v)]
+        if "gap_" + v in out:
+            gap = out["gap_" + v].cpu().numpy()
+            clear = gap > 1e-3 * (1 + np.abs(gap))
+            assert np.array_equal(ids[clear], ref[clear]), "ids_%s step %d" % (v, s)
+        assert np.mean(ids == ref) > 0.999, "ids_%s agreement %.5f" % (v, np.mean(ids == ref))
+        assert_close(out["recon_" + v], g["step%d/recon_%s" % (s, v)], 10 * tol, "recon_" + v)
+    gmax = max(float(g[k]) for k in g.files if k.startswith("step%d/gnorm." % s))
+    n_checked, loose = 0, []
+    for pre, grads, P in (("enc", out["grads_enc"], PE), ("dec", out["grads_dec"], PD)):
+        for k, gr in grads.items():
+            ref_n = float(g["step%d/gnorm.%s.%s" % (s, pre, k)])
+            if ref_n < 1e-6 * gmax:        # analytically zero (bias in front of an InstanceNorm): noise only
+                assert gr is None or float(gr.norm()) < 1e-4 * gmax
+                continue
+            gr = gr.detach().cpu()
+            idx = sample_idx(gr.numel())
+            ref_s = g.t("step%d/g.%s.%s" % (s, pre, k)).double()
+            err = float((gr.reshape(-1)[idx].double() - ref_s).norm()) / (float(ref_s.norm()) + ref_n / gr.numel() ** 0.5)
+            err = max(err, abs(float(gr.norm()) - ref_n) / ref_n)
+            if err > grad_tol:
+                # scale-invariant weights (1-channel 1x1 conv feeding an InstanceNorm) only get gradient through
+                # eps: ill-conditioned in any fp32 implementation.  Tolerate a couple, bounded.
+                assert err < loose_bound, "grad %s.%s: error %.3e" % (pre, k, err)
+                loose.append(k)
+                continue
+            # first Adam step moves every element by lr*sign(g): agree unless g ~ 0
+            pv = P[k].detach().cpu().float().reshape(-1)[idx]
+            ok = (pv - g.t("step%d/after.%s.%s" % (s, pre, k))).abs() < 0.1 * lr
+            assert ok.float().mean() > (0.9 if loose_bound < 1 else 0.6), "after-step %s.%s" % (pre, k)
+            n_checked += 1
+    assert n_checked + len(loose) > 20 and len(loose) <= max_loose, loose
+    for key in ("vq.embed", "vq.cluster_size", "vq.embed_avg"):
+        v = PE[key].detach().cpu().float()
+        c = g["step%d/after_sum.enc.%s" % (s, key)]
+        assert abs(checksum(v)[1] - c[1]) <= 1e-4 * c[1], "after-step " + key
+    for k, v in PD.items():
+        if "running_" in k:
+            c = g["step%d/after_sum.dec.%s" % (s, k)]
+            assert abs(checksum(v.float())[1] - c[1]) <= 1e-4 * c[1] + 1e-6, "after-step " + k
+
+
+@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg32.npz"])
+def test_first_step(golden, name):
+    """Full first training step(s): losses, ids, recon, sampled grads, params/buffers after Adam."""
+    g = golden(name)
+    enc, dec = build_models(g.group("cfg"))
+    check_init(g, enc, dec)
+    PE = {k: v.detach().clone().contiguous() for k, v in enc.state_dict().items()}
+    PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
+    apply_warm_state(g, PE)
+    gt, ml, lb = GRAD_TOL[name]
+    # eval-mode forward and mask-guided reconstruction (run_recon.py:179-194) on the initial state
+    with torch.no_grad():
+        q, _, ids1, gap = O.encoder_forward(PE, g.t("eval/image"), False, float(g["cfg/momentum"]))
+        rec = O.decoder_forward(PD, q, False)
+        clear = gap.numpy() > 1e-3 * (1 + np.abs(gap.numpy()))
+        assert np.array_equal(ids1.numpy()[clear], g["eval/ids"][clear])
+        assert_close(rec, g["eval/recon"], 1e-3, "eval recon")
+        rec2 = O.recon_from_ids(PE, PD, g.t("recon/label_map"))
+        assert_close(rec2, g["recon/recon"], 1e-3, "mask-guided recon")
+        emb = O.vq_lookup(O.vq_state(PE), torch.clamp(g.t("recon/label_map"), min=1) - 1)
+        m = (g.t("recon/label_map") != 0)
+        assert_close(emb * m[:, None] * (m.numel() / m.sum()), g["recon/embed"], 1e-6, "masked embed")
+    tr = O.FirstStepTrainer(PE, PD, step_cfg(g))
+    lr = float(g["cfg/lr"])
+    for s in range(int(g["cfg/n_steps"])):
+        out = tr.step(g.t("step%d/image" % s), g.t("step%d/noise" % s))
+        check_step(g, s, out, PE, PD, lr, tight=(s == 0), grad_tol=gt, max_loose=ml, loose_bound=lb)
