@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the VQ-W-Net first training step on synthetic 256x256 slices.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (the driver launches N>1 with torch.distributed.run); per-GPU batch is fixed
+(32 source images = 64 views per step) so scaling is weak.  A step = 2 views x (encoder + VQ + decoder)
+forward, embedding / reconstruction losses, backward and two Adam updates (the reference's
+trainers/single_window_trainer.py:68-147), all in the HIP kernels behind libvqwnet_hip.so.
+Rank 0 prints ONE JSON line.  Extra fields: `roofline` for the dominant kernel family (timed with HIP
+events on the launch stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on the
+host cores, rank 0, N=1 only, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "medical-image-editing_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work per source image at 256x256 with the R-cfg model
+FLOP_PER_IMAGE = 490.3e9
+BYTES_PER_IMAGE = 3.28e9
+PEAK_FP32_MFMA = 157.3e12        # MI355X_MICROARCH.md: fp32-input MFMA = vector fp32 peak
+PEAK_HBM = 8.0e12
+
+
+def synthetic_batch(batch, size, seed, device):
+    """smooth random field + noise in [-1, 1]; noise for the second view's noised copy."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.randn(batch, 1, size // 8, size // 8, generator=g)
+    field = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=False)
+    img = (field * 0.6 + 0.05 * torch.randn(batch, 1, size, size, generator=g)).clamp_(-1, 1)
+    noise = 0.02 * torch.randn(batch, 1, size, size, generator=g)
+    return img.to(device), noise.to(device)
+
+
+def host_cores():
+    """Usable host cores: min(affinity, cgroup CPU quota), capped at 16 (the CPU share of a 1-GPU box)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(size, batch, steps):
+    """The oracle's training step on the host cores (bounded sample of the same workload)."""
+    from oracle import vqwnet_ref as O
+    from networks import UNetEncoder, UNetDecoder
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    print("[bench] cpu_baseline: %d threads, batch %d at %dx%d" % (cores, batch, size, size), file=sys.stderr, flush=True)
+    torch.manual_seed(0)
+    enc = UNetEncoder(1, [16, 32, 64, 128, 256], 10, 0.999, 'torch', False, 1, True)
+    dec = UNetDecoder(16, 1, [32, 64, 128, 256, 512], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
+    PE = {k: v.detach().clone().contiguous() for k, v in enc.state_dict().items()}
+    PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
+    cfg = dict(dict_size=10, margin=0.5, border=0, momentum=0.999,
+               weights=dict(commit=1.0, cross=1.0, dist=1.0, reg=1.0, recon=1.0),
+               optim=dict(lr=1e-4, betas=(0.5, 0.999), weight_decay=0.0))
+    tr = O.FirstStepTrainer(PE, PD, cfg)
+    img, noise = O.synthetic_slices(batch, size, 1234)
+    tr.step(img, noise)                                   # warm-up (allocator, oneDNN primitives)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        img, noise = O.synthetic_slices(batch, size, 1235 + s)
+        tr.step(img, noise)
+        print("[bench] cpu_baseline step %d: %.1f s elapsed" % (s, time.perf_counter() - t0), file=sys.stderr, flush=True)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=batch / dt, unit="images/sec", cores=cores, kind="port",
+                sample="%d steps of the oracle's first training step, batch %d at %dx%d, torch %s CPU (fp32)"
+                       % (steps, batch, size, size, torch.__version__))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="source images per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hipops import _lib
+    from trainers import FirstStepTrainer
+    L = _lib.load()
+
+    torch.manual_seed(0)                                   # identical replicas on every rank
+    tr = FirstStepTrainer(device=dev, data_parallel=world > 1)
+    pool = [synthetic_batch(args.batch, args.size, 1234 + 1000 * rank + s, dev) for s in range(4)]
+
+    def step(i):
+        img, noise = pool[i % len(pool)]
+        return tr.training_step({"image": img}, noise=noise)
+
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        if rank == 0:
+            print("[bench] warm-up step %d done" % i, file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timing = not args.no_kernel_timing
+    if timing:
+        _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print("[bench] %d timed steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3), file=sys.stderr, flush=True)
+    prof = (ctypes.c_double * 12)()
+    if timing:
+        _lib.check(L.vqw_profile_end(prof), "vqw_profile_end")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total = float(out["total"].detach())
+    assert total == total, "loss is NaN"
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        imgs = args.batch * world * args.steps / dt
+        fam = ["conv_mfma_fwd_dgrad", "conv_mfma_wgrad", "conv_generic_fwd", "conv_generic_wgrad"]
+        kern = {}
+        for f, name in enumerate(fam):
+            n, ms, fl = prof[3 * f], prof[3 * f + 1], prof[3 * f + 2]
+            if n > 0:
+                kern[name] = dict(launches_per_step=n / args.steps, ms_per_step=ms / args.steps,
+                                  tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        roofline = None
+        if kern:
+            dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+            ach = kern[dom]["tflops"]
+            roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s",
+                            frac=ach / (PEAK_FP32_MFMA / 1e12), traffic=None,
+                            avg_launch_ms=kern[dom]["ms_per_step"] / kern[dom]["launches_per_step"],
+                            kernels=kern)
+        per_gpu = imgs / world
+        scale = (args.size / 256.0) ** 2
+        line = {
+            "metric": "images/sec (train step, 256x256 2D slices)", "value": imgs, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VQ-W-Net first training step (2 views: encoder+VQ+decoder fwd/bwd + 2x Adam), "
+                                   "R-cfg filters enc [16,32,64,128,256] dec [32,64,128,256,512], dict_size 10, "
+                                   "%dx%d 1-ch synthetic slices" % (args.size, args.size),
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "step_fraction_of_fp32_mfma_roofline": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA,
+            "step_fraction_of_hbm_roofline": per_gpu * BYTES_PER_IMAGE * scale / PEAK_HBM,
+            "loss_total": total,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.size, 1, 2)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

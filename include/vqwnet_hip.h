@@ -35,6 +35,12 @@ const char* vqw_last_error(void);
 int vqw_abi_version(void);
 /* 0 = auto (MFMA kernels when shapes allow), 1 = force the generic VALU kernels. */
 int vqw_set_conv_backend(int mode);
+/* Measurement aid (bench.py roofline): HIP events recorded on the launch stream around every convolution kernel
+ * family between begin and end.  end() synchronises on those events and fills out[4][3] =
+ * {launches, total ms, total algorithmic FLOPs} for {MFMA fwd/dgrad, MFMA wgrad, generic fwd, generic wgrad}.
+ * Not meant for graph capture; off by default.                                                              */
+int vqw_profile_begin(void);
+int vqw_profile_end(double* out);
 
 /* ---- convolution: replaces F.conv2d fwd/bwd behind nn.Conv2d in
  *      networks/blocks.py:5-6,25,45,48,75,79,80,102,108,112,117; networks/aspp.py:19-24;

@@ -4,6 +4,63 @@
 #include "../../include/vqwnet_hip.h"
 
 static int g_conv_backend = 0;  // 0 auto, 1 generic only
+
+// ---------------------------------------------------------------------------------------------
+// Optional per-launch timing of the convolution kernels (bench.py roofline): HIP events recorded on the SAME
+// stream right around each conv kernel family.  Off by default; nothing is recorded, allocated or synchronised
+// unless vqw_profile_begin() was called.  Families: 0 = MFMA fwd/dgrad, 1 = MFMA wgrad (incl. slab reduce),
+// 2 = generic fwd, 3 = generic wgrad.
+#define PROF_MAX 16384
+#define PROF_FAMILIES 4
+static bool g_prof_on = false;
+static int g_prof_n = 0;
+static hipEvent_t* g_prof_ev = nullptr;   // 2 * PROF_MAX events
+static double g_prof_flops[PROF_MAX];
+static int g_prof_family[PROF_MAX];
+
+extern "C" int vqw_profile_begin(void) {
+    if (!g_prof_ev) {
+        g_prof_ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * PROF_MAX);
+        for (int i = 0; i < 2 * PROF_MAX; ++i)
+            if (hipEventCreate(&g_prof_ev[i]) != hipSuccess) { vqw_set_error("vqw_profile_begin: hipEventCreate failed"); return VQW_ERR_HIP; }
+    }
+    g_prof_n = 0;
+    g_prof_on = true;
+    return VQW_OK;
+}
+// out[f] = {launches, total ms, total algorithmic flops} per family.  Synchronises on the recorded events.
+extern "C" int vqw_profile_end(double* out /*[PROF_FAMILIES][3]*/) {
+    g_prof_on = false;
+    if (!out) return VQW_OK;
+    for (int i = 0; i < PROF_FAMILIES * 3; ++i) out[i] = 0.0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess) {
+            vqw_set_error("vqw_profile_end: event query failed");
+            return VQW_ERR_HIP;
+        }
+        int f = g_prof_family[i];
+        out[3 * f] += 1.0;
+        out[3 * f + 1] += (double)ms;
+        out[3 * f + 2] += g_prof_flops[i];
+    }
+    return VQW_OK;
+}
+struct ProfScope {
+    int idx;
+    hipStream_t st;
+    ProfScope(int family, double flops, hipStream_t s) : idx(-1), st(s) {
+        if (g_prof_on && g_prof_n < PROF_MAX) {
+            idx = g_prof_n++;
+            g_prof_family[idx] = family;
+            g_prof_flops[idx] = flops;
+            (void)hipEventRecord(g_prof_ev[2 * idx], st);
+        }
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(g_prof_ev[2 * idx + 1], st);
+    }
+};
 extern "C" int vqw_set_conv_backend(int mode) {
     int old = g_conv_backend;
     g_conv_backend = mode;
@@ -30,8 +87,12 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
     VQW_CHECK(w_ohwi && y, "vqw_conv2d_fwd: weights and output must be set");
     ConvIn in{src0, src1, C0, C1, up0};
     hipStream_t st = (hipStream_t)stream;
-    if (g_conv_backend == 0 && conv_mfma_fwd_ok(in, Cout, ksize))
+    const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
+    if (g_conv_backend == 0 && conv_mfma_fwd_ok(in, Cout, ksize)) {
+        ProfScope ps(0, flops, st);
         return conv_mfma_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
+    }
+    ProfScope ps(2, flops, st);
     return conv_direct_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
 }
 
@@ -60,7 +121,11 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
         if (rc) return rc;
         wsf += bias_grad_ws_floats(Cout);
     }
-    if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize))
+    const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
+    if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
+        ProfScope ps(1, flops, st);
         return conv_mfma_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st);
+    }
+    ProfScope ps(3, flops, st);
     return conv_direct_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st);
 }

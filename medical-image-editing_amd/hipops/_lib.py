@@ -23,6 +23,8 @@ SIGNATURES = {
     "vqw_last_error": (ctypes.c_char_p, []),
     "vqw_abi_version": (c_i, []),
     "vqw_set_conv_backend": (c_i, [c_i]),
+    "vqw_profile_begin": (c_i, []),
+    "vqw_profile_end": (c_i, [c_p]),
     "vqw_conv2d_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_pack_dgrad_weights": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "vqw_conv2d_wgrad_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),

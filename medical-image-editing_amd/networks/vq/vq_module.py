@@ -30,7 +30,7 @@ class VQModule(nn.Module):
         embed = torch.randn(self.dict_size, self.emb_dim)
         self.register_buffer('embed', embed)
         self.register_buffer('cluster_size', torch.zeros(self.dict_size))
-        self.register_buffer('embed_avg', self.embed.T.clone())
+        self.register_buffer('embed_avg', self.embed.T.clone(memory_format=torch.contiguous_format))
 
     def forward(self, input: torch.Tensor, id_base: int = 0):
         """-> (quantized (B,D,H,W) with straight-through grad, commit_loss, ids).

@@ -1,0 +1,95 @@
+"""Data-parallel gradient exchange for one process per GPU (RCCL over xGMI via torch.distributed).
+
+Replaces the Lightning DDPPlugin the reference launches with (run_vqwnet.py:112-121).  Parameters are
+grouped into buckets in the order their gradients become ready in backward (decoder tail first); a
+post-accumulate hook on each parameter counts its bucket down, and the moment a bucket is complete
+its flat buffer is all-reduced asynchronously on a side stream while the remaining backward kernels
+keep running.  `finish()` waits for the outstanding collectives and scatters the averaged gradients back.
+
+MI355X sizing: xGMI is point-to-point (7 links per GPU), so a ring all-reduce is per-link bound and the
+61.8 MB of fp32 gradients of the R-cfg model cost ~1 ms in total; few large buckets (default 16 MiB)
+keep launch/latency overhead negligible against a >100 ms step while still overlapping.
+Works unchanged on the gloo backend (CPU tests, world_size 2).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradientAllReducer:
+    def __init__(self, params, bucket_bytes=16 << 20, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = []       # list of lists of params
+        cur, size = [], 0
+        for p in params:
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._bucket_of[p] = bi
+        self._pending = None
+        self._work = []
+        self._flat = [None] * len(self.buckets)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self._armed = False
+        self._stream = None
+
+    def prepare(self):
+        """Arm the hooks for one backward pass."""
+        self._pending = [len(b) for b in self.buckets]
+        self._work = []
+        self._armed = self.world > 1
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        bi = self._bucket_of[p]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def _launch(self, bi):
+        grads = [p.grad for p in self.buckets[bi]]
+        # flatten in MEMORY order (grads may be channels_last): view each as its dense storage
+        views = [_dense_1d(g) for g in grads]
+        flat = torch.cat(views)
+        self._flat[bi] = (flat, views)
+        # async: on RCCL the collective runs on the process group's own stream, ordered after the producing
+        # kernels by the event torch.distributed records, so it overlaps with the rest of backward
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._work.append((bi, work))
+
+    def finish(self):
+        """Wait for every bucket, write the rank-mean back into p.grad."""
+        if not self._armed:
+            return
+        for bi, pend in enumerate(self._pending):
+            if pend != 0:      # parameters without gradient this step: reduce what is there
+                raise RuntimeError("gradient bucket %d incomplete: a parameter received no gradient" % bi)
+        inv = 1.0 / self.world
+        for bi, work in self._work:
+            work.wait()
+            flat, views = self._flat[bi]
+            off = 0
+            for v in views:
+                n = v.numel()
+                v.copy_(flat[off:off + n])
+                v.mul_(inv)
+                off += n
+            self._flat[bi] = None
+        self._armed = False
+
+
+def _dense_1d(t):
+    """1-D view over a dense tensor's storage in memory order (contiguous or channels_last)."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t.permute(0, 2, 3, 1).reshape(-1)      # a view: permute makes it contiguous in memory order
+    raise RuntimeError("gradient tensor is not dense")

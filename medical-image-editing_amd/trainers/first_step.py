@@ -1,0 +1,114 @@
+"""First training step of the VQ-W-Net (reference: trainers/single_window_trainer.py:68-147,
+construction per trainers/base.py:164-237, 261-278) on the MI355X kernels.
+
+PyTorch-Lightning and kornia are not part of this build: the trainer is a plain class that
+owns the same modules, optimisers and loss weighting and exposes `training_step(batch)`.
+The two augmented views are produced by a `views` callable; the default is the exact-integer
+pair (identity, horizontal flip + additive noise on the noised copy) whose cross-view id
+map is an index flip.
+"""
+from collections import namedtuple
+
+import torch
+
+from hipops import ops, Adam
+from networks import UNetEncoder, UNetDecoder
+from functions import EmbeddingLoss, OneHotEncoder
+from utils import norm, denorm
+from .data_parallel import GradientAllReducer
+
+LossWeights = namedtuple("LossWeights", "commit cross dist reg recon freq perceptual", defaults=(1.0,) * 5 + (0.0, 0.0))
+
+
+class FlipViews:
+    """view 1 = identity, view 2 = horizontal flip; noise (if given) only on the noised copy of view 2.
+    `cross_ids(ids, which)` maps a view's id map into the other view's frame (flip), zeroing a border."""
+
+    def __init__(self, border=0):
+        self.border = border
+
+    def __call__(self, image, noise=None):
+        flipped = torch.flip(image, dims=[3])
+        noised2 = flipped if noise is None else ops.add(flipped, noise)
+        return (image, image), (noised2, flipped)
+
+    def cross_ids(self, ids):
+        return ops.flip_labels(ids, self.border)
+
+
+class FirstStepTrainer:
+    def __init__(self, in_channels=1, enc_filters=(16, 32, 64, 128, 256), dec_filters=(32, 64, 128, 256, 512),
+                 dict_size=10, momentum=0.999, margin=0.5, loss_weight=None, lr=1e-4, betas=(0.5, 0.999),
+                 weight_decay=0.0, use_pixel_shuffle=False, dropped_skip_layers=(), views=None, device="cuda",
+                 encoder=None, decoder=None, data_parallel=False, use_onehot=False):
+        self.device = torch.device(device)
+        self.encoder = encoder if encoder is not None else UNetEncoder(
+            in_channels, list(enc_filters), dict_size, momentum, 'torch', False, 1, True)
+        self.decoder = decoder if decoder is not None else UNetDecoder(
+            enc_filters[0], in_channels, list(dec_filters), use_dropblock=False,
+            dropped_skip_layers=list(dropped_skip_layers), use_styled_up_block=True, use_pixel_shuffle=use_pixel_shuffle)
+        self.encoder.to(self.device).train()
+        self.decoder.to(self.device).train()
+        self.dict_size = dict_size
+        self.embed_loss = EmbeddingLoss(dict_size, margin, True, True)
+        self.one_hot_encoder = OneHotEncoder(n_classes=dict_size + 1)
+        self.use_onehot = use_onehot
+        self.w = loss_weight if loss_weight is not None else LossWeights()
+        self.views = views if views is not None else FlipViews()
+        # base.py:165-175: one Adam per sub-network over its trainable parameters
+        self.enc_optim = Adam([p for p in self.encoder.parameters() if p.requires_grad], lr=lr, betas=betas,
+                              weight_decay=weight_decay)
+        self.dec_optim = Adam([p for p in self.decoder.parameters() if p.requires_grad], lr=lr, betas=betas,
+                              weight_decay=weight_decay)
+        self.reducer = None
+        if data_parallel:
+            params = [p for p in self.decoder.parameters() if p.requires_grad][::-1] + \
+                     [p for p in self.encoder.parameters() if p.requires_grad][::-1]
+            self.reducer = GradientAllReducer(params)      # buckets in backward order: decoder tail first
+
+    def forward_losses(self, image, noise=None):
+        """Lines 73-137 of the reference step.  `image` is in [-1, 1] (dataloader convention)."""
+        w = self.w
+        (noised_1, clear_1), (noised_2, clear_2) = self.views(image, noise)
+        embed_1, l_commit_1, ids_1 = self.encoder(noised_1)
+        embed_2, l_commit_2, ids_2 = self.encoder(noised_2)
+        r_ids_1 = self.views.cross_ids(ids_1)
+        r_ids_2 = self.views.cross_ids(ids_2)
+        codebook = self.encoder.vq.get_codebook()
+        if self.use_onehot:      # the reference's literal route: (B,K+1,H,W) one-hot, class 0 dropped
+            oh1 = self.one_hot_encoder(r_ids_1)[:, 1:, ...]
+            oh2 = self.one_hot_encoder(r_ids_2)[:, 1:, ...]
+            l_cross, l_dist, l_reg = self.embed_loss(embed_1, oh1, embed_2, oh2, codebook)
+        else:
+            l_cross, l_dist, l_reg = self.embed_loss.forward_labels(embed_1, r_ids_1, embed_2, r_ids_2, codebook)
+        recon_1 = self.decoder(embed_1)
+        recon_2 = self.decoder(embed_2)
+        l_rec_1 = ops.mse_loss(recon_1, clear_1)
+        l_rec_2 = ops.mse_loss(recon_2, clear_2)
+        l_total = ops.weighted_sum(
+            [l_commit_1, l_commit_2, l_cross, l_dist, l_reg, l_rec_1, l_rec_2],
+            [w.commit, w.commit, w.cross, w.dist, w.reg, w.recon, w.recon])
+        return dict(total=l_total, commit_1=l_commit_1, commit_2=l_commit_2, cross=l_cross, dist=l_dist, reg=l_reg,
+                    recon_l1=l_rec_1, recon_l2=l_rec_2, ids_1=ids_1, ids_2=ids_2, recon_1=recon_1, recon_2=recon_2,
+                    embed_1=embed_1, embed_2=embed_2)
+
+    def training_step(self, batch, noise=None):
+        image = batch['image'] if isinstance(batch, dict) else batch
+        out = self.forward_losses(image, noise)
+        self.enc_optim.zero_grad()
+        self.dec_optim.zero_grad()
+        if self.reducer is not None:
+            self.reducer.prepare()
+        out["total"].backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.enc_optim.step()
+        self.dec_optim.step()
+        return out
+
+    @staticmethod
+    def scalars(out):
+        """Host copies of the logged scalars (one sync; keep out of timed regions)."""
+        f = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)  # noqa: E731
+        return dict(total=f(out["total"]), commit=f(out["commit_1"]) + f(out["commit_2"]), cross=f(out["cross"]),
+                    dist=f(out["dist"]), reg=f(out["reg"]), recon=f(out["recon_l1"]) + f(out["recon_l2"]))

@@ -1,0 +1,417 @@
+"""GPU parity tests: the HIP path (through the C ABI / hipops) against the reference's golden vectors and the
+CPU oracle.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (relative L2 unless stated): fp32 everywhere.
+  single kernels vs torch CPU ............ 2e-5
+  block forward / backward vs golden ..... 1e-4 / 1e-3
+  VQ ids ................................. bit-exact wherever the top-1/top-2 score gap > 1e-4*(1+|gap|)
+  training step (step 0) ................. losses 5e-4, recon 5e-3, gradients per fixture (GRAD_TOL)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close, build_models, check_init, step_cfg
+from test_oracle_golden import check_step, GRAD_TOL, apply_warm_state
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from hipops import ops
+    return ops
+
+
+# --------------------------------------------------------------------------------------------------
+# single kernels
+# --------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, H, W, C0, C1, up, Cout, ks, dil, bias, relu
+    (2, 16, 16, 16, 0, False, 32, 3, 1, True, False),
+    (2, 16, 16, 32, 0, False, 16, 3, 1, True, True),
+    (1, 24, 24, 16, 0, False, 16, 3, 6, False, False),     # dilated (ASPP)
+    (1, 20, 20, 32, 0, False, 32, 3, 18, False, False),    # dilation close to the image size
+    (2, 16, 16, 32, 16, True, 16, 3, 1, True, False),      # up-sampled + concat (UpBlock)
+    (2, 8, 8, 64, 0, True, 32, 3, 1, True, False),         # up-sampled only (StyledResUpBlock)
+    (2, 16, 16, 16, 0, False, 32, 1, 1, False, False),     # 1x1 projection
+    (3, 12, 10, 48, 0, False, 80, 3, 1, True, False),      # ragged tiles, H != W
+    (2, 16, 16, 128, 0, False, 160, 3, 1, True, False),    # >128 couts: two N tiles
+    (2, 16, 16, 1, 0, False, 16, 3, 1, True, False),       # 1-channel stem  (generic kernel)
+    (2, 16, 16, 32, 0, False, 1, 1, 1, True, False),       # 32->1 head      (generic kernel)
+    (2, 10, 10, 3, 0, False, 5, 3, 1, True, False),        # odd channels    (generic kernel)
+    (1, 2, 2, 32, 0, False, 64, 3, 1, True, False),        # tiny map (deepest level of a 32x32 input)
+    (2, 4, 4, 64, 32, True, 32, 3, 1, True, False),
+]
+
+
+def _conv_ref(x0, x1, w, b, up, dil, relu):
+    xin = x0
+    if up:
+        xin = xin.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    if x1 is not None:
+        xin = torch.cat([xin, x1], 1)
+    k = w.shape[-1]
+    y = F.conv2d(xin, w, b, padding=dil * (k // 2), dilation=dil)
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("backend", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case, backend):
+    ops = _ops()
+    N, H, W, C0, C1, up, Cout, ks, dil, bias, relu = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    hs, wsz = (H // 2, W // 2) if up else (H, W)
+    x0 = torch.randn(N, C0, hs, wsz, generator=g, dtype=torch.float64)
+    x1 = torch.randn(N, C1, H, W, generator=g, dtype=torch.float64) if C1 else None
+    w = torch.randn(Cout, C0 + C1, ks, ks, generator=g, dtype=torch.float64) * 0.2
+    b = torch.randn(Cout, generator=g, dtype=torch.float64) if bias else None
+    r = torch.randn(N, Cout, H, W, generator=g, dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (x0, x1, w, b) if t is not None]
+    it = iter(leaves)
+    rx0 = next(it); rx1 = next(it) if C1 else None; rw = next(it); rb = next(it) if bias else None
+    yref = _conv_ref(rx0, rx1, rw, rb, up, dil, relu)
+    (yref * r).sum().backward()
+
+    old = ops.set_conv_backend(backend)
+    try:
+        dx0 = x0.float().to(DEV).requires_grad_(True)
+        dx1 = x1.float().to(DEV).requires_grad_(True) if C1 else None
+        dw = w.float().to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        db = b.float().to(DEV).requires_grad_(True) if bias else None
+        y = ops.conv2d(dx0, dw, db, dilation=dil, up2x=up, skip=dx1, relu=relu)
+        (y * r.float().to(DEV)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_backend(old)
+    tol = 2e-5
+    assert_close(y, yref, tol, "y")
+    assert_close(dx0.grad, rx0.grad, tol, "dx0")
+    if C1:
+        assert_close(dx1.grad, rx1.grad, tol, "dx1")
+    assert_close(dw.grad, rw.grad, tol, "dw")
+    if bias:
+        assert_close(db.grad, rb.grad, tol, "db")
+
+
+def test_mfma_equals_generic_bitwise_shape():
+    """The MFMA kernel is a k-ordered fp32 FMA chain like the VALU kernel; they agree to rounding (not bitwise:
+    the k order inside an 8-channel group differs)."""
+    ops = _ops()
+    x = torch.randn(2, 32, 16, 16, device=DEV)
+    w = torch.randn(32, 32, 3, 3, device=DEV).contiguous(memory_format=torch.channels_last)
+    ya = ops.conv2d(x, w)
+    old = ops.set_conv_backend(1)
+    yb = ops.conv2d(x, w)
+    ops.set_conv_backend(old)
+    assert_close(ya, yb, 1e-6, "mfma vs generic")
+
+
+@pytest.mark.parametrize("shape,relu", [((2, 16, 16, 16), True), ((3, 48, 8, 8), False), ((2, 5, 10, 10), True),
+                                        ((1, 512, 4, 4), True), ((2, 160, 12, 12), True)])
+def test_instance_norm(shape, relu):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(*shape, generator=g, dtype=torch.float64) * 2 + 0.3).requires_grad_(True)
+    r = torch.randn(*shape, generator=g, dtype=torch.float64)
+    y = F.instance_norm(x, eps=1e-5)
+    y = torch.relu(y) if relu else y
+    (y * r).sum().backward()
+    dx = x.detach().float().to(DEV).requires_grad_(True)
+    dy = ops.instance_norm(dx, relu=relu)
+    (dy * r.float().to(DEV)).sum().backward()
+    assert_close(dy, y, 2e-5, "inorm y")
+    assert_close(dx.grad, x.grad, 5e-5, "inorm dx")
+
+
+def test_pool_add_tanh_mse():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(2, 16, 12, 12, generator=g).requires_grad_(True)
+    b = torch.randn(2, 16, 12, 12, generator=g).requires_grad_(True)
+    tgt = torch.randn(2, 16, 6, 6, generator=g)
+    out = torch.relu(a + b)
+    pooled = F.max_pool2d(out, 2)
+    loss = F.mse_loss(torch.tanh(pooled), tgt) + 0.1 * out.sum()
+    loss.backward()
+    da = a.detach().to(DEV).requires_grad_(True)
+    db = b.detach().to(DEV).requires_grad_(True)
+    dout = ops.add(da, db, relu=True)
+    dpool = ops.maxpool2(dout)
+    dmse = ops.mse_loss(ops.tanh(dpool), tgt.to(DEV))
+    dloss = ops.weighted_sum([dmse, (dout * 1.0).sum()], [1.0, 0.1])
+    dloss.backward()
+    assert_close(dpool, pooled, 1e-6, "pool")
+    assert_close(dloss, loss, 1e-5, "loss")
+    assert_close(da.grad, a.grad, 1e-5, "da")
+    assert_close(db.grad, b.grad, 1e-5, "db")
+
+
+def test_maxpool_ties_route_to_first():
+    """A piecewise-constant (quantised) map puts max-pool windows on exact ties; the gradient must go to the first
+    maximum in row-major window order, as ATen does (see oracle STE note)."""
+    ops = _ops()
+    x = torch.ones(1, 4, 4, 4)
+    x[0, :, 2:, :] = 2.0
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(xr, 2).sum().backward()
+    dx = x.to(DEV).requires_grad_(True)
+    ops.maxpool2(dx).sum().backward()
+    assert torch.equal(dx.grad.cpu(), xr.grad)
+
+
+# --------------------------------------------------------------------------------------------------
+# blocks against the reference's golden vectors
+# --------------------------------------------------------------------------------------------------
+def _run_block(golden, tag, mod, n_in, train=True, fwd_tol=1e-4, bwd_tol=1e-3):
+    g = golden("blocks.npz")
+    sd = {k[2:]: v for k, v in g.group(tag).items() if k.startswith("P.")}
+    mod.load_state_dict(sd, strict=True)
+    mod.to(DEV).train(train)
+    ins = [g.t("%s/in.%d" % (tag, i), DEV).requires_grad_(True) for i in range(n_in)]
+    outs = mod(*ins)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    loss = None
+    for i, o in enumerate(outs):
+        t = (o * g.t("%s/R.%d" % (tag, i), DEV)).sum()
+        loss = t if loss is None else loss + t
+    loss.backward()
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert_close(o, g["%s/out.%d" % (tag, i)], fwd_tol, "%s out.%d" % (tag, i))
+    for i, x in enumerate(ins):
+        key = "%s/gin.%d" % (tag, i)
+        if key in g.files:
+            assert_close(x.grad, g[key], bwd_tol, key, atol=1e-6)
+    for k, p in mod.named_parameters():
+        assert_close(p.grad, g["%s/gP.%s" % (tag, k)], bwd_tol, "%s gP.%s" % (tag, k), atol=2e-5)
+    for k, v in mod.state_dict().items():
+        key = "%s/after.%s" % (tag, k)
+        if key in g.files:
+            assert_close(v.float(), g[key].astype(np.float32), 1e-5, key)
+
+
+def test_blocks_golden(golden):
+    from networks import blocks as B
+    from networks.aspp import ASPP
+    _run_block(golden, "double_conv", B.DoubleConv(16, 32), 1)
+    _run_block(golden, "double_conv_odd", B.DoubleConv(3, 5), 1)
+    _run_block(golden, "res_block", B.ResBlock(16, 32), 1)
+    _run_block(golden, "res_block_c1", B.ResBlock(1, 16), 1)
+    _run_block(golden, "up_block", B.UpBlock(32 + 16, 16), 2)
+    _run_block(golden, "styled_denorm", B.StyledDenorm(16, 32), 2)
+    _run_block(golden, "styled_denorm_eval", B.StyledDenorm(16, 16), 2, train=False)
+    _run_block(golden, "styled_res_up", B.StyledResUpBlock(32, 16, 16, use_pixel_shuffle=False), 2)
+    _run_block(golden, "aspp", ASPP(16, 16, [2, 6, 12, 18]), 1)
+
+
+# --------------------------------------------------------------------------------------------------
+# vector quantiser
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["k10", "k64", "k1024"])
+def test_vq_golden(golden, tag):
+    from networks.vq import VQ
+    g = golden("vq.npz")
+    K, D = g[tag + "/embed0"].shape
+    vq = VQ(emb_dim=D, dict_size=K, momentum=float(g[tag + "/momentum"]), eps=1e-5, knn_backend="torch")
+    vq.embed.copy_(g.t(tag + "/embed0"))
+    vq.embed_avg.copy_(g.t(tag + "/embed0").t())
+    vq.to(DEV).train()
+    for call in (1, 2):
+        x = g.t("%s/x%d" % (tag, call), DEV).requires_grad_(True)
+        q, commit, ids = vq(x)
+        ((q * g.t("%s/R%d" % (tag, call), DEV)).sum() + 3.0 * commit).backward()
+        ids = ids.transpose(1, 2).cpu().numpy()        # module returns the reference's (B,W,H) order
+        gap = g["%s/gap%d" % (tag, call)]
+        clear = gap > 1e-4 * (1 + np.abs(gap))
+        assert np.array_equal(ids[clear], g["%s/ids%d" % (tag, call)][clear]), "ids differ on tie-free pixels"
+        assert np.mean(ids == g["%s/ids%d" % (tag, call)]) > 0.999
+        assert_close(q, g["%s/q%d" % (tag, call)], 1e-5 if call == 1 else 5e-5, "q")   # call 2 gathers the EMA-updated codebook
+        assert_close(commit, g["%s/commit%d" % (tag, call)], 1e-5, "commit")
+        assert_close(x.grad, g["%s/gx%d" % (tag, call)], 1e-5, "gx")
+        for b in ("embed", "cluster_size", "embed_avg"):
+            assert_close(getattr(vq, b), g["%s/%s_after%d" % (tag, b, call)], 5e-5, "%s after call %d" % (b, call))
+        assert abs(float(vq.cluster_size.sum())) > 0
+    vq.eval()
+    before = vq.embed.clone()
+    q, commit, ids = vq(g.t(tag + "/x_eval", DEV))
+    assert torch.equal(before, vq.embed), "eval mode must not touch the codebook"
+    assert np.mean(ids.transpose(1, 2).cpu().numpy() == g[tag + "/ids_eval"]) > 0.999
+    assert_close(commit, g[tag + "/commit_eval"], 1e-4, "commit eval")
+    look = vq.lookup(torch.from_numpy(g[tag + "/ids_eval"]).transpose(1, 2).contiguous().to(DEV))
+    assert_close(look, g[tag + "/lookup_eval"], 1e-4, "lookup")
+
+
+def test_vq_conservation_and_ties():
+    """Properties: sum of counts == N pixels; all-equal scores resolve to the lowest index; ids in range."""
+    ops = _ops()
+    K, D = 10, 16
+    embed = torch.randn(K, D, device=DEV)
+    embed[3] = embed[7]                      # duplicate code -> exact tie, must pick 3
+    x = embed[7][None, :, None, None].expand(2, D, 8, 8).contiguous()
+    cs = torch.zeros(K, device=DEV); ea = embed.t().contiguous()
+    q, commit, ids = ops.vq_quantize(x, embed.clone(), cs, ea, True, 0.5, 1e-5)
+    assert int(ids.min()) == 3 and int(ids.max()) == 3
+    assert abs(float(cs.sum()) - 0.5 * 2 * 8 * 8) < 1e-3
+    assert float(commit) < 1e-12
+
+
+# --------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------
+def test_losses_golden(golden):
+    from functions import EmbeddingLoss, OneHotEncoder
+    g = golden("losses.npz")
+    for tag, use_d in (("full", True), ("cross_only", None)):
+        cb = g.t(tag + "/cb", DEV)
+        K = cb.shape[1]
+        oh = OneHotEncoder(K + 1)
+        onehot1 = oh(g.t(tag + "/ids1", DEV).int())
+        assert np.array_equal(onehot1.cpu().numpy(), g[tag + "/onehot1"])
+        L = EmbeddingLoss(K, 0.5, use_d, use_d)
+        for route in ("dense", "labels"):
+            e1 = g.t(tag + "/e1", DEV).requires_grad_(True)
+            e2 = g.t(tag + "/e2", DEV).requires_grad_(True)
+            if route == "dense":
+                r1 = onehot1[:, 1:].contiguous()
+                r2 = oh(g.t(tag + "/ids2", DEV).int())[:, 1:].contiguous()
+                lc, ld, lr = L(e1, r1, e2, r2, cb)
+            else:
+                lc, ld, lr = L.forward_labels(e1, g.t(tag + "/ids1", DEV).int(), e2, g.t(tag + "/ids2", DEV).int(), cb)
+            lc.backward()
+            assert_close(lc, g[tag + "/l_cross"], 1e-5, "l_cross " + route)
+            assert_close(float(ld), g[tag + "/l_dist"], 1e-5, "l_dist")
+            assert_close(float(lr), g[tag + "/l_reg"], 1e-5, "l_reg")
+            assert_close(e1.grad, g[tag + "/ge1"], 1e-5, "ge1 " + route)
+            assert_close(e2.grad, g[tag + "/ge2"], 1e-5, "ge2 " + route)
+
+
+# --------------------------------------------------------------------------------------------------
+# the training step
+# --------------------------------------------------------------------------------------------------
+def _hip_trainer(g):
+    from trainers import FirstStepTrainer, FlipViews
+    enc, dec = build_models(g.group("cfg"))
+    check_init(g, enc, dec)
+    sd = enc.state_dict()
+    apply_warm_state(g, sd)
+    cfg = step_cfg(g)
+    tr = FirstStepTrainer(dict_size=cfg["dict_size"], momentum=cfg["momentum"], margin=cfg["margin"],
+                          lr=cfg["optim"]["lr"], betas=cfg["optim"]["betas"], views=FlipViews(border=cfg["border"]),
+                          encoder=enc, decoder=dec, device=DEV)
+    return tr, cfg
+
+
+@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg32.npz"])
+def test_first_step_golden(golden, name):
+    from oracle import vqwnet_ref as O
+    g = golden(name)
+    tr, cfg = _hip_trainer(g)
+    # eval-mode forward + mask-guided reconstruction on the initial state (run_recon.py:179-194)
+    tr.encoder.eval(); tr.decoder.eval()
+    with torch.no_grad():
+        q, _, ids = tr.encoder(g.t("eval/image", DEV))
+        rec = tr.decoder(q)
+        assert np.mean(ids.cpu().numpy() == g["eval/ids"]) > 0.999
+        assert_close(rec, g["eval/recon"], 5e-3, "eval recon")
+        from hipops import ops
+        mask, ids0, scale = ops.mask_scale(g.t("recon/label_map", DEV))
+        emb = ops.vq_lookup(ids0, tr.encoder.vq.embed, mask=mask, scale=scale)
+        assert_close(emb, g["recon/embed"], 1e-6, "masked embed")
+        assert_close(tr.decoder(emb), g["recon/recon"], 5e-3, "mask-guided recon")
+        e2 = tr.encoder.get_embed_from_ids(ids0)
+        assert_close(e2 * mask[:, None].float() * scale, g["recon/embed"], 1e-6, "get_embed_from_ids")
+    tr.encoder.train(); tr.decoder.train()
+    gt, ml, lb = GRAD_TOL[name]
+    lr = cfg["optim"]["lr"]
+    for s in range(int(g["cfg/n_steps"])):
+        out = tr.training_step({"image": g.t("step%d/image" % s, DEV)}, noise=g.t("step%d/noise" % s, DEV))
+        torch.cuda.synchronize()
+        sc = tr.scalars(out)
+        rec = dict(sc)
+        rec.update(ids_1=out["ids_1"], ids_2=out["ids_2"], recon_1=out["recon_1"], recon_2=out["recon_2"])
+        rec["grads_enc"] = {k: p.grad for k, p in tr.encoder.named_parameters()}
+        rec["grads_dec"] = {k: p.grad for k, p in tr.decoder.named_parameters()}
+        PE = dict(tr.encoder.state_dict())
+        PD = dict(tr.decoder.state_dict())
+        check_step(g, s, rec, PE, PD, lr, tight=(s == 0), tol=5e-4, grad_tol=max(gt, 5e-3), max_loose=ml + 2,
+                   loose_bound=lb)
+
+
+def test_step_vs_oracle_128():
+    """R-cfg at 128x128, batch 2, warm VQ state: HIP step vs the CPU oracle on the same seeded inputs."""
+    from oracle import vqwnet_ref as O
+    from trainers import FirstStepTrainer, FlipViews
+    from networks import UNetEncoder, UNetDecoder
+    torch.manual_seed(3)
+    K = 10
+    enc = UNetEncoder(1, [16, 32, 64, 128, 256], K, 0.999, 'torch', False, 1, True)
+    dec = UNetDecoder(16, 1, [32, 64, 128, 256, 512], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
+    B, S = 2, 128
+    with torch.no_grad():
+        enc.vq.embed.mul_(0.7)
+        enc.vq.cluster_size.fill_(B * S * S / K)
+        enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
+    PE = {k: v.detach().clone().contiguous() for k, v in enc.state_dict().items()}
+    PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
+    cfg = dict(dict_size=K, margin=0.5, border=2, momentum=0.999,
+               weights=dict(commit=1.0, cross=1.0, dist=1.0, reg=1.0, recon=1.0),
+               optim=dict(lr=1e-4, betas=(0.5, 0.999), weight_decay=0.0))
+    image, noise = O.synthetic_slices(B, S, 77)
+    otr = O.FirstStepTrainer(PE, PD, cfg)
+    ref = otr.step(image, noise)
+    tr = FirstStepTrainer(dict_size=K, momentum=0.999, margin=0.5, views=FlipViews(border=2), encoder=enc, decoder=dec,
+                          device=DEV)
+    out = tr.training_step({"image": image.to(DEV)}, noise=noise.to(DEV))
+    sc = tr.scalars(out)
+    for k in ("total", "cross", "reg", "dist"):
+        assert_close(sc[k], float(ref[k]), 5e-4, k)
+    assert_close(sc["commit"], float(ref["commit"]), 5e-4, "commit")
+    assert_close(sc["recon"], float(ref["recon"]), 5e-4, "recon")
+    for v in ("1", "2"):
+        gap = ref["gap_" + v].numpy()
+        clear = gap > 1e-3 * (1 + np.abs(gap))
+        assert np.array_equal(out["ids_" + v].cpu().numpy()[clear], ref["ids_" + v].numpy()[clear])
+        assert_close(out["recon_" + v], ref["recon_" + v], 5e-3, "recon_" + v)
+    errs = []
+    for pre, mod, grads in (("enc", tr.encoder, ref["grads_enc"]), ("dec", tr.decoder, ref["grads_dec"])):
+        gmax = max(float(gr.norm()) for gr in grads.values() if gr is not None)
+        for k, p in mod.named_parameters():
+            gr = grads[k]
+            if gr is None or float(gr.norm()) < 1e-6 * gmax:
+                continue
+            errs.append(float((p.grad.cpu() - gr).norm() / gr.norm()))
+    errs = np.array(errs)
+    assert np.median(errs) < 2e-2 and np.quantile(errs, 0.9) < 0.1 and errs.max() < 0.5, \
+        "grad errors: median %.3e p90 %.3e max %.3e" % (np.median(errs), np.quantile(errs, 0.9), errs.max())
+
+
+def test_full_size_properties():
+    """BASELINE config 2 shapes (256x256, batch 32): properties that do not need the oracle at full size."""
+    from trainers import FirstStepTrainer
+    from oracle.vqwnet_ref import synthetic_slices
+    torch.manual_seed(0)
+    B, S, K = 32, 256, 10
+    tr = FirstStepTrainer(device=DEV)
+    image, noise = synthetic_slices(B, S, 1234)
+    image, noise = image.to(DEV), noise.to(DEV)
+    cs0 = tr.encoder.vq.cluster_size.clone()
+    out = tr.training_step({"image": image}, noise=noise)
+    sc = tr.scalars(out)
+    assert all(np.isfinite(v) for v in sc.values()), sc
+    for v in ("1", "2"):
+        ids = out["ids_" + v]
+        assert ids.shape == (B, S, S) and int(ids.min()) >= 1 and int(ids.max()) <= K
+    # EMA conservation: cluster_size after two updates = m^2*cs0 + (1-m)*(m*N + N) with N = B*S*S pixels per view
+    m, N = 0.999, B * S * S
+    expect = m * m * float(cs0.sum()) + (1 - m) * (m * N + N)
+    assert abs(float(tr.encoder.vq.cluster_size.sum()) - expect) <= 1e-3 * expect
+    rec = out["recon_1"]
+    assert float(rec.abs().max()) <= 1.0 and rec.shape == (B, 1, S, S)
+    # quantised embeddings are exact codebook rows: every pixel equals one of <= K distinct vectors
+    e = out["embed_1"].detach().permute(0, 2, 3, 1).reshape(-1, 16)
+    assert torch.unique(e[: 65536], dim=0).shape[0] <= K
+    for p in list(tr.encoder.parameters()) + list(tr.decoder.parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
