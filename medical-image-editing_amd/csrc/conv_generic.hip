@@ -106,18 +106,37 @@ __global__ void __launch_bounds__(256) k_conv_direct_wgrad(ConvIn in, const floa
     if (threadIdx.x == 0) part[(long)s * gridDim.x + o] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// out[i] = sum_s part[s][i]
-__global__ void k_reduce_rows(const float* __restrict__ part, float* __restrict__ out, long n, int rows) {
-    long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float a = 0.f;
-        for (int r = 0; r < rows; ++r) a += part[(long)r * n + i];
-        out[i] = a;
+// out[i] = sum_s part[s][i].  Workgroup = 64 columns x 16 row groups: every thread sums rows g, g+16, ... of its
+// column (coalesced 256-B row segments), then a fixed-order LDS tree over the 16 groups -> deterministic.
+__global__ void __launch_bounds__(1024) k_reduce_rows(const float* __restrict__ part, float* __restrict__ out, long n, int rows) {
+    __shared__ float sm[16][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + cx;
+    float a = 0.f;
+    if (i < n) {
+        int r = g;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (; r + 48 < rows; r += 64) {
+            a0 += part[(long)r * n + i];
+            a1 += part[(long)(r + 16) * n + i];
+            a2 += part[(long)(r + 32) * n + i];
+            a3 += part[(long)(r + 48) * n + i];
+        }
+        for (; r < rows; r += 16) a0 += part[(long)r * n + i];
+        a = (a0 + a1) + (a2 + a3);
+    }
+    sm[g][cx] = a;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][cx];
+        out[i] = t;
     }
 }
 
 int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st) {
-    k_reduce_rows<<<stream_grid(n, 256), 256, 0, st>>>(part, out, n, rows);
+    k_reduce_rows<<<(unsigned)((n + 63) / 64), 1024, 0, st>>>(part, out, n, rows);
     VQW_LAUNCH_CHECK("reduce_rows");
     return VQW_OK;
 }

@@ -38,6 +38,8 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
 // =============================================================================================
 // forward / dgrad
 // =============================================================================================
+// Index arithmetic is 32-bit (the host checks numel < 2^31) and hoisted: pixel coordinates once per thread,
+// bounds / base offsets once per TAP, only an add per channel chunk.
 template <int BM, int BN, int WM, int WN, int KC>
 __global__ void __launch_bounds__(256, 2)
 k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int N, int H,
@@ -46,6 +48,7 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
     constexpr int C4 = KC / 4;            // float4 per row
     constexpr int LA = BM * C4 / 256;     // A float4 loads per thread per chunk
     constexpr int LB = (BN * C4 + 255) / 256;
+    constexpr int RSTEP = 256 / C4;       // A rows covered by one pass of the workgroup
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
@@ -55,66 +58,88 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int Cin = in.C0 + in.C1;
+    const int C0 = in.C0, C1 = in.C1, Cin = C0 + C1;
     const int taps = ks * ks, half = ks >> 1;
-    const long P = (long)N * H * W;
+    const unsigned P = (unsigned)N * H * W;
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = swz % ntn, tile_m = swz / ntn;
-    const long p_base = (long)tile_m * BM;
+    const unsigned p_base = (unsigned)tile_m * BM;
     const int co_base = tile_n * BN;
     const int Hs = H >> 1, Ws = W >> 1;
+    const int up0 = in.up0;
 
     // per-thread pixel coordinates of the A rows it loads (fixed for the whole K loop)
-    int a_n[LA], a_h[LA], a_w[LA];
+    const int a_c = (tid % C4) * 4;       // channel offset inside a chunk
+    const int a_row = tid / C4;
+    int a_h[LA], a_w[LA];
+    unsigned a_pix[LA], a_upb[LA];
     bool a_ok[LA];
-    const int a_c4 = tid % C4;
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
-        int m = (tid + j * 256) / C4;
-        long p = p_base + m;
+        unsigned p = p_base + a_row + j * RSTEP;
         a_ok[j] = p < P;
-        long pp = a_ok[j] ? p : 0;
-        a_w[j] = (int)(pp % W);
-        long q = pp / W;
-        a_h[j] = (int)(q % H);
-        a_n[j] = (int)(q / H);
+        unsigned pp = a_ok[j] ? p : 0u;
+        unsigned q = pp / (unsigned)W;
+        a_w[j] = (int)(pp - q * W);
+        unsigned n = q / (unsigned)H;
+        a_h[j] = (int)(q - n * H);
+        a_pix[j] = pp;
+        a_upb[j] = n * (unsigned)(Hs * Ws);
     }
-    const int cpt = (Cin + KC - 1) / KC;  // chunks per tap
-    const int nchunks = taps * cpt;
+    // weight rows this thread loads
+    const float* b_ptr[LB];
+    bool b_ok[LB];
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        int f = tid + j * 256;
+        int row = f / C4;
+        int co = co_base + row;
+        b_ok[j] = (BN * C4 % 256 == 0 || f < BN * C4) && co < Cout;
+        b_ptr[j] = w + (size_t)(b_ok[j] ? co : 0) * taps * Cin + (f % C4) * 4;
+    }
 
-    float4 ra[LA], rb[LB];
-    auto load_chunk = [&](int it) {
-        const int t = it / cpt, cc = (it - t * cpt) * KC;
-        const int dyy = (t / ks - half) * dil, dxx = (t % ks - half) * dil;
-        const int c = cc + a_c4 * 4;
+    // loader state: current tap / channel chunk, per-tap validity and element offsets
+    int l_t = 0, l_cc = 0, l_ky = 0, l_kx = 0;
+    bool t_ok[LA];
+    unsigned t_off0[LA], t_off1[LA];
+    auto setup_tap = [&]() {
+        const int dyy = (l_ky - half) * dil, dxx = (l_kx - half) * dil;
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             int hy = a_h[j] + dyy, wx = a_w[j] + dxx;
-            bool ok = a_ok[j] && hy >= 0 && hy < H && wx >= 0 && wx < W && c < Cin;
-            const float* src;
-            if (c < in.C0) {
-                src = in.up0 ? in.src0 + (((long)a_n[j] * Hs + (hy >> 1)) * Ws + (wx >> 1)) * in.C0 + c
-                             : in.src0 + (((long)a_n[j] * H + hy) * W + wx) * in.C0 + c;
-            } else {
-                src = in.src1 + (((long)a_n[j] * H + hy) * W + wx) * in.C1 + (c - in.C0);
-            }
-            ra[j] = ld4_or_zero(src, ok);
+            t_ok[j] = a_ok[j] && (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
+            unsigned pix = a_pix[j] + (unsigned)(dyy * W + dxx);
+            t_off0[j] = up0 ? (a_upb[j] + (unsigned)((hy >> 1) * Ws + (wx >> 1))) * (unsigned)C0 : pix * (unsigned)C0;
+            t_off1[j] = pix * (unsigned)C1;
         }
+    };
+    float4 ra[LA], rb[LB];
+    auto load_chunk = [&]() {     // loads chunk (l_t, l_cc) into registers, then advances the loader state
+        const int c = l_cc + a_c;
+        const bool from0 = c < C0;
+        const bool cok = c < Cin;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            const float* src = from0 ? in.src0 + t_off0[j] + c : in.src1 + t_off1[j] + (c - C0);
+            ra[j] = ld4_or_zero(src, t_ok[j] && cok);
+        }
+        const int wofs = l_t * Cin + l_cc;
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
-            int f = tid + j * 256;
-            int row = f / C4, c4 = f % C4;
-            int co = co_base + row, cb = cc + c4 * 4;
-            bool ok = (BN * C4 % 256 == 0 || f < BN * C4) && co < Cout && cb < Cin;
-            rb[j] = ld4_or_zero(w + ((long)co * taps + t) * Cin + cb, ok);
+            int cb = l_cc + ((tid + j * 256) % C4) * 4;
+            rb[j] = ld4_or_zero(b_ptr[j] + wofs, b_ok[j] && cb < Cin);
+        }
+        l_cc += KC;
+        if (l_cc >= Cin) {
+            l_cc = 0;
+            ++l_t;
+            if (++l_kx == ks) { l_kx = 0; ++l_ky; }
+            if (l_t < taps) setup_tap();
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            int f = tid + j * 256;
-            *(float4*)&As[buf][(f / C4) * LDK + (f % C4) * 4] = ra[j];
-        }
+        for (int j = 0; j < LA; ++j) *(float4*)&As[buf][(a_row + j * RSTEP) * LDK + a_c] = ra[j];
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
             int f = tid + j * 256;
@@ -132,13 +157,15 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
 
     const int wm0 = (wv / WAVES_N) * WM, wn0 = (wv % WAVES_N) * WN;
     const int lrow = lane & 31, lk = (lane >> 5) * 4;
+    const int nchunks = taps * ((Cin + KC - 1) / KC);
 
-    load_chunk(0);
+    setup_tap();
+    load_chunk();
     store_chunk(0);
     __syncthreads();
     for (int it = 0; it < nchunks; ++it) {
         const int cur = it & 1;
-        if (it + 1 < nchunks) load_chunk(it + 1);
+        if (it + 1 < nchunks) load_chunk();
 #pragma unroll
         for (int kg = 0; kg < KC / 8; ++kg) {
             float4 a[TM], b[TN];
@@ -171,10 +198,10 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                long p = p_base + wm0 + i * 32 + row;
+                unsigned p = p_base + wm0 + i * 32 + row;
                 if (cok && p < P) {
                     float v = acc[i][j][r] + bv;
-                    y[p * Cout + co] = relu ? fmaxf(v, 0.f) : v;
+                    y[(size_t)p * Cout + co] = relu ? fmaxf(v, 0.f) : v;
                 }
             }
         }
@@ -189,25 +216,43 @@ bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks) {
     return (in.C0 % 4 == 0) && (in.C1 % 4 == 0) && Cin >= 8 && Cout >= 8;
 }
 
-template <int BM, int BN, int WM, int WN>
+static inline bool fits_u32(long P, int Cin, int Cout) {
+    long c = Cin > Cout ? Cin : Cout;
+    return P * c < (1L << 31);
+}
+
+template <int BM, int BN, int WM, int WN, int KC>
 static int launch_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks,
                       int dil, int relu, hipStream_t st) {
     long P = (long)N * H * W;
     int ntm = ceil_div(P, BM), ntn = ceil_div(Cout, BN);
-    k_conv_mfma_fwd<BM, BN, WM, WN, 16><<<ntm * ntn, 256, 0, st>>>(in, w, bias, y, N, H, W, Cout, ks, dil, ntn, relu);
+    k_conv_mfma_fwd<BM, BN, WM, WN, KC><<<ntm * ntn, 256, 0, st>>>(in, w, bias, y, N, H, W, Cout, ks, dil, ntn, relu);
     VQW_LAUNCH_CHECK("conv_mfma_fwd");
     return VQW_OK;
 }
 
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
                   int relu, hipStream_t st) {
-    if (Cout > 64) return launch_fwd<128, 128, 64, 64>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
-    if (Cout > 32) return launch_fwd<128, 64, 64, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
-    return launch_fwd<256, 32, 64, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    const int Cin = in.C0 + in.C1;
+    if (!fits_u32((long)N * H * W, Cin, Cout)) return conv_direct_fwd(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    const bool k32 = (Cin % 32 == 0);
+    if (Cout > 64) {
+        if (k32) return launch_fwd<128, 128, 64, 64, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+        return launch_fwd<128, 128, 64, 64, 16>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    }
+    if (Cout > 32) {
+        if (k32) return launch_fwd<128, 64, 64, 32, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+        return launch_fwd<128, 64, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    }
+    if (k32) return launch_fwd<128, 32, 32, 32, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    return launch_fwd<256, 32, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
 }
 
+// 0 = auto, 1 = per-tap kernel only, (testing / A-B timing)
+int g_wgrad_variant = 0;
+
 // =============================================================================================
-// wgrad
+// wgrad, one tap per workgroup (1x1 convs, ragged widths)
 // =============================================================================================
 template <int BM, int BN, int WM, int WN, int KP>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN))
@@ -242,40 +287,53 @@ k_conv_mfma_wgrad(ConvIn in, const float* __restrict__ dy, float* __restrict__ p
     if (p_end > P) p_end = P;
     const int nchunks = p_begin < p_end ? (int)((p_end - p_begin + KP - 1) / KP) : 0;
 
+    // Loader state (32-bit, incremental): every load slot (thread, j) walks pixels p, p+KP, p+2KP, ... so its
+    // (h, w) coordinates are advanced by KP per chunk instead of being re-derived by division.
+    constexpr int DROW = NT / (BM / 4);   // pixel rows covered by one pass over the dy tile
+    constexpr int XROW = NT / (BN / 4);
+    static_assert(NT % (BM / 4) == 0 && NT % (BN / 4) == 0, "tile rows must divide the workgroup");
+    const int d_c = co_base + (tid % (BM / 4)) * 4;
+    const bool d_cok = d_c < Cout;
+    const int x_c = ci_base + (tid % (BN / 4)) * 4;
+    const bool x_cok = x_c < Cin;
+    const bool x_from0 = x_c < in.C0;
+    const unsigned xC = x_from0 ? (unsigned)in.C0 : (unsigned)in.C1;
+    const float* x_src = x_from0 ? in.src0 + x_c : in.src1 + (x_c - in.C0);
+    const bool x_up = x_from0 && in.up0;
+    const int shift = dyy * W + dxx;
+    unsigned d_p = (unsigned)p_begin + tid / (BM / 4);       // pixel of dy load slot 0 (slot j adds j*DROW)
+    unsigned x_p[LX];
+    int x_h[LX], x_w[LX], x_n[LX];
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+        unsigned p = (unsigned)p_begin + tid / (BN / 4) + j * XROW;
+        x_p[j] = p;
+        unsigned q = p / (unsigned)W;
+        x_w[j] = (int)(p - q * W);
+        unsigned n = q / (unsigned)H;
+        x_h[j] = (int)(q - n * H);
+        x_n[j] = (int)n;
+    }
+    const unsigned pe = (unsigned)p_end;
     float4 rd[LD], rx[LX];
-    auto load_chunk = [&](int it) {
-        const long p0 = p_begin + (long)it * KP;
+    auto load_chunk = [&]() {
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
-            int f = tid + j * NT;
-            int k = f / (BM / 4), c4 = f % (BM / 4);
-            long p = p0 + k;
-            int co = co_base + c4 * 4;
-            bool ok = p < p_end && co < Cout;
-            rd[j] = ld4_or_zero(dy + p * Cout + co, ok);   // Cout % 4 == 0 (conv_mfma_wgrad_ok)
+            unsigned p = d_p + j * DROW;
+            rd[j] = ld4_or_zero(dy + (size_t)p * Cout + d_c, p < pe && d_cok);   // Cout % 4 == 0 (conv_mfma_wgrad_ok)
         }
+        d_p += KP;
 #pragma unroll
         for (int j = 0; j < LX; ++j) {
-            int f = tid + j * NT;
-            int k = f / (BN / 4), c4 = f % (BN / 4);
-            long p = p0 + k;
-            bool ok = p < p_end;
-            long pp = ok ? p : 0;
-            int x = (int)(pp % W);
-            long q = pp / W;
-            int yy = (int)(q % H);
-            int n = (int)(q / H);
-            int hy = yy + dyy, wx = x + dxx;
-            int c = ci_base + c4 * 4;
-            ok = ok && hy >= 0 && hy < H && wx >= 0 && wx < W && c < Cin;
-            const float* src;
-            if (c < in.C0) {
-                src = in.up0 ? in.src0 + (((long)n * Hs + (hy >> 1)) * Ws + (wx >> 1)) * in.C0 + c
-                             : in.src0 + (((long)n * H + hy) * W + wx) * in.C0 + c;
-            } else {
-                src = in.src1 + (((long)n * H + hy) * W + wx) * in.C1 + (c - in.C0);
-            }
-            rx[j] = ld4_or_zero(src, ok);
+            int hy = x_h[j] + dyy, wx = x_w[j] + dxx;
+            bool ok = x_p[j] < pe && x_cok && (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
+            unsigned pix = x_up ? ((unsigned)x_n[j] * Hs + (hy >> 1)) * Ws + (wx >> 1) : x_p[j] + (unsigned)shift;
+            rx[j] = ld4_or_zero(x_src + (size_t)pix * xC, ok);
+            // advance this slot by KP pixels
+            x_p[j] += KP;
+            x_w[j] += KP;
+            while (x_w[j] >= W) { x_w[j] -= W; x_h[j] += 1; }
+            while (x_h[j] >= H) { x_h[j] -= H; x_n[j] += 1; }
         }
     };
     auto store_chunk = [&](int buf) {
@@ -303,13 +361,13 @@ k_conv_mfma_wgrad(ConvIn in, const float* __restrict__ dy, float* __restrict__ p
     const int lcol = lane & 31, lk = lane >> 5;
 
     if (nchunks > 0) {
-        load_chunk(0);
+        load_chunk();
         store_chunk(0);
     }
     __syncthreads();
     for (int it = 0; it < nchunks; ++it) {
         const int cur = it & 1;
-        if (it + 1 < nchunks) load_chunk(it + 1);
+        if (it + 1 < nchunks) load_chunk();
 #pragma unroll 8
         for (int k = 0; k < KP; k += 2) {
             float a[TM], bb[TN];
@@ -343,6 +401,169 @@ k_conv_mfma_wgrad(ConvIn in, const float* __restrict__ dy, float* __restrict__ p
     }
 }
 
+// =============================================================================================
+// wgrad, all nine taps per wave ("wg9"): the 3x3 workhorse
+// =============================================================================================
+// One WAVE = one worker: a 32(co) x 32(ci) weight tile for ALL 9 taps (9 x 16 accumulator registers) over a strided
+// set of 32-pixel chunks.  A chunk lies inside one image row (W % 32 == 0), so the X operand of tap (ky,kx) is the
+// row segment of row h+(ky-1)*d shifted by (kx-1)*d: three zero-filled halo segments [32+2d px][32 ci] are staged once
+// per chunk in the wave's private LDS area next to the dY tile [32 px][32 co]; every A fragment (dY) read feeds 9 MFMAs.
+// No workgroup barrier anywhere: a wave only reads LDS it wrote itself (LDS ops of one wave execute in order).
+// Global loads for chunk i+1 are issued before the 144 MFMAs of chunk i (register prefetch) when they fit in registers.
+// Partial slabs [worker-split][Cout][9][Cin] are reduced in fixed order by reduce_rows.
+template <int NXL, bool PREFETCH>
+__global__ void __launch_bounds__(256, 2)
+k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part, int N, int H, int W, int Cout, int dil,
+              int n_ci_t, int ntiles, int nsplit_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int C0 = in.C0, C1 = in.C1, Cin = C0 + C1;
+    const int SEG = 32 + 2 * dil;                   // pixels per halo row segment
+    const int XF4 = 3 * SEG * 8;                    // float4 per X stage (3 segments x SEG px x 32 ci)
+    const int wave_floats = 32 * 32 + 3 * SEG * 32;
+    float* Ds = smem + wv * wave_floats;            // [32 px][32 co]
+    float* Xs = Ds + 32 * 32;                       // [3][SEG px][32 ci]
+    const int tile = blockIdx.x % ntiles, sblk = blockIdx.x / ntiles;
+    const int co_base = (tile / n_ci_t) * 32, ci_base = (tile % n_ci_t) * 32;
+    const int split = sblk * 4 + wv, nsplits = nsplit_blocks * 4;
+    const unsigned P = (unsigned)N * H * W;
+    const int nchunks = (int)(P >> 5);
+    const int Hs = H >> 1, Ws = W >> 1;
+
+    // chunk-invariant part of this lane's load slots (slot i of a lane = float4 number lane + 64*i of the stage;
+    // 8 lanes per pixel, so its pixel slot is (lane>>3) + 8*i — nothing to keep in registers)
+    const int d_c = co_base + (lane & 7) * 4;
+    const bool d_ok = d_c < Cout;
+    const int x_c = ci_base + (lane & 7) * 4;
+    const bool x_cok = x_c < Cin;
+    const bool x_from0 = x_c < C0;
+    const unsigned xC = x_from0 ? (unsigned)C0 : (unsigned)C1;
+    const float* x_src = x_from0 ? in.src0 + x_c : in.src1 + (x_c - C0);
+    const bool x_up = x_from0 && in.up0;
+    const int lpx = lane >> 3;
+
+    float4 rd[4], rx[PREFETCH ? NXL : 8];
+    int c_w0 = 0, c_h = 0, lpv = lpx;
+    unsigned c_n = 0, c_p0 = 0;
+    auto chunk_coords = [&](int c) {
+        // opaque copy of the lane's pixel slot: keeps the per-slot (row, column) arithmetic inside the chunk loop
+        // instead of being hoisted into ~3 registers per slot (the 144 accumulators leave no room for that)
+        lpv = lpx;
+        asm volatile("" : "+v"(lpv));
+        c_p0 = (unsigned)c << 5;
+        const unsigned q = c_p0 / (unsigned)W;
+        c_w0 = (int)(c_p0 - q * W);
+        c_n = q / (unsigned)H;
+        c_h = (int)(q - c_n * H);
+    };
+    auto load_dy = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned p = c_p0 + lpv + 8 * i;
+            rd[i] = ld4_or_zero(dy + (size_t)p * Cout + d_c, d_ok);
+        }
+    };
+    auto load_x = [&](int i, float4& dst) {       // slot i (compile-time after unrolling)
+        const int px = lpv + 8 * i;
+        const int r = (px >= SEG) + (px >= 2 * SEG);
+        const int sgm = px - r * SEG;
+        const int hy = c_h + (r - 1) * dil;
+        const int wx = c_w0 - dil + sgm;
+        const bool ok = px < 3 * SEG && x_cok && (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
+        const unsigned pix = x_up ? (c_n * Hs + (unsigned)(hy >> 1)) * Ws + (unsigned)(wx >> 1)
+                                  : (c_n * H + (unsigned)hy) * W + (unsigned)wx;
+        dst = ld4_or_zero(x_src + (size_t)pix * xC, ok);
+    };
+    auto store_dy = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(float4*)&Ds[(lane + 64 * i) * 4] = rd[i];
+    };
+    auto store_x = [&](int i, const float4& v) {
+        const int f = lane + 64 * i;
+        if (f < XF4) *(float4*)&Xs[f * 4] = v;
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int lcol = lane & 31, lk = lane >> 5;
+    int c = split;
+    if (PREFETCH && c < nchunks) {
+        chunk_coords(c);
+        load_dy();
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) load_x(i, rx[i]);
+    }
+    for (; c < nchunks; c += nsplits) {
+        if (PREFETCH) {
+            store_dy();
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) store_x(i, rx[i]);
+            if (c + nsplits < nchunks) {
+                chunk_coords(c + nsplits);
+                load_dy();
+#pragma unroll
+                for (int i = 0; i < NXL; ++i) load_x(i, rx[i]);
+            }
+        } else {                                   // large dilation: stage in groups of 8 slots, no prefetch
+            chunk_coords(c);
+            load_dy();
+            store_dy();
+#pragma unroll
+            for (int g = 0; g < NXL; g += 8) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (g + i < NXL) load_x(g + i, rx[i]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (g + i < NXL) store_x(g + i, rx[i]);
+            }
+        }
+        // (LDS accesses of one wave complete in issue order; the compiler inserts the lgkmcnt waits for the reads)
+#pragma unroll 2
+        for (int k = 0; k < 32; k += 2) {
+            const float a = Ds[(k + lk) * 32 + lcol];
+            const float* xr = Xs + (k + lk) * 32 + lcol;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float b0 = xr[(r * SEG) * 32];
+                const float b1 = xr[(r * SEG + dil) * 32];
+                const float b2 = xr[(r * SEG + 2 * dil) * 32];
+                acc[r * 3 + 0] = MFMA32(a, b0, acc[r * 3 + 0]);
+                acc[r * 3 + 1] = MFMA32(a, b1, acc[r * 3 + 1]);
+                acc[r * 3 + 2] = MFMA32(a, b2, acc[r * 3 + 2]);
+            }
+        }
+    }
+
+    float* o = part + (size_t)split * Cout * 9 * Cin;
+    const int ci = ci_base + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < Cout && ci < Cin) o[((size_t)co * 9 + t) * Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+// shapes the wg9 kernel takes, and its split count (shared by the workspace query and the launcher)
+static inline bool wg9_ok(int C0, int C1, int Cout, int ks, int W, int dil, long P) {
+    return ks == 3 && (W % 32 == 0) && (C0 % 4 == 0) && (C1 % 4 == 0) && (Cout % 4 == 0) && dil <= 24 && P >= 32;
+}
+static inline int wg9_split_blocks(int Cin, int Cout, long P) {
+    long tiles = (long)ceil_div(Cout, 32) * ceil_div(Cin, 32);
+    long nchunks = P / 32;
+    long nb = ceil_div(512, tiles);                 // ~2048 wave-workers = 2 per SIMD over the chip
+    long cap = nchunks / 8 > 1 ? nchunks / 8 : 1;   // at least 2 chunks per worker
+    if (nb > cap) nb = cap;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks) {
     (void)ks;
     int Cin = in.C0 + in.C1;
@@ -362,7 +583,9 @@ static inline int wgrad_splits(int Cin, int Cout, int ks, long P) {
 }
 
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P) {
-    return (size_t)wgrad_splits(Cin, Cout, ks, P) * Cout * ks * ks * Cin;
+    size_t a = (size_t)wgrad_splits(Cin, Cout, ks, P) * Cout * ks * ks * Cin;
+    size_t b = ks == 3 ? (size_t)wg9_split_blocks(Cin, Cout, P) * 4 * Cout * 9 * Cin : 0;
+    return a > b ? a : b;
 }
 
 template <int BM, int BN, int KP>
@@ -387,6 +610,39 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
 
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
                     hipStream_t st) {
+    if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout)) return conv_direct_wgrad(in, dy, dw, ws, N, H, W, Cout, ks, dil, st);
+    if (g_wgrad_variant != 1 && wg9_ok(in.C0, in.C1, Cout, ks, W, dil, (long)N * H * W)) {
+        const int Cin = in.C0 + in.C1;
+        const long P = (long)N * H * W;
+        const int n_ci_t = ceil_div(Cin, 32), ntiles = ceil_div(Cout, 32) * n_ci_t;
+        const int nsb = wg9_split_blocks(Cin, Cout, P);
+        const int SEG = 32 + 2 * dil;
+        const int nxl = ceil_div(3 * SEG * 8, 64);
+        const size_t lds = (size_t)4 * (32 * 32 + 3 * SEG * 32) * sizeof(float);
+        const long nout = (long)Cout * 9 * Cin;
+#define WG9_LAUNCH(NXL_, PF_)                                                                                         \
+        do {                                                                                                          \
+            static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in, once per instantiation */     \
+            if (!attr_set) {                                                                                          \
+                if (hipFuncSetAttribute((const void*)k_conv_wgrad9<NXL_, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                        160 * 1024) != hipSuccess) {                                                  \
+                    vqw_set_error("conv_wgrad9: cannot raise the dynamic LDS limit");                                 \
+                    return VQW_ERR_HIP;                                                                               \
+                }                                                                                                     \
+                attr_set = true;                                                                                      \
+            }                                                                                                         \
+            k_conv_wgrad9<NXL_, PF_><<<ntiles * nsb, 256, lds, st>>>(in, dy, ws, N, H, W, Cout, dil, n_ci_t, ntiles, nsb); \
+        } while (0)
+        if (nxl <= 13) WG9_LAUNCH(13, true);
+        else if (nxl <= 14) WG9_LAUNCH(14, true);
+        else if (nxl <= 17) WG9_LAUNCH(17, false);
+        else if (nxl <= 21) WG9_LAUNCH(21, false);
+        else if (nxl <= 26) WG9_LAUNCH(26, false);
+        else WG9_LAUNCH(30, false);
+#undef WG9_LAUNCH
+        VQW_LAUNCH_CHECK("conv_wgrad9");
+        return reduce_rows(ws, dw, nout, nsb * 4, st);
+    }
     const int bm = wg_tile(Cout), bn = wg_tile(in.C0 + in.C1);
 #define WG_CASE(M_, N_, K_) \
     if (bm == M_ && bn == N_) return launch_wgrad<M_, N_, K_>(in, dy, dw, ws, N, H, W, Cout, ks, dil, st)

@@ -43,6 +43,13 @@ CONV_CASES = [
     (2, 10, 10, 3, 0, False, 5, 3, 1, True, False),        # odd channels    (generic kernel)
     (1, 2, 2, 32, 0, False, 64, 3, 1, True, False),        # tiny map (deepest level of a 32x32 input)
     (2, 4, 4, 64, 32, True, 32, 3, 1, True, False),
+    # widths that are multiples of 32 -> the all-taps-per-wave wgrad kernel
+    (2, 32, 32, 32, 0, False, 32, 3, 1, True, False),
+    (1, 64, 64, 32, 0, False, 32, 3, 6, False, False),
+    (1, 64, 64, 16, 0, False, 16, 3, 18, False, False),
+    (2, 32, 32, 32, 16, True, 16, 3, 1, True, False),
+    (1, 32, 64, 64, 0, True, 32, 3, 1, True, False),
+    (2, 32, 32, 96, 0, False, 80, 3, 2, True, False),
 ]
 
 
@@ -229,8 +236,8 @@ def test_vq_golden(golden, tag):
         assert np.array_equal(ids[clear], g["%s/ids%d" % (tag, call)][clear]), "ids differ on tie-free pixels"
         assert np.mean(ids == g["%s/ids%d" % (tag, call)]) > 0.999
         assert_close(q, g["%s/q%d" % (tag, call)], 1e-5 if call == 1 else 5e-5, "q")   # call 2 gathers the EMA-updated codebook
-        assert_close(commit, g["%s/commit%d" % (tag, call)], 1e-5, "commit")
-        assert_close(x.grad, g["%s/gx%d" % (tag, call)], 1e-5, "gx")
+        assert_close(commit, g["%s/commit%d" % (tag, call)], 1e-5 if call == 1 else 5e-5, "commit")
+        assert_close(x.grad, g["%s/gx%d" % (tag, call)], 1e-5 if call == 1 else 5e-5, "gx")
         for b in ("embed", "cluster_size", "embed_avg"):
             assert_close(getattr(vq, b), g["%s/%s_after%d" % (tag, b, call)], 5e-5, "%s after call %d" % (b, call))
         assert abs(float(vq.cluster_size.sum())) > 0

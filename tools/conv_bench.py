@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the convolution kernels for every distinct conv of the R-cfg model (fwd, dgrad, wgrad).
+
+    python tools/conv_bench.py [--batch 32] [--size 256] [--iters 5] [--only fwd|dgrad|wgrad]
+
+Prints one line per (shape, pass): calls per training step, ms per call, achieved TFLOP/s, share of step time.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "medical-image-editing_amd"))
+import torch  # noqa: E402
+from hipops import _lib, ops  # noqa: E402
+
+
+def model_convs(size):
+    """(C0, C1, up, Cout, ks, dil, H, needs_dgrad) with multiplicity per VIEW, from the module wiring."""
+    ef, df = [16, 32, 64, 128, 256], [32, 64, 128, 256, 512]
+    L = []
+
+    def add(c0, c1, up, co, ks, dil, h, dg=True, n=1):
+        L.extend([(c0, c1, up, co, ks, dil, h, dg)] * n)
+
+    def res(ci, co, h, dg=True):
+        add(ci, 0, False, co, 1, 1, h, dg)
+        add(ci, 0, False, co, 3, 1, h, dg)
+        add(co, 0, False, co, 3, 1, h)
+    # encoder
+    h = size
+    chans = [1] + ef[:4]
+    for i in range(4):
+        res(chans[i], ef[i], h, dg=(i > 0))
+        h //= 2
+    add(ef[3], 0, False, ef[4], 3, 1, h); add(ef[4], 0, False, ef[4], 3, 1, h)
+    for i in (3, 2, 1, 0):
+        h *= 2
+        add(ef[i + 1], ef[i], True, ef[i], 3, 1, h); add(ef[i], 0, False, ef[i], 3, 1, h)
+    # decoder
+    h = size
+    chans = [ef[0]] + df[:4]
+    for i in range(4):
+        res(chans[i], df[i], h)
+        h //= 2
+    add(df[3], 0, False, df[4], 3, 1, h); add(df[4], 0, False, df[4], 3, 1, h)
+    for i in (3, 2, 1, 0):
+        h *= 2
+        cin, c = df[i + 1], df[i]
+        add(cin, 0, True, c, 3, 1, h, n=2)           # conv, conv1
+        add(c, 0, False, c, 3, 1, h, n=7)            # 2 x (shared, gamma, beta) + conv2
+    c = df[0]
+    add(c, 0, False, c, 1, 1, h)
+    for r in (2, 6, 12, 18):
+        add(c, 0, False, c, 3, r, h)
+    add(5 * c, 0, False, c, 3, 1, h); add(c, 0, False, c, 3, 1, h)
+    add(c, 0, False, 1, 1, 1, h)
+    return L
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--filter", default="", help="substring filter on the shape label")
+    args = ap.parse_args()
+    dev = "cuda"
+    L = _lib.load()
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    from collections import Counter
+    cnt = Counter(model_convs(args.size))
+    N = args.batch
+    rows = []
+    for (c0, c1, up, co, ks, dil, h, dg), n in sorted(cnt.items(), key=lambda kv: -kv[0][6]):
+        cin = c0 + c1
+        label = "%3d%s->%3d k%d d%-2d @%3d%s" % (c0, ("+%d" % c1) if c1 else "", co, ks, dil, h, " up" if up else "")
+        if args.filter and args.filter not in label:
+            continue
+        hs = h // 2 if up else h
+        x0 = torch.randn(N, hs, hs, c0, device=dev)
+        x1 = torch.randn(N, h, h, c1, device=dev) if c1 else None
+        w = torch.randn(co, ks, ks, cin, device=dev) * 0.05
+        b = torch.randn(co, device=dev)
+        y = torch.empty(N, h, h, co, device=dev)
+        dy = torch.randn(N, h, h, co, device=dev)
+        wt = torch.empty(cin * ks * ks * co, device=dev)
+        gfull = torch.empty(N, h, h, cin, device=dev)
+        dw = torch.empty_like(w)
+        db = torch.empty(co, device=dev)
+        ws = torch.empty(L.vqw_conv2d_wgrad_ws_bytes(c0, c1, N, h, h, co, ks), dtype=torch.uint8, device=dev)
+        flops = 2.0 * N * h * h * co * ks * ks * cin
+
+        def fwd():
+            _lib.check(L.vqw_conv2d_fwd(p(x0), c0, int(up), p(x1), c1, p(w), p(b), p(y), N, h, h, co, ks, dil, 0, st()))
+
+        def dgrad():
+            _lib.check(L.vqw_conv2d_fwd(p(dy), co, 0, None, 0, p(wt), None, p(gfull), N, h, h, cin, ks, dil, 0, st()))
+
+        def wgrad():
+            _lib.check(L.vqw_conv2d_wgrad(p(x0), c0, int(up), p(x1), c1, p(dy), p(dw), p(db), p(ws), ws.numel(), N, h, h, co, ks,
+                                          dil, st()))
+        for name, fn, on in (("fwd", fwd, True), ("dgrad", dgrad, dg), ("wgrad", wgrad, True)):
+            if not on or (args.only and args.only != name):
+                continue
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            rows.append((label, name, 2 * n, ms, flops / ms / 1e9))
+    tot = sum(r[2] * r[3] for r in rows)
+    print("%-28s %-6s %5s %9s %8s %7s" % ("shape (Cin->Cout k dil @H)", "pass", "n/stp", "ms/call", "TFLOP/s", "share"))
+    for label, name, n, ms, tf in rows:
+        print("%-28s %-6s %5d %9.3f %8.1f %6.1f%%" % (label, name, n, ms, tf, 100 * n * ms / tot))
+    print("sum over one step (2 views): %.1f ms" % tot)
+    for name in ("fwd", "dgrad", "wgrad"):
+        sel = [r for r in rows if r[1] == name]
+        if sel:
+            t = sum(r[2] * r[3] for r in sel)
+            f = sum(r[2] * r[3] * r[4] for r in sel)
+            print("  %-6s %.1f ms/step, %.1f TFLOP/s average" % (name, t, f / t))
+
+
+if __name__ == "__main__":
+    main()
