@@ -116,15 +116,19 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     ConvIn in{src0, src1, C0, C1, up0};
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)ws;
+    const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
+    if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
+        ProfScope ps(1, flops, st);
+        int bias_done = 0;
+        rc = conv_mfma_wgrad(in, dy, dw_ohwi, dbias, &bias_done, wsf + bias_grad_ws_floats(Cout), N, H, W, Cout, ksize, dil, st);
+        if (rc) return rc;
+        if (dbias && !bias_done) return bias_grad(dy, dbias, wsf, (long)N * H * W, Cout, st);
+        return VQW_OK;
+    }
     if (dbias) {
         rc = bias_grad(dy, dbias, wsf, (long)N * H * W, Cout, st);
         if (rc) return rc;
         wsf += bias_grad_ws_floats(Cout);
-    }
-    const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
-    if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
-        ProfScope ps(1, flops, st);
-        return conv_mfma_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st);
     }
     ProfScope ps(3, flops, st);
     return conv_direct_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st);

@@ -26,5 +26,5 @@ int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
                   int relu, hipStream_t st);
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
-int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
-                    hipStream_t st);
+int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
+                    int Cout, int ks, int dil, hipStream_t st);

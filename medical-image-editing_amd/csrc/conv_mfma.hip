@@ -29,6 +29,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Raw buffer loads: 32-bit byte offsets against a wave-uniform descriptor; an offset >= num_records returns 0 in
+// hardware, which is the conv zero padding / tile masking for free (no exec-mask branches, no 64-bit address math).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nbytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    float4 f;     // (index, then convert: __builtin_bit_cast on a vector element mis-reads element 0 with this clang)
+    unsigned a = v[0], b = v[1], c = v[2], d = v[3];
+    f.x = __uint_as_float(a); f.y = __uint_as_float(b); f.z = __uint_as_float(c); f.w = __uint_as_float(d);
+    return f;
+}
+
 __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
     float4 z;
     z.x = z.y = z.z = z.w = 0.f;
@@ -43,7 +57,7 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
 template <int BM, int BN, int WM, int WN, int KC>
 __global__ void __launch_bounds__(256, 2)
 k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int N, int H,
-                int W, int Cout, int ks, int dil, int ntn, int relu) {
+                int W, int Cout, int ks, int dil, int ntn, int relu, unsigned nb0, unsigned nb1, unsigned nbw) {
     constexpr int LDK = KC + 4;           // padded row length (floats)
     constexpr int C4 = KC / 4;            // float4 per row
     constexpr int LA = BM * C4 / 256;     // A float4 loads per thread per chunk
@@ -67,6 +81,7 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
     const int co_base = tile_n * BN;
     const int Hs = H >> 1, Ws = W >> 1;
     const int up0 = in.up0;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(in.src0, nb0), rs1 = make_rsrc(in.src1, nb1), rsw = make_rsrc(w, nbw);
 
     // per-thread pixel coordinates of the A rows it loads (fixed for the whole K loop)
     const int a_c = (tid % C4) * 4;       // channel offset inside a chunk
@@ -86,48 +101,50 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
         a_pix[j] = pp;
         a_upb[j] = n * (unsigned)(Hs * Ws);
     }
-    // weight rows this thread loads
-    const float* b_ptr[LB];
-    bool b_ok[LB];
+    // weight rows this thread loads (byte offsets; an invalid row sits at the out-of-range offset)
+    unsigned b_off[LB];
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
         int f = tid + j * 256;
-        int row = f / C4;
-        int co = co_base + row;
-        b_ok[j] = (BN * C4 % 256 == 0 || f < BN * C4) && co < Cout;
-        b_ptr[j] = w + (size_t)(b_ok[j] ? co : 0) * taps * Cin + (f % C4) * 4;
+        int co = co_base + f / C4;
+        bool ok = (BN * C4 % 256 == 0 || f < BN * C4) && co < Cout;
+        b_off[j] = ok ? ((unsigned)co * taps * Cin + (f % C4) * 4) * 4u : nbw;
     }
 
-    // loader state: current tap / channel chunk, per-tap validity and element offsets
+    // loader state: current tap / channel chunk, per-tap byte offsets (out-of-range offset = zero padding)
     int l_t = 0, l_cc = 0, l_ky = 0, l_kx = 0;
-    bool t_ok[LA];
     unsigned t_off0[LA], t_off1[LA];
     auto setup_tap = [&]() {
         const int dyy = (l_ky - half) * dil, dxx = (l_kx - half) * dil;
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             int hy = a_h[j] + dyy, wx = a_w[j] + dxx;
-            t_ok[j] = a_ok[j] && (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
+            bool ok = a_ok[j] && (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
             unsigned pix = a_pix[j] + (unsigned)(dyy * W + dxx);
-            t_off0[j] = up0 ? (a_upb[j] + (unsigned)((hy >> 1) * Ws + (wx >> 1))) * (unsigned)C0 : pix * (unsigned)C0;
-            t_off1[j] = pix * (unsigned)C1;
+            unsigned e0 = up0 ? (a_upb[j] + (unsigned)((hy >> 1) * Ws + (wx >> 1))) * (unsigned)C0 : pix * (unsigned)C0;
+            t_off0[j] = ok ? (e0 + a_c) * 4u : nb0;
+            t_off1[j] = ok ? (pix * (unsigned)C1 + a_c) * 4u : nb1;
         }
     };
     float4 ra[LA], rb[LB];
     auto load_chunk = [&]() {     // loads chunk (l_t, l_cc) into registers, then advances the loader state
-        const int c = l_cc + a_c;
-        const bool from0 = c < C0;
-        const bool cok = c < Cin;
+        // a chunk never straddles the two sources (C0 % KC == 0 is required when C1 > 0), so the choice is uniform;
+        // channels beyond Cin (ragged last chunk) fall off the end of the pixel row: masked by the offset below
+        const bool tail = (l_cc + a_c) >= Cin;
+        if (l_cc < C0) {
+            const unsigned cb = (unsigned)l_cc * 4u;
 #pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            const float* src = from0 ? in.src0 + t_off0[j] + c : in.src1 + t_off1[j] + (c - C0);
-            ra[j] = ld4_or_zero(src, t_ok[j] && cok);
+            for (int j = 0; j < LA; ++j) ra[j] = buf_ld4(rs0, (tail || t_off0[j] == nb0) ? nb0 : t_off0[j] + cb);
+        } else {
+            const unsigned cb = (unsigned)(l_cc - C0) * 4u;
+#pragma unroll
+            for (int j = 0; j < LA; ++j) ra[j] = buf_ld4(rs1, (tail || t_off1[j] == nb1) ? nb1 : t_off1[j] + cb);
         }
-        const int wofs = l_t * Cin + l_cc;
+        const unsigned wofs = (unsigned)(l_t * Cin + l_cc) * 4u;
 #pragma unroll
         for (int j = 0; j < LB; ++j) {
-            int cb = l_cc + ((tid + j * 256) % C4) * 4;
-            rb[j] = ld4_or_zero(b_ptr[j] + wofs, b_ok[j] && cb < Cin);
+            int cbw = l_cc + ((tid + j * 256) % C4) * 4;
+            rb[j] = buf_ld4(rsw, (cbw >= Cin || b_off[j] == nbw) ? nbw : b_off[j] + wofs);
         }
         l_cc += KC;
         if (l_cc >= Cin) {
@@ -213,12 +230,14 @@ bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks) {
     int Cin = in.C0 + in.C1;
     // float4 channel loads: every source a multiple of 4 channels; tiny Cout (1-channel head) is left to the
     // generic kernel (a 32-wide MFMA tile would be >90% padding).
-    return (in.C0 % 4 == 0) && (in.C1 % 4 == 0) && Cin >= 8 && Cout >= 8;
+    return (in.C0 % 4 == 0) && (in.C1 % 4 == 0) && Cin >= 8 && Cout >= 8 && (in.C1 == 0 || in.C0 % 32 == 0);
 }
 
+// buffer descriptors address at most 4 GiB per tensor (32-bit byte offsets; the top 32 bytes are kept as the
+// guaranteed-out-of-range offset)
 static inline bool fits_u32(long P, int Cin, int Cout) {
     long c = Cin > Cout ? Cin : Cout;
-    return P * c < (1L << 31);
+    return P * c * 4 <= 0xFFFFFFE0L;
 }
 
 template <int BM, int BN, int WM, int WN, int KC>
@@ -226,7 +245,10 @@ static int launch_fwd(const ConvIn& in, const float* w, const float* bias, float
                       int dil, int relu, hipStream_t st) {
     long P = (long)N * H * W;
     int ntm = ceil_div(P, BM), ntn = ceil_div(Cout, BN);
-    k_conv_mfma_fwd<BM, BN, WM, WN, KC><<<ntm * ntn, 256, 0, st>>>(in, w, bias, y, N, H, W, Cout, ks, dil, ntn, relu);
+    const unsigned nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
+    const unsigned nbw = (unsigned)((long)Cout * ks * ks * (in.C0 + in.C1) * 4);
+    k_conv_mfma_fwd<BM, BN, WM, WN, KC><<<ntm * ntn, 256, 0, st>>>(in, w, bias, y, N, H, W, Cout, ks, dil, ntn, relu, nb0, nb1,
+                                                                   nbw);
     VQW_LAUNCH_CHECK("conv_mfma_fwd");
     return VQW_OK;
 }
@@ -413,8 +435,8 @@ k_conv_mfma_wgrad(ConvIn in, const float* __restrict__ dy, float* __restrict__ p
 // Partial slabs [worker-split][Cout][9][Cin] are reduced in fixed order by reduce_rows.
 template <int NXL, bool PREFETCH>
 __global__ void __launch_bounds__(256, 2)
-k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part, int N, int H, int W, int Cout, int dil,
-              int n_ci_t, int ntiles, int nsplit_blocks) {
+k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part, float* __restrict__ bias_part, int N, int H,
+              int W, int Cout, int dil, int n_ci_t, int ntiles, int nsplit_blocks, unsigned nb0, unsigned nb1, unsigned nbd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int C0 = in.C0, C1 = in.C1, Cin = C0 + C1;
@@ -436,13 +458,18 @@ k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part,
     const bool d_ok = d_c < Cout;
     const int x_c = ci_base + (lane & 7) * 4;
     const bool x_cok = x_c < Cin;
-    const bool x_from0 = x_c < C0;
+    const bool x_from0 = ci_base < C0;              // a 32-wide ci tile never straddles the sources (wg9_ok)
     const unsigned xC = x_from0 ? (unsigned)C0 : (unsigned)C1;
-    const float* x_src = x_from0 ? in.src0 + x_c : in.src1 + (x_c - C0);
+    const unsigned x_cb = (unsigned)(x_from0 ? x_c : x_c - C0) * 4u;
+    const unsigned nbx = x_from0 ? nb0 : nb1;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(x_from0 ? in.src0 : in.src1, nbx), rsd = make_rsrc(dy, nbd);
     const bool x_up = x_from0 && in.up0;
     const int lpx = lane >> 3;
+    const bool do_bias = bias_part != nullptr && ci_base == 0;
 
     float4 rd[4], rx[PREFETCH ? NXL : 8];
+    float4 bsum;
+    bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
     int c_w0 = 0, c_h = 0, lpv = lpx;
     unsigned c_n = 0, c_p0 = 0;
     auto chunk_coords = [&](int c) {
@@ -460,7 +487,7 @@ k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned p = c_p0 + lpv + 8 * i;
-            rd[i] = ld4_or_zero(dy + (size_t)p * Cout + d_c, d_ok);
+            rd[i] = buf_ld4(rsd, d_ok ? (p * (unsigned)Cout + d_c) * 4u : nbd);
         }
     };
     auto load_x = [&](int i, float4& dst) {       // slot i (compile-time after unrolling)
@@ -472,11 +499,14 @@ k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part,
         const bool ok = px < 3 * SEG && x_cok && (unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W;
         const unsigned pix = x_up ? (c_n * Hs + (unsigned)(hy >> 1)) * Ws + (unsigned)(wx >> 1)
                                   : (c_n * H + (unsigned)hy) * W + (unsigned)wx;
-        dst = ld4_or_zero(x_src + (size_t)pix * xC, ok);
+        dst = buf_ld4(rsx, ok ? pix * xC * 4u + x_cb : nbx);
     };
     auto store_dy = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(float4*)&Ds[(lane + 64 * i) * 4] = rd[i];
+        for (int i = 0; i < 4; ++i) {
+            *(float4*)&Ds[(lane + 64 * i) * 4] = rd[i];
+            bsum.x += rd[i].x; bsum.y += rd[i].y; bsum.z += rd[i].z; bsum.w += rd[i].w;   // fused bias gradient
+        }
     };
     auto store_x = [&](int i, const float4& v) {
         const int f = lane + 64 * i;
@@ -539,6 +569,14 @@ k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part,
         }
     }
 
+    if (do_bias) {     // lanes with equal (lane & 7) hold the same 4 channels: butterfly over lane bits 3..5
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
+            bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
+        }
+        if (lane < 8 && d_ok) *(float4*)&bias_part[(size_t)split * Cout + d_c] = bsum;
+    }
     float* o = part + (size_t)split * Cout * 9 * Cin;
     const int ci = ci_base + (lane & 31);
 #pragma unroll
@@ -553,7 +591,8 @@ k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part,
 
 // shapes the wg9 kernel takes, and its split count (shared by the workspace query and the launcher)
 static inline bool wg9_ok(int C0, int C1, int Cout, int ks, int W, int dil, long P) {
-    return ks == 3 && (W % 32 == 0) && (C0 % 4 == 0) && (C1 % 4 == 0) && (Cout % 4 == 0) && dil <= 24 && P >= 32;
+    return ks == 3 && (W % 32 == 0) && (C0 % 4 == 0) && (C1 % 4 == 0) && (Cout % 4 == 0) && dil <= 24 && P >= 32 &&
+           (C1 == 0 || C0 % 32 == 0);
 }
 static inline int wg9_split_blocks(int Cin, int Cout, long P) {
     long tiles = (long)ceil_div(Cout, 32) * ceil_div(Cin, 32);
@@ -584,7 +623,7 @@ static inline int wgrad_splits(int Cin, int Cout, int ks, long P) {
 
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P) {
     size_t a = (size_t)wgrad_splits(Cin, Cout, ks, P) * Cout * ks * ks * Cin;
-    size_t b = ks == 3 ? (size_t)wg9_split_blocks(Cin, Cout, P) * 4 * Cout * 9 * Cin : 0;
+    size_t b = ks == 3 ? (size_t)wg9_split_blocks(Cin, Cout, P) * 4 * ((size_t)Cout * 9 * Cin + Cout) : 0;
     return a > b ? a : b;
 }
 
@@ -608,10 +647,13 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
     return VQW_OK;
 }
 
-int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
-                    hipStream_t st) {
+// dbias != nullptr asks the kernel to produce the bias gradient too; returns 1 (not an error) in *bias_done when it did.
+int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
+                    int Cout, int ks, int dil, hipStream_t st) {
+    *bias_done = 0;
     if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout)) return conv_direct_wgrad(in, dy, dw, ws, N, H, W, Cout, ks, dil, st);
     if (g_wgrad_variant != 1 && wg9_ok(in.C0, in.C1, Cout, ks, W, dil, (long)N * H * W)) {
+        *bias_done = dbias != nullptr;
         const int Cin = in.C0 + in.C1;
         const long P = (long)N * H * W;
         const int n_ci_t = ceil_div(Cin, 32), ntiles = ceil_div(Cout, 32) * n_ci_t;
@@ -620,6 +662,9 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int
         const int nxl = ceil_div(3 * SEG * 8, 64);
         const size_t lds = (size_t)4 * (32 * 32 + 3 * SEG * 32) * sizeof(float);
         const long nout = (long)Cout * 9 * Cin;
+        const unsigned nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
+        const unsigned nbd = (unsigned)(P * Cout * 4);
+        float* bpart = dbias ? ws + (size_t)nsb * 4 * nout : nullptr;      // [splits][Cout] after the weight slabs
 #define WG9_LAUNCH(NXL_, PF_)                                                                                         \
         do {                                                                                                          \
             static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in, once per instantiation */     \
@@ -631,7 +676,8 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int
                 }                                                                                                     \
                 attr_set = true;                                                                                      \
             }                                                                                                         \
-            k_conv_wgrad9<NXL_, PF_><<<ntiles * nsb, 256, lds, st>>>(in, dy, ws, N, H, W, Cout, dil, n_ci_t, ntiles, nsb); \
+            k_conv_wgrad9<NXL_, PF_><<<ntiles * nsb, 256, lds, st>>>(in, dy, ws, bpart, N, H, W, Cout, dil, n_ci_t, ntiles, nsb, \
+                                                                      nb0, nb1, nbd);                                       \
         } while (0)
         if (nxl <= 13) WG9_LAUNCH(13, true);
         else if (nxl <= 14) WG9_LAUNCH(14, true);
@@ -641,6 +687,10 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int
         else WG9_LAUNCH(30, false);
 #undef WG9_LAUNCH
         VQW_LAUNCH_CHECK("conv_wgrad9");
+        if (dbias) {
+            int rc = reduce_rows(bpart, dbias, Cout, nsb * 4, st);
+            if (rc) return rc;
+        }
         return reduce_rows(ws, dw, nout, nsb * 4, st);
     }
     const int bm = wg_tile(Cout), bn = wg_tile(in.C0 + in.C1);
