@@ -102,6 +102,45 @@ __global__ void k_inorm_apply(const float* __restrict__ x, const float* __restri
     }
 }
 
+// float4 variants for C % 4 == 0 and un-sliced tensors (the common case): 16 B per lane streams
+template <int RELU>
+__global__ void k_inorm_apply4(const float4* __restrict__ x, const float* __restrict__ mr, float4* __restrict__ y, long total4,
+                               int HW, int C4) {
+    long stride = (long)gridDim.x * blockDim.x;
+    long plane4 = (long)HW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        int c = (int)(i % C4) * 4;
+        int n = (int)(i / plane4);
+        const float4* m = (const float4*)(mr + 2 * ((long)n * C4 * 4 + c));
+        float4 m0 = m[0], m1 = m[1];          // (mean,rstd) pairs of channels c..c+3
+        float4 v = x[i], r;
+        r.x = (v.x - m0.x) * m0.y; r.y = (v.y - m0.z) * m0.w; r.z = (v.z - m1.x) * m1.y; r.w = (v.w - m1.z) * m1.w;
+        if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+        y[i] = r;
+    }
+}
+template <int RELU>
+__global__ void k_inorm_bwd_apply4(const float4* __restrict__ x, const float* __restrict__ mr, const float4* __restrict__ gy,
+                                   const float* __restrict__ means, float4* __restrict__ gx, long total4, int HW, int C4) {
+    long stride = (long)gridDim.x * blockDim.x;
+    long plane4 = (long)HW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        int c = (int)(i % C4) * 4;
+        int n = (int)(i / plane4);
+        long k = 2 * ((long)n * C4 * 4 + c);
+        const float4* m = (const float4*)(mr + k);
+        const float4* e = (const float4*)(means + k);
+        float4 m0 = m[0], m1 = m[1], e0 = e[0], e1 = e[1];
+        float4 v = x[i], g = gy[i], o;
+        float xh, gg;
+        xh = (v.x - m0.x) * m0.y; gg = (RELU && !(xh > 0.f)) ? 0.f : g.x; o.x = m0.y * (gg - e0.x - xh * e0.y);
+        xh = (v.y - m0.z) * m0.w; gg = (RELU && !(xh > 0.f)) ? 0.f : g.y; o.y = m0.w * (gg - e0.z - xh * e0.w);
+        xh = (v.z - m1.x) * m1.y; gg = (RELU && !(xh > 0.f)) ? 0.f : g.z; o.z = m1.y * (gg - e1.x - xh * e1.y);
+        xh = (v.w - m1.z) * m1.w; gg = (RELU && !(xh > 0.f)) ? 0.f : g.w; o.w = m1.w * (gg - e1.z - xh * e1.w);
+        gx[i] = o;
+    }
+}
+
 extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, void* ws,
                              size_t ws_bytes, int N, int HW, int C, float eps, int relu, void* stream) {
     VQW_CHECK(x && y && mean_rstd && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd: bad arguments");
@@ -114,7 +153,11 @@ extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff
     k_inorm_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>((const double*)ws, mean_rstd, N * C, C, splits,
                                                                  1.0 / (double)HW, eps);
     long total = (long)N * HW * C;
-    if (relu) k_inorm_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
+    if ((C & 3) == 0 && y_cstride == C && y_coff == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
+        long t4 = total / 4;
+        if (relu) k_inorm_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4);
+        else k_inorm_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4);
+    } else if (relu) k_inorm_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     else k_inorm_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     VQW_LAUNCH_CHECK("vqw_inorm_fwd");
     return VQW_OK;
@@ -189,7 +232,12 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
     }
     k_plane_sum_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, means, N * C, C, splits, 1.0 / (double)HW);
-    if (relu) k_inorm_bwd_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
+    if ((C & 3) == 0 && gy_cstride == C && gy_coff == 0 &&
+        ((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)mean_rstd | (uintptr_t)means) & 15) == 0)) {
+        long t4 = total / 4;
+        if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4);
+        else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4);
+    } else if (relu) k_inorm_bwd_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
     else k_inorm_bwd_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
     VQW_LAUNCH_CHECK("vqw_inorm_bwd");
     return VQW_OK;
@@ -197,17 +245,28 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm statistics (per channel over N*H*W) -> double sums[C][2] so ranks can be summed (SyncBN).
-__global__ void k_channel_sum_finalize(const double* __restrict__ part, double* __restrict__ sums, int C, int rows) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// sums[c] = sum over `rows` partial rows; workgroup = 16 channels x 16 row groups, fixed-order tree -> deterministic
+__global__ void __launch_bounds__(256) k_channel_sum_finalize(const double* __restrict__ part, double* __restrict__ sums, int C, int rows) {
+    __shared__ double sa[16][17], sb[16][17];
+    const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     double a = 0.0, b = 0.0;
-    for (int r = 0; r < rows; ++r) {
-        const double* o = part + ((long)r * C + c) * 2;
-        a += o[0];
-        b += o[1];
+    if (c < C) {
+        for (int r = g; r < rows; r += 16) {
+            const double* o = part + ((long)r * C + c) * 2;
+            a += o[0];
+            b += o[1];
+        }
     }
-    sums[2 * c] = a;
-    sums[2 * c + 1] = b;
+    sa[g][cx] = a;
+    sb[g][cx] = b;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double ta = 0.0, tb = 0.0;
+        for (int k = 0; k < 16; ++k) { ta += sa[k][cx]; tb += sb[k][cx]; }
+        sums[2 * c] = ta;
+        sums[2 * c + 1] = tb;
+    }
 }
 
 extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size_t ws_bytes, int N, int HW, int C,
@@ -218,7 +277,7 @@ extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size
     int splits = plane_splits(N, HW);
     FStats f{x};
     k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
-    k_channel_sum_finalize<<<ceil_div(C, 256), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
     VQW_LAUNCH_CHECK("vqw_bn_partial_stats");
     return VQW_OK;
 }
@@ -323,7 +382,7 @@ extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, cons
         FSpadeBwd<0> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     }
-    k_channel_sum_finalize<<<ceil_div(C, 256), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
     VQW_LAUNCH_CHECK("vqw_spade_bwd_reduce");
     return VQW_OK;
 }

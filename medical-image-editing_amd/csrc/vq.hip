@@ -132,11 +132,22 @@ __global__ void k_vq_finalize(const double* __restrict__ commit_part, const floa
         __syncthreads();
         if (t == 0) commit[0] = (float)((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_numel);
     }
-    if (stats) {
-        for (int i = blockIdx.x * blockDim.x + t; i < KD1; i += gridDim.x * blockDim.x) {
+    if (stats) {      // column sums of the per-block partial rows: 16 columns x 16 row groups per workgroup, fixed order
+        __shared__ double sm[16][17];
+        const int cx = t & 15, g = t >> 4;
+        for (int base = blockIdx.x * 16; base < KD1; base += gridDim.x * 16) {
+            const int i = base + cx;
             double a = 0.0;
-            for (int b = 0; b < nstat_rows; ++b) a += (double)stat_part[(long)b * KD1 + i];
-            stats[i] = a;
+            if (i < KD1)
+                for (int b = g; b < nstat_rows; b += 16) a += (double)stat_part[(long)b * KD1 + i];
+            sm[g][cx] = a;
+            __syncthreads();
+            if (g == 0 && i < KD1) {
+                double s2 = 0.0;
+                for (int k = 0; k < 16; ++k) s2 += sm[k][cx];
+                stats[i] = s2;
+            }
+            __syncthreads();
         }
     }
 }
@@ -177,7 +188,7 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
     else if (D == 64) launch_vq<64>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
     else launch_vq<0>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
     VQW_LAUNCH_CHECK("vqw_vq_fwd");
-    k_vq_finalize<<<imax(1, imin(64, ceil_div(KD1, 256))), 256, 0, st>>>(cpart, spart, nb, lds_st ? nb : 1, commit,
+    k_vq_finalize<<<imax(1, imin(256, ceil_div(KD1, 16))), 256, 0, st>>>(cpart, spart, nb, lds_st ? nb : 1, commit,
                                                                          want ? stats : nullptr, KD1,
                                                                          1.0 / ((double)Npix * D));
     VQW_LAUNCH_CHECK("vqw_vq_finalize");
