@@ -1,0 +1,87 @@
+"""2-rank data-parallel rehearsal on ONE GPU (gloo backend, both ranks on cuda:0): the real HIP path with the
+gradient reducer, synchronised StyledDenorm statistics and the VQ EMA all-reduce, compared with a single process
+on the concatenated batch.  (RCCL needs one GPU per rank; the driver exercises that at N = 2/4/8.)"""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "medical-image-editing_amd"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+from trainers import FirstStepTrainer, FlipViews
+from networks import UNetEncoder, UNetDecoder
+from oracle.vqwnet_ref import synthetic_slices
+torch.manual_seed(5)
+K = 10
+enc = UNetEncoder(1, [16, 32, 32, 64, 64], K, 0.99, 'torch', False, 1, True)
+dec = UNetDecoder(16, 1, [32, 32, 64, 64, 128], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
+B, S = 4, 64
+with torch.no_grad():
+    enc.vq.embed.mul_(0.7); enc.vq.cluster_size.fill_(B * S * S / K)
+    enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
+tr = FirstStepTrainer(dict_size=K, momentum=0.99, views=FlipViews(border=2), encoder=enc, decoder=dec, device="cuda:0",
+                      data_parallel=world > 1)
+img, noise = synthetic_slices(B, S, 11)
+lo, hi = (rank * B // world, (rank + 1) * B // world)
+o = tr.training_step({"image": img[lo:hi].cuda()}, noise=noise[lo:hi].cuda())
+torch.cuda.synchronize()
+res = {"total": float(o["total"].detach()), "ids_1": o["ids_1"].cpu(),
+       "vq": {k: v.cpu() for k, v in enc.vq.state_dict().items()},
+       "bn": {k: v.cpu() for k, v in dec.state_dict().items() if "running_" in k},
+       "g": {k: p.grad.cpu() for k, p in list(enc.named_parameters())[:8] + list(dec.named_parameters())[:40:4]},
+       "p": {k: p.detach().cpu() for k, p in list(dec.named_parameters())[:6]}}
+torch.save(res, out + ".%d" % rank)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run(world, tmp_path, tag, port):
+    script = tmp_path / "dpw.py"
+    script.write_text(WORKER)
+    out = str(tmp_path / tag)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        o = p.communicate(timeout=500)[0].decode()
+        assert p.returncode == 0, o[-3000:]
+    return [torch.load(out + ".%d" % r) for r in range(world)]
+
+
+def test_two_rank_dp_matches_single_process(tmp_path):
+    single = _run(1, tmp_path, "single", 29621)[0]
+    dp = _run(2, tmp_path, "dp", 29622)
+    # replicas stay identical
+    for k in dp[0]["p"]:
+        assert torch.equal(dp[0]["p"][k], dp[1]["p"][k]), "ranks diverged on " + k
+    for k in dp[0]["vq"]:
+        assert torch.allclose(dp[0]["vq"][k], dp[1]["vq"][k], rtol=0, atol=0), "VQ buffers differ across ranks: " + k
+    # global-batch semantics: ids, VQ EMA buffers, BN running statistics equal the single-process run
+    assert torch.equal(torch.cat([dp[0]["ids_1"], dp[1]["ids_1"]]), single["ids_1"])
+    for k in single["vq"]:
+        assert torch.allclose(dp[0]["vq"][k], single["vq"][k], rtol=2e-5, atol=1e-6), k
+    for k in single["bn"]:
+        assert torch.allclose(dp[0]["bn"][k], single["bn"][k], rtol=1e-4, atol=1e-6), k
+    # averaged gradients ~ single-process gradients (the cross loss averages per-rank means, so not bit-equal)
+    errs = []
+    gmax = max(float(g.norm()) for g in single["g"].values())
+    for k, g in single["g"].items():
+        if float(g.norm()) < 1e-4 * gmax:       # analytically-zero gradients (bias in front of a norm): noise only
+            continue
+        errs.append(float((dp[0]["g"][k] - g).norm() / g.norm()))
+    assert max(errs) < 0.15 and sorted(errs)[len(errs) // 2] < 0.05, errs
+    mean_total = 0.5 * (dp[0]["total"] + dp[1]["total"])
+    assert abs(mean_total - single["total"]) <= 0.05 * abs(single["total"])
