@@ -57,10 +57,11 @@ int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* src1, int C1
  * relu=1 fuses nn.ReLU into the epilogue (blocks.py:75-77 mlp_shared).             */
 int vqw_pack_dgrad_weights(const float* w_ohwi, float* wt, int Cout, int Cin, int ksize, void* stream);
 size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, int ksize);
-/* dW[co][ky][kx][ci] (OHWI) and, if dbias != NULL, dbias[co] = sum_p dY. */
+/* dW[co][ky][kx][ci] (OHWI) and, if dbias != NULL, dbias[co] = sum_p dY.
+ * accumulate=1 adds into dw / dbias (a layer used by both views of a step: one gradient buffer, no extra pass). */
 int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float* src1, int C1,
                      const float* dy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes,
-                     int N, int H, int W, int Cout, int ksize, int dil, void* stream);
+                     int N, int H, int W, int Cout, int ksize, int dil, int accumulate, void* stream);
 /* Gradient of the virtual input: g_full is [N,H,W,Ctot]; takes channels
  * [c_off, c_off+C).  up=1: dst[N,H/2,W/2,C] = 2x2 block sums; up=0: plain slice copy.
  * accumulate=1 adds into dst.                                                      */

@@ -108,7 +108,7 @@ extern "C" size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W,
 
 extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float* src1, int C1, const float* dy, float* dw_ohwi,
                                 float* dbias, void* ws, size_t ws_bytes, int N, int H, int W, int Cout, int ksize, int dil,
-                                void* stream) {
+                                int accumulate, void* stream) {
     int rc = check_conv_args("vqw_conv2d_wgrad", src0, C0, up0, src1, C1, N, H, W, Cout, ksize, dil);
     if (rc) return rc;
     VQW_CHECK(dy && dw_ohwi && ws, "vqw_conv2d_wgrad: dy, dw and workspace must be set");
@@ -120,16 +120,17 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
         ProfScope ps(1, flops, st);
         int bias_done = 0;
-        rc = conv_mfma_wgrad(in, dy, dw_ohwi, dbias, &bias_done, wsf + bias_grad_ws_floats(Cout), N, H, W, Cout, ksize, dil, st);
+        rc = conv_mfma_wgrad(in, dy, dw_ohwi, dbias, &bias_done, wsf + bias_grad_ws_floats(Cout), N, H, W, Cout, ksize, dil, st,
+                             accumulate);
         if (rc) return rc;
-        if (dbias && !bias_done) return bias_grad(dy, dbias, wsf, (long)N * H * W, Cout, st);
+        if (dbias && !bias_done) return bias_grad(dy, dbias, wsf, (long)N * H * W, Cout, st, accumulate);
         return VQW_OK;
     }
     if (dbias) {
-        rc = bias_grad(dy, dbias, wsf, (long)N * H * W, Cout, st);
+        rc = bias_grad(dy, dbias, wsf, (long)N * H * W, Cout, st, accumulate);
         if (rc) return rc;
         wsf += bias_grad_ws_floats(Cout);
     }
     ProfScope ps(3, flops, st);
-    return conv_direct_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st);
+    return conv_direct_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st, accumulate);
 }

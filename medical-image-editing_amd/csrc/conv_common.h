@@ -14,11 +14,11 @@ struct ConvIn {
 int conv_direct_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks,
                     int dil, int relu, hipStream_t st);
 int conv_direct_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
-                      hipStream_t st);
+                      hipStream_t st, int acc = 0);
 int conv_direct_wgrad_splits(long nout, long P);
 size_t bias_grad_ws_floats(int C);
-int bias_grad(const float* dy, float* dbias, float* ws, long P, int C, hipStream_t st);
-int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st);
+int bias_grad(const float* dy, float* dbias, float* ws, long P, int C, hipStream_t st, int acc = 0);
+int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st, int acc = 0);
 
 // MFMA implicit-GEMM kernels (conv_mfma.hip)
 bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks);
@@ -27,4 +27,4 @@ int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
-                    int Cout, int ks, int dil, hipStream_t st);
+                    int Cout, int ks, int dil, hipStream_t st, int acc);

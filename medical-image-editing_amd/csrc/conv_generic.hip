@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256) k_conv_direct_wgrad(ConvIn in, const floa
 
 // out[i] = sum_s part[s][i].  Workgroup = 64 columns x 16 row groups: every thread sums rows g, g+16, ... of its
 // column (coalesced 256-B row segments), then a fixed-order LDS tree over the 16 groups -> deterministic.
-__global__ void __launch_bounds__(1024) k_reduce_rows(const float* __restrict__ part, float* __restrict__ out, long n, int rows) {
+__global__ void __launch_bounds__(1024) k_reduce_rows(const float* __restrict__ part, float* __restrict__ out, long n, int rows,
+                                                      int acc) {
     __shared__ float sm[16][64];
     const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long i = (long)blockIdx.x * 64 + cx;
@@ -131,12 +132,12 @@ __global__ void __launch_bounds__(1024) k_reduce_rows(const float* __restrict__ 
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][cx];
-        out[i] = t;
+        out[i] = acc ? out[i] + t : t;
     }
 }
 
-int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st) {
-    k_reduce_rows<<<(unsigned)((n + 63) / 64), 1024, 0, st>>>(part, out, n, rows);
+int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st, int acc) {
+    k_reduce_rows<<<(unsigned)((n + 63) / 64), 1024, 0, st>>>(part, out, n, rows, acc);
     VQW_LAUNCH_CHECK("reduce_rows");
     return VQW_OK;
 }
@@ -150,13 +151,13 @@ int conv_direct_wgrad_splits(long nout, long P) {
 }
 
 int conv_direct_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
-                      hipStream_t st) {
+                      hipStream_t st, int acc) {
     const int Cin = in.C0 + in.C1;
     long nout = (long)Cout * ks * ks * Cin;
     int splits = conv_direct_wgrad_splits(nout, (long)N * H * W);
     k_conv_direct_wgrad<<<dim3((unsigned)nout, splits), 256, 0, st>>>(in, dy, ws, N, H, W, Cout, ks, dil, splits);
     VQW_LAUNCH_CHECK("conv_direct_wgrad");
-    return reduce_rows(ws, dw, nout, splits, st);
+    return reduce_rows(ws, dw, nout, splits, st, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -184,11 +185,11 @@ __global__ void __launch_bounds__(256) k_bias_grad_partial(const float* __restri
     }
 }
 size_t bias_grad_ws_floats(int C) { return (size_t)BG_ROWS * C; }
-int bias_grad(const float* dy, float* dbias, float* ws, long P, int C, hipStream_t st) {
+int bias_grad(const float* dy, float* dbias, float* ws, long P, int C, hipStream_t st, int acc) {
     int rows = (int)imin(BG_ROWS, imax(1, (int)(P / 256)));
     k_bias_grad_partial<<<rows, 256, 0, st>>>(dy, ws, P, C);
     VQW_LAUNCH_CHECK("bias_grad");
-    return reduce_rows(ws, dbias, C, rows, st);
+    return reduce_rows(ws, dbias, C, rows, st, acc);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -629,7 +629,7 @@ size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P) {
 
 template <int BM, int BN, int KP>
 static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
-                        hipStream_t st) {
+                        hipStream_t st, int acc) {
     constexpr int WM = BM > 64 ? 64 : BM, WN = BN > 64 ? 64 : BN;
     constexpr int NT = 64 * (BM / WM) * (BN / WN);
     const int Cin = in.C0 + in.C1;
@@ -639,19 +639,19 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
     per = ((per + KP - 1) / KP) * KP;
     const int ntm = ceil_div(Cout, BM), ntn = ceil_div(Cin, BN);
     const long nout = (long)Cout * ks * ks * Cin;
-    float* part = splits > 1 ? ws : dw;
+    float* part = (splits > 1 || acc) ? ws : dw;
     k_conv_mfma_wgrad<BM, BN, WM, WN, KP><<<ntm * ntn * ks * ks * splits, NT, 0, st>>>(in, dy, part, N, H, W, Cout, ks, dil,
                                                                                          ntm, ntn, per);
     VQW_LAUNCH_CHECK("conv_mfma_wgrad");
-    if (splits > 1) return reduce_rows(ws, dw, nout, splits, st);
+    if (splits > 1 || acc) return reduce_rows(ws, dw, nout, splits, st, acc);
     return VQW_OK;
 }
 
 // dbias != nullptr asks the kernel to produce the bias gradient too; returns 1 (not an error) in *bias_done when it did.
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
-                    int Cout, int ks, int dil, hipStream_t st) {
+                    int Cout, int ks, int dil, hipStream_t st, int acc) {
     *bias_done = 0;
-    if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout)) return conv_direct_wgrad(in, dy, dw, ws, N, H, W, Cout, ks, dil, st);
+    if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout)) return conv_direct_wgrad(in, dy, dw, ws, N, H, W, Cout, ks, dil, st, acc);
     if (g_wgrad_variant != 1 && wg9_ok(in.C0, in.C1, Cout, ks, W, dil, (long)N * H * W)) {
         *bias_done = dbias != nullptr;
         const int Cin = in.C0 + in.C1;
@@ -688,14 +688,14 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
 #undef WG9_LAUNCH
         VQW_LAUNCH_CHECK("conv_wgrad9");
         if (dbias) {
-            int rc = reduce_rows(bpart, dbias, Cout, nsb * 4, st);
+            int rc = reduce_rows(bpart, dbias, Cout, nsb * 4, st, acc);
             if (rc) return rc;
         }
-        return reduce_rows(ws, dw, nout, nsb * 4, st);
+        return reduce_rows(ws, dw, nout, nsb * 4, st, acc);
     }
     const int bm = wg_tile(Cout), bn = wg_tile(in.C0 + in.C1);
 #define WG_CASE(M_, N_, K_) \
-    if (bm == M_ && bn == N_) return launch_wgrad<M_, N_, K_>(in, dy, dw, ws, N, H, W, Cout, ks, dil, st)
+    if (bm == M_ && bn == N_) return launch_wgrad<M_, N_, K_>(in, dy, dw, ws, N, H, W, Cout, ks, dil, st, acc)
     WG_CASE(32, 32, 32);
     WG_CASE(32, 64, 32);
     WG_CASE(64, 32, 32);

@@ -9,6 +9,7 @@ library or a CPU tensor raises (no eager fallback).
 Conv weights are logically OIHW and physically OHWI (channels_last too).
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -67,6 +68,81 @@ def _flat(t):
 
 
 # ----------------------------------------------------------------------------------------------
+# weight-gradient side stream
+# ----------------------------------------------------------------------------------------------
+# In backward the weight gradient of a conv is a leaf of the dependency chain: nothing downstream needs it before the
+# optimiser.  It is therefore enqueued on a side HIP stream, where the MFMA-bound wgrad kernels overlap with the
+# HBM-bound normalisation / element-wise backward kernels of the main chain, and written straight into `param.grad`
+# (overwrite on the first use of a step, in-kernel accumulate afterwards — both views of a step share one buffer, no
+# autograd add pass).  The main stream re-joins the side stream at the end of the backward pass (engine callback).
+# VQW_WGRAD_STREAM=0 disables it (weight gradients then flow through autograd as usual).
+WGRAD_ASYNC = os.environ.get("VQW_WGRAD_STREAM", "1") != "0"
+_side_streams = {}
+_join_queued = False
+grad_ready_listeners = []      # callables(param): the param's gradient is final and enqueued on the side stream
+
+
+def reset_pending(params):
+    """Forget forward passes that were never back-propagated (call before the forwards of a training step)."""
+    for p in params:
+        if hasattr(p, "_vqw_pending"):
+            p._vqw_pending = 0
+
+
+def wgrad_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=key)
+        _side_streams[key] = st
+    return st
+
+
+def _join_side_stream():
+    global _join_queued
+    _join_queued = False
+    for st in _side_streams.values():
+        torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout):
+    """Enqueue dW (and db) on the side stream, writing into weight.grad / bias.grad."""
+    global _join_queued
+    L = _L()
+    main = torch.cuda.current_stream()
+    side = wgrad_stream(gy.device)
+    ev = main.record_event()
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    for t in (x0, x1, gy):
+        if t is not None:
+            t.record_stream(side)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        acc = weight.grad is not None
+        if not acc:
+            weight.grad = torch.empty((Cout, C0 + C1, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+            if bias is not None:
+                bias.grad = torch.empty(Cout, dtype=torch.float32, device=gy.device)
+        gw, gb = weight.grad, (bias.grad if bias is not None else None)
+        if gw.stride() != weight.stride():
+            raise RuntimeError("conv2d: existing weight.grad layout does not match the parameter layout")
+        ws = _ws(L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks), gy)
+        _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
+                                      N, H, W, Cout, ks, dilation, int(acc), _st()), "vqw_conv2d_wgrad")
+        weight._vqw_pending = getattr(weight, "_vqw_pending", 1) - 1
+        if weight._vqw_pending <= 0:
+            weight._vqw_pending = 0
+            for fn in grad_ready_listeners:
+                fn(weight)
+                if bias is not None:
+                    fn(bias)
+    if not _join_queued:
+        _join_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+
+
+# ----------------------------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------------------------
 def _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dil, relu=False):
@@ -96,6 +172,12 @@ class _Conv2d(torch.autograd.Function):
         y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
         ctx.save_for_backward(x0, x1, w, y if relu else None)
         ctx.cfg = (dilation, up0, ks, N, H, W, Cout, bias is not None)
+        # leaf parameters get their gradient written out-of-band on the side stream (see _deferred_wgrad)
+        ctx.defer = (WGRAD_ASYNC and ctx.needs_input_grad[2] and weight.is_leaf and w is weight
+                     and (bias is None or (bias.is_leaf and bias.is_contiguous())))
+        if ctx.defer:
+            ctx.params = (weight, bias)
+            weight._vqw_pending = getattr(weight, "_vqw_pending", 0) + 1
         return y
 
     @staticmethod
@@ -130,13 +212,17 @@ class _Conv2d(torch.autograd.Function):
                     g1 = torch.empty_like(x1, memory_format=CL)
                     _lib.check(L.vqw_input_grad_gather(_p(g_full), Cin, C0, C1, 0, _p(g1), 0, N, H, W, _st()),
                                "vqw_input_grad_gather")
-        if needw or (needb and has_bias):
+        if ctx.defer and (needw or (needb and has_bias)):
+            weight, bias = ctx.params
+            _deferred_wgrad(weight, bias if (has_bias and bias.requires_grad) else None, x0, x1, gy, up0, ks, dilation,
+                            N, H, W, Cout)
+        elif needw or (needb and has_bias):
             nb = L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks)
             ws = _ws(nb, gy)
             gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
             gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
             _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
-                                          N, H, W, Cout, ks, dilation, _st()), "vqw_conv2d_wgrad")
+                                          N, H, W, Cout, ks, dilation, 0, _st()), "vqw_conv2d_wgrad")
         return g0, g1, gw, gb, None, None, None
 
 

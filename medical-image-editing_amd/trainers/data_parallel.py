@@ -36,19 +36,33 @@ class GradientAllReducer:
         self._pending = None
         self._work = []
         self._flat = [None] * len(self.buckets)
+        # gradients that flow through autograd announce themselves via the hook; conv weight gradients written
+        # out-of-band on the side stream announce themselves via hipops.ops.grad_ready_listeners (when importable)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self._armed = False
-        self._stream = None
+        try:
+            from hipops import ops as _ops
+            _ops.grad_ready_listeners.append(self._on_grad_listener)
+        except Exception:       # plain torch modules (CPU tests)
+            pass
 
     def prepare(self):
         """Arm the hooks for one backward pass."""
         self._pending = [len(b) for b in self.buckets]
+        self._seen = set()
         self._work = []
         self._armed = self.world > 1
 
+    def _on_grad_listener(self, p):
+        if p in self._bucket_of:
+            self._on_grad(p)
+
     def _on_grad(self, p):
-        if not self._armed:
-            return
+        if not self._armed or id(p) in self._seen:
+            return          # a parameter may be announced by both the autograd hook and the side-stream listener
+        if p.grad is None:
+            return          # hook fired for a gradient that is written out-of-band: wait for the listener
+        self._seen.add(id(p))
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:

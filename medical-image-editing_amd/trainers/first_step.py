@@ -61,6 +61,7 @@ class FirstStepTrainer:
         self.dec_optim = Adam([p for p in self.decoder.parameters() if p.requires_grad], lr=lr, betas=betas,
                               weight_decay=weight_decay)
         self.reducer = None
+        self._params = list(self.encoder.parameters()) + list(self.decoder.parameters())
         if data_parallel:
             params = [p for p in self.decoder.parameters() if p.requires_grad][::-1] + \
                      [p for p in self.encoder.parameters() if p.requires_grad][::-1]
@@ -94,6 +95,8 @@ class FirstStepTrainer:
 
     def training_step(self, batch, noise=None):
         image = batch['image'] if isinstance(batch, dict) else batch
+        if self.reducer is not None:
+            ops.reset_pending(self._params)
         out = self.forward_losses(image, noise)
         self.enc_optim.zero_grad()
         self.dec_optim.zero_grad()

@@ -102,7 +102,7 @@ def main():
 
         def wgrad():
             _lib.check(L.vqw_conv2d_wgrad(p(x0), c0, int(up), p(x1), c1, p(dy), p(dw), p(db), p(ws), ws.numel(), N, h, h, co, ks,
-                                          dil, st()))
+                                          dil, 0, st()))
         for name, fn, on in (("fwd", fwd, True), ("dgrad", dgrad, dg), ("wgrad", wgrad, True)):
             if not on or (args.only and args.only != name):
                 continue
