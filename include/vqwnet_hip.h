@@ -158,6 +158,21 @@ int vqw_codebook_losses(const float* codebook_kd, float margin, float* l_dist, f
 int vqw_onehot(const int32_t* labels, float* out_nchw, int B, long HW, int n_classes, void* stream);
 int vqw_flip_labels(const int64_t* ids, int32_t* out, int border, int B, int H, int W, void* stream);
 
+/* ---- optional paths
+ * PixelShuffle(2) in NHWC (blocks.py:100-104): (H, W, C) are the high-resolution output dims; inverse=1 is the backward. */
+int vqw_pixel_shuffle2(const float* src, float* dst, int N, int H, int W, int C, int inverse, void* stream);
+/* DropBlock (dropblock.py:47-94): keep = 1 - dilate(seed), scale = numel/sum(keep); apply is also its own backward. */
+int vqw_dropblock_mask(const float* seed, float* keep, float* scale_dev, int N, int H, int W, int block_size, void* stream);
+int vqw_dropblock_apply(const float* x, const float* keep, const float* scale_dev, float* y, long P, int C, void* stream);
+/* SoftDice + Focal (functions/seg_loss.py:15-62) on NCHW logits / one-hot targets, C <= 64: loss_out = {dice, focal}. */
+size_t vqw_seg_ws_bytes(int C);
+int vqw_seg_losses_fwd(const float* logits_nchw, const float* target_nchw, float* loss_out, double* sums, void* ws,
+                       size_t ws_bytes, int B, long HW, int C, int ignore_index, float smooth, float gamma, float eps,
+                       void* stream);
+int vqw_seg_losses_bwd(const float* logits_nchw, const float* target_nchw, const double* sums, const float* g_dice,
+                       const float* g_focal, float* glogits, int B, long HW, int C, int ignore_index, float smooth,
+                       float gamma, float eps, void* stream);
+
 /* ---- optimiser: torch.optim.Adam as built in trainers/base.py:165-175 */
 int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,

@@ -1,3 +1,4 @@
 """Drop-in `functions` package (reference: functions/__init__.py): losses of the first training step."""
 from .embed_loss import EmbeddingLoss  # noqa: F401
 from .onehot import OneHotEncoder  # noqa: F401
+from .seg_loss import SoftDiceLoss, FocalLoss  # noqa: F401

@@ -64,6 +64,12 @@ SIGNATURES = {
     "vqw_codebook_losses": (c_i, [c_p, c_f, c_p, c_p, c_i, c_i, c_p]),
     "vqw_onehot": (c_i, [c_p, c_p, c_i, c_l, c_i, c_p]),
     "vqw_flip_labels": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_pixel_shuffle2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_dropblock_mask": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_dropblock_apply": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_p]),
+    "vqw_seg_ws_bytes": (c_sz, [c_i]),
+    "vqw_seg_losses_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p]),
+    "vqw_seg_losses_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqw_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
 }
 

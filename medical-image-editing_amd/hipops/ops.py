@@ -694,3 +694,106 @@ def flip_labels(ids, border=0):
 def set_conv_backend(mode):
     """0 = auto (MFMA kernels where shapes allow), 1 = generic VALU kernels only (testing)."""
     return _L().vqw_set_conv_backend(int(mode))
+
+
+# ----------------------------------------------------------------------------------------------
+# optional paths: PixelShuffle(2), DropBlock, SoftDice / Focal
+# ----------------------------------------------------------------------------------------------
+class _PixelShuffle2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev(x)
+        x = nhwc(x)
+        N, C4, h, w = x.shape
+        if C4 % 4:
+            raise RuntimeError("pixel_shuffle(2): channels must be a multiple of 4")
+        y = empty_nhwc(N, C4 // 4, 2 * h, 2 * w, x)
+        _lib.check(_L().vqw_pixel_shuffle2(_p(x), _p(y), N, 2 * h, 2 * w, C4 // 4, 0, _st()), "vqw_pixel_shuffle2")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = nhwc(gy)
+        N, C, H, W = gy.shape
+        gx = empty_nhwc(N, 4 * C, H // 2, W // 2, gy)
+        _lib.check(_L().vqw_pixel_shuffle2(_p(gy), _p(gx), N, H, W, C, 1, _st()), "vqw_pixel_shuffle2")
+        return gx
+
+
+def pixel_shuffle2(x):
+    return _PixelShuffle2.apply(x)
+
+
+def dropblock_mask(seed_mask, block_size):
+    """seed (B,H,W) float {0,1} on device -> (keep (B,H,W), scale (1,) = numel/sum(keep))."""
+    _dev(seed_mask)
+    seed = seed_mask.float().contiguous()
+    B, H, W = seed.shape
+    keep = torch.empty_like(seed)
+    scale = torch.empty(1, dtype=torch.float32, device=seed.device)
+    _lib.check(_L().vqw_dropblock_mask(_p(seed), _p(keep), _p(scale), B, H, W, int(block_size), _st()), "vqw_dropblock_mask")
+    return keep, scale
+
+
+class _DropBlockApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, keep, scale):
+        _dev(x, keep, scale)
+        x = nhwc(x)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x, memory_format=CL)
+        _lib.check(_L().vqw_dropblock_apply(_p(x), _p(keep), _p(scale), _p(y), N * H * W, C, _st()), "vqw_dropblock_apply")
+        ctx.save_for_backward(keep, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        keep, scale = ctx.saved_tensors
+        gy = nhwc(gy)
+        N, C, H, W = gy.shape
+        gx = torch.empty_like(gy, memory_format=CL)
+        _lib.check(_L().vqw_dropblock_apply(_p(gy), _p(keep), _p(scale), _p(gx), N * H * W, C, _st()), "vqw_dropblock_apply")
+        return gx, None, None
+
+
+def dropblock_apply(x, keep, scale):
+    return _DropBlockApply.apply(x, keep, scale)
+
+
+class _SegLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, smooth, gamma, eps):
+        _dev(logits, target)
+        z = logits.contiguous()
+        t = target.float().contiguous()
+        if z.dtype != torch.float32 or z.shape != t.shape or z.dim() < 2:
+            raise RuntimeError("seg losses: fp32 logits and same-shape one-hot targets (B,C,...) expected")
+        B, C = z.shape[0], z.shape[1]
+        HW = z.numel() // (B * C)
+        L = _L()
+        out = torch.empty(2, dtype=torch.float32, device=z.device)
+        sums = torch.empty(2 * C + 2, dtype=torch.float64, device=z.device)
+        ws = _ws(L.vqw_seg_ws_bytes(C), z)
+        _lib.check(L.vqw_seg_losses_fwd(_p(z), _p(t), _p(out), _p(sums), _p(ws), ws.numel(), B, HW, C, ignore_index, smooth, gamma,
+                                        eps, _st()), "vqw_seg_losses_fwd")
+        ctx.save_for_backward(z, t, sums)
+        ctx.cfg = (ignore_index, smooth, gamma, eps)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_dice, g_focal):
+        z, t, sums = ctx.saved_tensors
+        ignore_index, smooth, gamma, eps = ctx.cfg
+        B, C = z.shape[0], z.shape[1]
+        HW = z.numel() // (B * C)
+        gz = torch.empty_like(z)
+        gd = g_dice.contiguous() if g_dice is not None else None
+        gf = g_focal.contiguous() if g_focal is not None else None
+        _lib.check(_L().vqw_seg_losses_bwd(_p(z), _p(t), _p(sums), _p(gd), _p(gf), _p(gz), B, HW, C, ignore_index, smooth, gamma,
+                                           eps, _st()), "vqw_seg_losses_bwd")
+        return gz, None, None, None, None, None
+
+
+def seg_losses(logits, target, ignore_index=-1, smooth=1e-6, gamma=2.0, eps=1e-6):
+    """-> (soft dice loss, focal loss) of functions/seg_loss.py for NCHW logits and one-hot targets."""
+    return _SegLosses.apply(logits, target, int(ignore_index), float(smooth), float(gamma), float(eps))

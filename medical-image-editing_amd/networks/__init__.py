@@ -5,3 +5,4 @@ from .unet_decoder import UNetDecoder  # noqa: F401
 from .blocks import UpBlock, ResBlock, DoubleConv, StyledDenorm, StyledResUpBlock  # noqa: F401
 from .aspp import ASPP  # noqa: F401
 from .vq import VQ  # noqa: F401
+from .vqwnet import VQWNet  # noqa: F401

@@ -125,12 +125,16 @@ class StyledDenorm(nn.Module):
 
 
 class PixelShuffle(nn.Module):
+    """nn.PixelShuffle(2) as an NHWC permutation kernel."""
+
     def __init__(self, r):
         super().__init__()
+        if r != 2:
+            raise NotImplementedError("only PixelShuffle(2) is used on this path")
         self.r = r
 
     def forward(self, x):
-        raise NotImplementedError("pixel-shuffle up-sampling is not built yet (use_pixel_shuffle=False)")
+        return ops.pixel_shuffle2(x)
 
 
 class StyledResUpBlock(nn.Module):

@@ -8,6 +8,8 @@ import numpy as np
 import torch
 from torch import nn
 
+from hipops import ops
+
 
 class LinearScheduler(nn.Module):
     def __init__(self, dropblock, start_value, stop_value, nr_steps):
@@ -36,12 +38,16 @@ class DropBlock2D(nn.Module):
             return x
         assert x.dim() == 4, "Expected input with 4 dimensions (bsize, channels, height, width)"
         gamma = self._compute_gamma(x)
-        mask = (torch.rand(x.shape[0], *x.shape[2:]) < gamma).float().to(x.device)
-        block_mask = self._compute_block_mask(mask)
-        self.block_mask = block_mask
+        mask = (torch.rand(x.shape[0], *x.shape[2:]) < gamma).float().to(x.device)    # host RNG, as upstream
+        return self.apply_seed_mask(x, mask)
+
+    def apply_seed_mask(self, x, mask):
+        """Deterministic part (dropblock.py:61-74) given the Bernoulli seed mask (B,H,W) on the device."""
+        keep, scale = ops.dropblock_mask(mask, self.block_size)
+        self.block_mask = keep
         if self.drop_prob == 0.:
             return x
-        raise NotImplementedError("DropBlock apply kernel is not built yet (use_dropblock=False)")
+        return ops.dropblock_apply(x, keep, scale)
 
     def _compute_block_mask(self, mask):
         """keep = 1 - dilate(mask, block_size) (stride-1 max-pool, pad block_size//2, crop for even sizes)."""

@@ -247,6 +247,22 @@ def decoder_forward(P, x, training, n_levels=4, dropped_skip_layers=(), pixel_sh
     return torch.tanh(conv(P, "conv1x1", y))
 
 
+def vqwnet_forward(P, x, training, momentum=0.99):
+    """networks/vqwnet.py:96-152 (freeze_first_half=False, no dropblock): two U-Nets in series around the VQ."""
+    feat = encoder_features(P, x)
+    q, commit, ids0, gap = vq_forward(vq_state(P), feat, training, momentum)
+    h = q
+    skips = []
+    for i in range(4):
+        h, sk = res_block(P, "down_conv2_%d" % (i + 1), h)
+        skips.append(sk)
+    h = double_conv(P, "double_conv2", h)
+    for lvl in (4, 3, 2, 1):
+        h = up_block(P, "up_conv2_%d" % lvl, h, skips[lvl - 1])
+    recon = torch.tanh(conv(P, "conv_last", h))
+    return {"recon": recon, "embed": feat, "commit_loss": commit, "ids": ids0 + 1, "gap": gap, "quantized": q}
+
+
 # ----------------------------------------------------------------------------
 # losses
 # ----------------------------------------------------------------------------

@@ -287,7 +287,61 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
     save(name, d)
 
 
+def gen_extras():
+    """Optional paths: pixel-shuffle up-sampling (the decoder's default), VQWNet monolith, DropBlock apply."""
+    d = {}
+    B = R.blocks
+    torch.manual_seed(31)
+    module_case("styled_res_up_ps", B.StyledResUpBlock(32, 16, 16, use_pixel_shuffle=True),
+                [torch.randn(2, 32, 8, 8), torch.randn(2, 16, 16, 16)], d)
+    # decoder with the constructor defaults that matter (use_pixel_shuffle=True); weights from the seed
+    torch.manual_seed(32)
+    dec = R.UNetDecoder(16, 1, [16, 32, 32, 32, 64], use_dropblock=False, dropped_skip_layers=[])
+    dec.train()
+    for k, v in dec.state_dict().items():
+        d["dec_ps/init_sum." + k] = checksum(v.float())
+    x = torch.randn(2, 16, 32, 32, requires_grad=True)
+    y = dec(x)
+    r = torch.randn_like(y)
+    (y * r).sum().backward()
+    d["dec_ps/x"], d["dec_ps/R"], d["dec_ps/y"], d["dec_ps/gx"] = npy(x), npy(r), npy(y), npy(x.grad)
+    for k, p in dec.named_parameters():
+        d["dec_ps/gnorm." + k] = np.array(float(p.grad.norm()))
+    # VQWNet monolith (vqwnet.py), warm VQ state for conditioning
+    torch.manual_seed(33)
+    net = R.VQWNet(1, 1, [16, 16, 32, 32, 32], dict_size=6)
+    for k, v in net.state_dict().items():
+        d["vqwnet/init_sum." + k] = checksum(v.float())
+    with torch.no_grad():
+        net.vq.embed.mul_(0.7)
+        net.vq.cluster_size.fill_(2 * 32 * 32 / 6)
+        net.vq.embed_avg.copy_(net.vq.embed.t() * net.vq.cluster_size[None, :])
+    net.train()
+    img = torch.randn(2, 1, 32, 32).clamp_(-1, 1)
+    out = net(img)
+    r = torch.randn_like(out["recon"])
+    ((out["recon"] * r).sum() + out["commit_loss"]).backward()
+    d["vqwnet/image"], d["vqwnet/R"] = npy(img), npy(r)
+    d["vqwnet/recon"], d["vqwnet/embed"], d["vqwnet/ids"] = npy(out["recon"]), npy(out["embed"]), npy(out["ids"])
+    d["vqwnet/commit"] = npy(out["commit_loss"])
+    for k, p in net.named_parameters():
+        d["vqwnet/gnorm." + k] = np.array(float(p.grad.norm()))
+    for b in ("embed", "cluster_size", "embed_avg"):
+        d["vqwnet/after.vq." + b] = npy(getattr(net.vq, b)).copy()
+    gen = net.generate_images_from_ids((out["ids"] - 1))
+    d["vqwnet/gen_recon"] = npy(gen["recon"])
+    # DropBlock deterministic apply
+    db = R.dropblock.DropBlock2D(drop_prob=0.3, block_size=4)
+    m = (torch.rand(2, 12, 12) < 0.05).float()
+    keep = db._compute_block_mask(m)
+    xx = torch.randn(2, 8, 12, 12)
+    d["dropblock/seed"], d["dropblock/x"] = npy(m), npy(xx)
+    d["dropblock/y"] = npy(xx * keep[:, None] * keep.numel() / keep.sum())
+    save("extras.npz", d)
+
+
 if __name__ == "__main__":
+    gen_extras()
     gen_blocks()
     gen_vq()
     gen_losses()

@@ -328,6 +328,8 @@ def test_first_step_golden(golden, name):
         emb = ops.vq_lookup(ids0, tr.encoder.vq.embed, mask=mask, scale=scale)
         assert_close(emb, g["recon/embed"], 1e-6, "masked embed")
         assert_close(tr.decoder(emb), g["recon/recon"], 5e-3, "mask-guided recon")
+        from run_recon import reconstruct
+        assert_close(reconstruct(tr.encoder, tr.decoder, g.t("recon/label_map", DEV)), g["recon/recon"], 5e-3, "run_recon")
         e2 = tr.encoder.get_embed_from_ids(ids0)
         assert_close(e2 * mask[:, None].float() * scale, g["recon/embed"], 1e-6, "get_embed_from_ids")
     tr.encoder.train(); tr.decoder.train()
@@ -422,3 +424,82 @@ def test_full_size_properties():
     assert torch.unique(e[: 65536], dim=0).shape[0] <= K
     for p in list(tr.encoder.parameters()) + list(tr.decoder.parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
+# --------------------------------------------------------------------------------------------------
+# optional paths
+# --------------------------------------------------------------------------------------------------
+def test_extras_golden(golden):
+    from networks import blocks as B, UNetDecoder, VQWNet
+    from networks.dropblock import DropBlock2D
+    from functions import SoftDiceLoss, FocalLoss
+    from helpers import checksum
+    g = golden("extras.npz")
+    # pixel-shuffle up block (reuses the block runner on the extras file)
+    sd = {k[2:]: v for k, v in g.group("styled_res_up_ps").items() if k.startswith("P.")}
+    mod = B.StyledResUpBlock(32, 16, 16, use_pixel_shuffle=True)
+    mod.load_state_dict(sd, strict=True)
+    mod.to(DEV).train()
+    ins = [g.t("styled_res_up_ps/in.%d" % i, DEV).requires_grad_(True) for i in range(2)]
+    out = mod(*ins)
+    (out * g.t("styled_res_up_ps/R.0", DEV)).sum().backward()
+    assert_close(out, g["styled_res_up_ps/out.0"], 1e-4, "ps block out")
+    for i in range(2):
+        assert_close(ins[i].grad, g["styled_res_up_ps/gin.%d" % i], 1e-3, "ps block gin.%d" % i, atol=1e-6)
+    for k, p in mod.named_parameters():
+        assert_close(p.grad, g["styled_res_up_ps/gP." + k], 1e-3, "ps block gP." + k, atol=2e-5)
+    # decoder with constructor defaults (use_pixel_shuffle=True)
+    torch.manual_seed(32)
+    dec = UNetDecoder(16, 1, [16, 32, 32, 32, 64], use_dropblock=False, dropped_skip_layers=[]).to(DEV).train()
+    x = g.t("dec_ps/x", DEV).requires_grad_(True)
+    y = dec(x)
+    (y * g.t("dec_ps/R", DEV)).sum().backward()
+    assert_close(y, g["dec_ps/y"], 2e-4, "decoder (pixel shuffle) y")
+    assert_close(x.grad, g["dec_ps/gx"], 5e-3, "decoder (pixel shuffle) gx")
+    gmax = max(float(g[k]) for k in g.files if k.startswith("dec_ps/gnorm."))
+    for k, p in dec.named_parameters():
+        ref = float(g["dec_ps/gnorm." + k])
+        if ref > 1e-5 * gmax:
+            assert abs(float(p.grad.norm()) - ref) <= 5e-3 * ref, "dec_ps grad norm " + k
+    # VQWNet monolith
+    torch.manual_seed(33)
+    net = VQWNet(1, 1, [16, 16, 32, 32, 32], dict_size=6)
+    with torch.no_grad():
+        net.vq.embed.mul_(0.7)
+        net.vq.cluster_size.fill_(2 * 32 * 32 / 6)
+        net.vq.embed_avg.copy_(net.vq.embed.t() * net.vq.cluster_size[None, :])
+    net.to(DEV).train()
+    o = net(g.t("vqwnet/image", DEV))
+    ((o["recon"] * g.t("vqwnet/R", DEV)).sum() + o["commit_loss"]).backward()
+    assert np.mean(o["ids"].cpu().numpy() == g["vqwnet/ids"]) > 0.999
+    assert_close(o["recon"], g["vqwnet/recon"], 2e-4, "vqwnet recon")
+    assert_close(o["embed"], g["vqwnet/embed"], 2e-4, "vqwnet embed")
+    assert_close(o["commit_loss"], g["vqwnet/commit"], 1e-4, "vqwnet commit")
+    for b in ("embed", "cluster_size", "embed_avg"):
+        assert_close(getattr(net.vq, b), g["vqwnet/after.vq." + b], 1e-4, "vqwnet vq." + b)
+    gmax = max(float(g[k]) for k in g.files if k.startswith("vqwnet/gnorm."))
+    for k, p in net.named_parameters():
+        ref = float(g["vqwnet/gnorm." + k])
+        if ref > 1e-5 * gmax:
+            assert abs(float(p.grad.norm()) - ref) <= 1e-2 * ref, "vqwnet grad norm " + k
+    gen = net.generate_images_from_ids(torch.from_numpy(g["vqwnet/ids"]).to(DEV) - 1)
+    assert_close(gen["recon"], g["vqwnet/gen_recon"], 5e-4, "vqwnet generate_images_from_ids")
+    # DropBlock
+    db = DropBlock2D(drop_prob=0.3, block_size=4).train()
+    xx = g.t("dropblock/x", DEV).requires_grad_(True)
+    yy = db.apply_seed_mask(xx, g.t("dropblock/seed", DEV))
+    yy.sum().backward()
+    assert_close(yy, g["dropblock/y"], 1e-6, "dropblock apply")
+    assert_close(xx.grad, g["dropblock/y"] / np.where(g["dropblock/x"] == 0, 1, g["dropblock/x"]), 1e-5, "dropblock grad")
+    gl = golden("losses.npz")
+    for bs, key in ((4, "keep4"), (5, "keep5")):
+        keep, _ = _ops().dropblock_mask(gl.t("dropblock/seed4", DEV), bs)
+        assert np.array_equal(keep.cpu().numpy(), gl["dropblock/" + key])
+    # segmentation losses
+    tgt = gl.t("seg/target", DEV)
+    for name, mod in (("dice", SoftDiceLoss()), ("dice_ign", SoftDiceLoss(ignore_index=0)), ("focal", FocalLoss())):
+        z = gl.t("seg/logits", DEV).requires_grad_(True)
+        l = mod(z, tgt)
+        l.backward()
+        assert_close(l, gl["seg/" + name], 1e-5, name)
+        assert_close(z.grad, gl["seg/g_" + name], 1e-4, "g_" + name)

@@ -240,3 +240,37 @@ def test_first_step(golden, name):
     for s in range(int(g["cfg/n_steps"])):
         out = tr.step(g.t("step%d/image" % s), g.t("step%d/noise" % s))
         check_step(g, s, out, PE, PD, lr, tight=(s == 0), grad_tol=gt, max_loose=ml, loose_bound=lb)
+
+
+def test_extras(golden):
+    """Optional paths: pixel-shuffle up block / default decoder, VQWNet monolith, DropBlock apply."""
+    from networks import UNetDecoder, VQWNet
+    g = golden("extras.npz")
+    _run_case(g, "styled_res_up_ps", lambda P, d, s: O.styled_res_up_block(_pref(P, "m."), "m", d, s, True, pixel_shuffle=True), 2)
+    torch.manual_seed(32)
+    dec = UNetDecoder(16, 1, [16, 32, 32, 32, 64], use_dropblock=False, dropped_skip_layers=[])
+    for k, v in dec.state_dict().items():
+        assert abs(checksum(v.float())[1] - g["dec_ps/init_sum." + k][1]) <= 1e-9 * max(1.0, g["dec_ps/init_sum." + k][1]), k
+    PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
+    for k in O.trainable_keys(PD):
+        PD[k].requires_grad_(True)
+    x = g.t("dec_ps/x").requires_grad_(True)
+    y = O.decoder_forward(PD, x, True, pixel_shuffle=True)
+    (y * g.t("dec_ps/R")).sum().backward()
+    assert_close(y, g["dec_ps/y"], 1e-4, "decoder (pixel shuffle) y")
+    assert_close(x.grad, g["dec_ps/gx"], 2e-3, "decoder (pixel shuffle) gx")
+    torch.manual_seed(33)
+    net = VQWNet(1, 1, [16, 16, 32, 32, 32], dict_size=6)
+    P = {k: v.detach().clone().contiguous() for k, v in net.state_dict().items()}
+    for k, v in P.items():
+        assert abs(checksum(v.float())[1] - g["vqwnet/init_sum." + k][1]) <= 1e-9 * max(1.0, g["vqwnet/init_sum." + k][1]), k
+    P["vq.embed"].mul_(0.7)
+    P["vq.cluster_size"].fill_(2 * 32 * 32 / 6)
+    P["vq.embed_avg"].copy_(P["vq.embed"].t() * P["vq.cluster_size"][None, :])
+    out = O.vqwnet_forward(P, g.t("vqwnet/image"), True)
+    assert np.mean(out["ids"].numpy() == g["vqwnet/ids"]) > 0.999
+    assert_close(out["recon"], g["vqwnet/recon"], 1e-4, "vqwnet recon")
+    assert_close(out["embed"], g["vqwnet/embed"], 1e-4, "vqwnet embed")
+    assert_close(out["commit_loss"], g["vqwnet/commit"], 1e-4, "vqwnet commit")
+    keep = O.dropblock_mask(g.t("dropblock/seed"), 4)
+    assert_close(O.dropblock_apply(g.t("dropblock/x"), keep), g["dropblock/y"], 1e-6, "dropblock apply")
