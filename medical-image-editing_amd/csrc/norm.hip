@@ -63,8 +63,120 @@ __global__ void __launch_bounds__(256) k_plane_reduce(F f, double* __restrict__ 
     }
 }
 
+// float4 variant for C % 4 == 0: a lane owns 4 consecutive channels, C/4 lanes span a pixel, 256/(C/4) pixel rows per
+// pass (1 KiB contiguous per wave-instruction).  Functor F4: (float4 index i4, n, channel c) -> a[4], b[4].
+template <class F4>
+__global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict__ part, int HW, int C, int splits) {
+    __shared__ double sa[4][256], sb[4][256];
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int C4 = C >> 2;
+    const int tcn = C4 < 256 ? C4 : 256;
+    const int rows = 256 / tcn;
+    const int t = threadIdx.x;
+    const int tc = t % tcn, tr = t / tcn;
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = s * per;
+    const int p1 = (p0 + per < HW) ? p0 + per : HW;
+    const bool active = tr < rows;
+    for (int cb = 0; cb < C4; cb += tcn) {
+        const int c4 = cb + tc;
+        double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+        if (active && c4 < C4) {
+            int p = p0 + tr;
+            for (; p + rows < p1; p += 2 * rows) {      // two independent loads in flight per lane
+                float va[4], vb[4], wa[4], wb[4];
+                f(((long)n * HW + p) * C4 + c4, n, c4 * 4, va, vb);
+                f(((long)n * HW + p + rows) * C4 + c4, n, c4 * 4, wa, wb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[k] += (double)va[k] + (double)wa[k]; b[k] += (double)vb[k] + (double)wb[k]; }
+            }
+            for (; p < p1; p += rows) {
+                float va[4], vb[4];
+                f(((long)n * HW + p) * C4 + c4, n, c4 * 4, va, vb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[k] += (double)va[k]; b[k] += (double)vb[k]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sa[k][t] = a[k]; sb[k][t] = b[k]; }
+        __syncthreads();
+        if (tr == 0 && c4 < C4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double ta = a[k], tb = b[k];
+                for (int r = 1; r < rows; ++r) { ta += sa[k][r * tcn + tc]; tb += sb[k][r * tcn + tc]; }
+                double* o = part + (((long)n * splits + s) * C + c4 * 4 + k) * 2;
+                o[0] = ta;
+                o[1] = tb;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // InstanceNorm
+struct FStats4 {
+    const float4* x;
+    __device__ void operator()(long i4, int, int, float* a, float* b) const {
+        float4 v = x[i4];
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+        b[0] = v.x * v.x; b[1] = v.y * v.y; b[2] = v.z * v.z; b[3] = v.w * v.w;
+    }
+};
+template <int RELU>
+struct FInBwd4 {
+    const float4* x;
+    const float* mr;
+    const float4* gy;
+    int C;
+    __device__ void operator()(long i4, int n, int c, float* a, float* b) const {
+        const float4* m = (const float4*)(mr + 2 * ((long)n * C + c));
+        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[i4];
+        float xh[4] = {(v.x - m0.x) * m0.y, (v.y - m0.z) * m0.w, (v.z - m1.x) * m1.y, (v.w - m1.z) * m1.w};
+        float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float q = (RELU && !(xh[k] > 0.f)) ? 0.f : gg[k];
+            a[k] = q;
+            b[k] = q * xh[k];
+        }
+    }
+};
+template <int RELU>
+struct FSpadeBwd4 {
+    const float4* x;
+    const float* mr;
+    const float4* gamma;
+    const float4* beta;
+    const float4* gy;
+    float4* dgamma;
+    float4* dbeta;
+    __device__ void operator()(long i4, int, int c, float* a, float* b) const {
+        const float4* m = (const float4*)(mr + 2 * c);
+        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[i4], ga = gamma[i4], be = beta[i4];
+        float xh[4] = {(v.x - m0.x) * m0.y, (v.y - m0.z) * m0.w, (v.z - m1.x) * m1.y, (v.w - m1.z) * m1.w};
+        float gg[4] = {g.x, g.y, g.z, g.w}, gm[4] = {1.f + ga.x, 1.f + ga.y, 1.f + ga.z, 1.f + ga.w};
+        float bb[4] = {be.x, be.y, be.z, be.w}, dg[4], db[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float q = gg[k];
+            if (RELU && !(xh[k] * gm[k] + bb[k] > 0.f)) q = 0.f;
+            dg[k] = q * xh[k];
+            db[k] = q;
+            float dxh = q * gm[k];
+            a[k] = dxh;
+            b[k] = dxh * xh[k];
+        }
+        float4 o1, o2;
+        o1.x = dg[0]; o1.y = dg[1]; o1.z = dg[2]; o1.w = dg[3];
+        o2.x = db[0]; o2.y = db[1]; o2.z = db[2]; o2.w = db[3];
+        dgamma[i4] = o1;
+        dbeta[i4] = o2;
+    }
+};
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
 struct FStats {
     const float* x;
     __device__ void operator()(long i, int, int, float& a, float& b) const { float v = x[i]; a = v; b = v * v; }
@@ -148,8 +260,13 @@ extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff
     VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_inorm_fwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int splits = plane_splits(N, HW);
-    FStats f{x};
-    k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    if ((C & 3) == 0 && al16(x)) {
+        FStats4 f{(const float4*)x};
+        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    } else {
+        FStats f{x};
+        k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    }
     k_inorm_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>((const double*)ws, mean_rstd, N * C, C, splits,
                                                                  1.0 / (double)HW, eps);
     long total = (long)N * HW * C;
@@ -224,7 +341,14 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
     double* part = (double*)ws;
     float* means = (float*)((char*)ws + plane_part_bytes(N, C));
     long total = (long)N * HW * C;
-    if (relu) {
+    const bool vec = (C & 3) == 0 && gy_cstride == C && gy_coff == 0 && al16(x) && al16(gy) && al16(mean_rstd);
+    if (vec && relu) {
+        FInBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gy, C};
+        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
+    } else if (vec) {
+        FInBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gy, C};
+        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
+    } else if (relu) {
         FInBwd<1> f{x, mean_rstd, gy, C, gy_cstride, gy_coff};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
     } else {
@@ -275,8 +399,13 @@ extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size
     VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_bn_partial_stats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int splits = plane_splits(N, HW);
-    FStats f{x};
-    k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    if ((C & 3) == 0 && al16(x)) {
+        FStats4 f{(const float4*)x};
+        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    } else {
+        FStats f{x};
+        k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    }
     k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
     VQW_LAUNCH_CHECK("vqw_bn_partial_stats");
     return VQW_OK;
@@ -375,7 +504,14 @@ extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, cons
     VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_spade_bwd_reduce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int splits = plane_splits(N, HW);
-    if (relu) {
+    const bool vec = (C & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(gy) && al16(dgamma) && al16(dbeta) && al16(mean_rstd);
+    if (vec && relu) {
+        FSpadeBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta};
+        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    } else if (vec) {
+        FSpadeBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta};
+        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    } else if (relu) {
         FSpadeBwd<1> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     } else {
