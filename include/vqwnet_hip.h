@@ -62,6 +62,17 @@ size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, 
 int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float* src1, int C1,
                      const float* dy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes,
                      int N, int H, int W, int Cout, int ksize, int dil, int accumulate, void* stream);
+/* 3x3 conv over a nearest x2 up-sampled single source (StyledResUpBlock conv / conv1, blocks.py:106,117,123-126),
+ * collapsed onto the low-resolution grid: four 2x2 convs forward, one 4x4 stride-2 gather for the input gradient —
+ * 4/9 of the FLOPs of the direct form and no full-resolution gradient intermediate.  x_low is [N,h,w,Cin], y and dy
+ * are [N,2h,2w,Cout].  prepare() writes the tap-summed weights for both directions into ws (valid while w is unchanged). */
+int vqw_conv3x3_up2_supported(int Cin, int Cout, int N, int h, int w);
+size_t vqw_conv3x3_up2_ws_bytes(int Cin, int Cout);
+int vqw_conv3x3_up2_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream);
+int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const float* bias, float* y, int N, int h, int w, int Cin,
+                        int Cout, int relu, void* stream);
+int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
+                          void* stream);
 /* Gradient of the virtual input: g_full is [N,H,W,Ctot]; takes channels
  * [c_off, c_off+C).  up=1: dst[N,H/2,W/2,C] = 2x2 block sums; up=0: plain slice copy.
  * accumulate=1 adds into dst.                                                      */

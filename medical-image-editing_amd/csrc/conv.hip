@@ -134,3 +134,31 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     ProfScope ps(3, flops, st);
     return conv_direct_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st, accumulate);
 }
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 conv over a nearest x2 up-sampled input (blocks.py:106,123-126), collapsed onto the low-resolution grid
+extern "C" int vqw_conv3x3_up2_supported(int Cin, int Cout, int N, int h, int w) {
+    return g_conv_backend == 0 && conv_up2_ok(Cin, Cout, (long)N * h * w) ? 1 : 0;
+}
+extern "C" size_t vqw_conv3x3_up2_ws_bytes(int Cin, int Cout) { return conv_up2_ws_floats(Cin, Cout) * sizeof(float) + 256; }
+extern "C" int vqw_conv3x3_up2_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream) {
+    VQW_CHECK(w_ohwi && ws && Cin > 0 && Cout > 0, "vqw_conv3x3_up2_prepare: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_conv3x3_up2_ws_bytes(Cin, Cout), "vqw_conv3x3_up2_prepare: workspace too small");
+    return conv_up2_prepare(w_ohwi, (float*)ws, Cin, Cout, (hipStream_t)stream);
+}
+extern "C" int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const float* bias, float* y, int N, int h, int w, int Cin,
+                                   int Cout, int relu, void* stream) {
+    VQW_CHECK(x_low && ws && y && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_fwd: bad arguments");
+    VQW_CHECK(conv_up2_ok(Cin, Cout, (long)N * h * w), "vqw_conv3x3_up2_fwd: unsupported shape (query vqw_conv3x3_up2_supported)");
+    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;       // 4 parities x 4 taps on the low-res grid
+    ProfScope ps(0, flops, (hipStream_t)stream);
+    return conv_up2_fwd(x_low, (const float*)ws, bias, y, N, h, w, Cin, Cout, relu, (hipStream_t)stream);
+}
+extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
+                                     void* stream) {
+    VQW_CHECK(dy && ws && dx_low && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_dgrad: bad arguments");
+    VQW_CHECK(conv_up2_ok(Cout, Cin, (long)N * h * w), "vqw_conv3x3_up2_dgrad: unsupported shape");
+    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
+    ProfScope ps(0, flops, (hipStream_t)stream);
+    return conv_up2_dgrad(dy, (const float*)ws, dx_low, N, h, w, Cin, Cout, (hipStream_t)stream);
+}

@@ -25,6 +25,13 @@ bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks);
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
                   int relu, hipStream_t st);
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
+// collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
+bool conv_up2_ok(int Cin, int Cout, long Plow);
+size_t conv_up2_ws_floats(int Cin, int Cout);
+int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st);
+int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
+                 hipStream_t st);
+int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st);
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc);

@@ -49,6 +49,18 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
     return ok ? *(const float4*)p : z;
 }
 
+// Tap geometry of one launch.  Taps are arbitrary (dy, dx) pixel offsets, so the same kernel serves the plain k x k
+// convolution, and the two "collapsed" forms of a 3x3 convolution over a nearest x2 up-sampled input:
+//   src_mode 0: source pixel = (y + dy, x + dx) on the M grid            (plain; up0 in ConvIn = virtual up-sampling)
+//   src_mode 2: source pixel = (2y + dy, 2x + dx) on a 2H x 2W tensor    (collapsed dgrad: M grid is the low-res map)
+//   out_mode 0: output pixel = M-grid pixel
+//   out_mode 1: output pixel = (2y + py, 2x + px) of a 2H x 2W tensor    (collapsed forward, one launch per parity)
+struct ConvGeom {
+    int ntaps;
+    int src_mode, out_mode, py, px;
+    signed char dy[16], dx[16];
+};
+
 // =============================================================================================
 // forward / dgrad
 // =============================================================================================
@@ -57,7 +69,7 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
 template <int BM, int BN, int WM, int WN, int KC>
 __global__ void __launch_bounds__(256, 2)
 k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int N, int H,
-                int W, int Cout, int ks, int dil, int ntn, int relu, unsigned nb0, unsigned nb1, unsigned nbw) {
+                int W, int Cout, ConvGeom geo, int ntn, int relu, unsigned nb0, unsigned nb1, unsigned nbw) {
     constexpr int LDK = KC + 4;           // padded row length (floats)
     constexpr int C4 = KC / 4;            // float4 per row
     constexpr int LA = BM * C4 / 256;     // A float4 loads per thread per chunk
@@ -73,7 +85,7 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int C0 = in.C0, C1 = in.C1, Cin = C0 + C1;
-    const int taps = ks * ks, half = ks >> 1;
+    const int taps = geo.ntaps;
     const unsigned P = (unsigned)N * H * W;
     const int swz = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = swz % ntn, tile_m = swz / ntn;
@@ -81,6 +93,9 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
     const int co_base = tile_n * BN;
     const int Hs = H >> 1, Ws = W >> 1;
     const int up0 = in.up0;
+    // collapsed forward: the four output parities are the y dimension of the grid, each with its own weight block
+    const int par_y = geo.out_mode == 1 ? (int)(blockIdx.y >> 1) : 0, par_x = geo.out_mode == 1 ? (int)(blockIdx.y & 1) : 0;
+    if (geo.out_mode == 1) w += (size_t)blockIdx.y * Cout * taps * Cin;
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(in.src0, nb0), rs1 = make_rsrc(in.src1, nb1), rsw = make_rsrc(w, nbw);
 
     // per-thread pixel coordinates of the A rows it loads (fixed for the whole K loop)
@@ -99,7 +114,9 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
         unsigned n = q / (unsigned)H;
         a_h[j] = (int)(q - n * H);
         a_pix[j] = pp;
-        a_upb[j] = n * (unsigned)(Hs * Ws);
+        // per-image base of the alternative source grids: the virtual up-sampled source (H/2 x W/2) or, for
+        // src_mode 2, the 2H x 2W source
+        a_upb[j] = geo.src_mode == 2 ? n * (unsigned)(4 * H * W) : n * (unsigned)(Hs * Ws);
     }
     // weight rows this thread loads (byte offsets; an invalid row sits at the out-of-range offset)
     unsigned b_off[LB];
@@ -112,10 +129,22 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
     }
 
     // loader state: current tap / channel chunk, per-tap byte offsets (out-of-range offset = zero padding)
-    int l_t = 0, l_cc = 0, l_ky = 0, l_kx = 0;
+    int l_t = 0, l_cc = 0;
     unsigned t_off0[LA], t_off1[LA];
     auto setup_tap = [&]() {
-        const int dyy = (l_ky - half) * dil, dxx = (l_kx - half) * dil;
+        const int dyy = geo.out_mode == 1 ? par_y - 1 + (l_t >> 1) : geo.dy[l_t];
+        const int dxx = geo.out_mode == 1 ? par_x - 1 + (l_t & 1) : geo.dx[l_t];
+        if (geo.src_mode == 2) {
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                int hy = 2 * a_h[j] + dyy, wx = 2 * a_w[j] + dxx;
+                bool ok = a_ok[j] && (unsigned)hy < (unsigned)(2 * H) && (unsigned)wx < (unsigned)(2 * W);
+                unsigned e0 = (a_upb[j] + (unsigned)(hy * 2 * W + wx)) * (unsigned)C0;
+                t_off0[j] = ok ? (e0 + a_c) * 4u : nb0;
+                t_off1[j] = nb1;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             int hy = a_h[j] + dyy, wx = a_w[j] + dxx;
@@ -150,7 +179,6 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
         if (l_cc >= Cin) {
             l_cc = 0;
             ++l_t;
-            if (++l_kx == ks) { l_kx = 0; ++l_ky; }
             if (l_t < taps) setup_tap();
         }
     };
@@ -218,7 +246,13 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
                 unsigned p = p_base + wm0 + i * 32 + row;
                 if (cok && p < P) {
                     float v = acc[i][j][r] + bv;
-                    y[(size_t)p * Cout + co] = relu ? fmaxf(v, 0.f) : v;
+                    size_t op = p;
+                    if (geo.out_mode == 1) {      // scatter to parity (py, px) of the 2H x 2W output
+                        unsigned q = p / (unsigned)W, xw = p - q * W;
+                        unsigned n = q / (unsigned)H, yh = q - n * H;
+                        op = ((size_t)n * 2 * H + 2 * yh + par_y) * (2 * W) + 2 * xw + par_x;
+                    }
+                    y[op * Cout + co] = relu ? fmaxf(v, 0.f) : v;
                 }
             }
         }
@@ -240,34 +274,124 @@ static inline bool fits_u32(long P, int Cin, int Cout) {
     return P * c * 4 <= 0xFFFFFFE0L;
 }
 
+static ConvGeom plain_geom(int ks, int dil) {
+    ConvGeom g{};
+    g.ntaps = ks * ks;
+    for (int t = 0; t < ks * ks; ++t) {
+        g.dy[t] = (signed char)((t / ks - ks / 2) * dil);
+        g.dx[t] = (signed char)((t % ks - ks / 2) * dil);
+    }
+    return g;
+}
+
 template <int BM, int BN, int WM, int WN, int KC>
-static int launch_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks,
-                      int dil, int relu, hipStream_t st) {
+static int launch_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
+                      const ConvGeom& geo, int relu, hipStream_t st) {
     long P = (long)N * H * W;
     int ntm = ceil_div(P, BM), ntn = ceil_div(Cout, BN);
-    const unsigned nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
-    const unsigned nbw = (unsigned)((long)Cout * ks * ks * (in.C0 + in.C1) * 4);
-    k_conv_mfma_fwd<BM, BN, WM, WN, KC><<<ntm * ntn, 256, 0, st>>>(in, w, bias, y, N, H, W, Cout, ks, dil, ntn, relu, nb0, nb1,
-                                                                   nbw);
+    const long src_px = geo.src_mode == 2 ? 4 * P : (in.up0 ? P / 4 : P);
+    const unsigned nb0 = (unsigned)(src_px * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
+    const unsigned nbw = (unsigned)((long)Cout * geo.ntaps * (in.C0 + in.C1) * 4);
+    k_conv_mfma_fwd<BM, BN, WM, WN, KC><<<dim3(ntm * ntn, geo.out_mode == 1 ? 4 : 1), 256, 0, st>>>(
+        in, w, bias, y, N, H, W, Cout, geo, ntn, relu, nb0, nb1, nbw);
     VQW_LAUNCH_CHECK("conv_mfma_fwd");
     return VQW_OK;
+}
+
+static int dispatch_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
+                        const ConvGeom& geo, int relu, hipStream_t st) {
+    const int Cin = in.C0 + in.C1;
+    const bool k32 = (Cin % 32 == 0);
+    if (Cout > 64) {
+        if (k32) return launch_fwd<128, 128, 64, 64, 32>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+        return launch_fwd<128, 128, 64, 64, 16>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    }
+    if (Cout > 32) {
+        if (k32) return launch_fwd<128, 64, 64, 32, 32>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+        return launch_fwd<128, 64, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    }
+    if (k32) return launch_fwd<128, 32, 32, 32, 32>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    return launch_fwd<256, 32, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
 }
 
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
                   int relu, hipStream_t st) {
     const int Cin = in.C0 + in.C1;
-    if (!fits_u32((long)N * H * W, Cin, Cout)) return conv_direct_fwd(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
-    const bool k32 = (Cin % 32 == 0);
-    if (Cout > 64) {
-        if (k32) return launch_fwd<128, 128, 64, 64, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
-        return launch_fwd<128, 128, 64, 64, 16>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    if (!fits_u32((long)N * H * W, Cin, Cout) || dil > 127) return conv_direct_fwd(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    return dispatch_fwd(in, w, bias, y, N, H, W, Cout, plain_geom(ks, dil), relu, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 convolution over a nearest x2 up-sampled input, collapsed onto the low-resolution grid (4/9 of the FLOPs):
+//   forward  y[2y+py, 2x+px] = sum_{a,b in {0,1}} Wc[py][px][a][b] * x[y + py-1+a, x + px-1+b]          (4 launches)
+//   dgrad    dx[y, x]        = sum_{r,s in {-1..2}} Wd[r][s] * dY[2y + r, 2x + s]                        (1 launch)
+// Wc / Wd are sums of the 3x3 taps that land on the same low-res pixel (k_collapse_up_weights).
+__global__ void k_collapse_up_weights(const float* __restrict__ w, float* __restrict__ wc, float* __restrict__ wd, int Cout, int Cin) {
+    long nfwd = 4L * Cout * 4 * Cin, nbwd = (long)Cin * 16 * Cout;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nfwd + nbwd; i += stride) {
+        if (i < nfwd) {          // wc[par][co][a*2+b][ci]
+            int ci = (int)(i % Cin);
+            long r = i / Cin;
+            int ab = (int)(r % 4);
+            r /= 4;
+            int co = (int)(r % Cout);
+            int par = (int)(r / Cout);
+            int py = par >> 1, px = par & 1, a = ab >> 1, b = ab & 1;
+            // rows of the 3x3 kernel that fall on low-res row offset a for parity py: (0,0)->{0} (0,1)->{1,2} (1,0)->{0,1} (1,1)->{2}
+            int ky0 = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+            int kx0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+            float acc = 0.f;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+            wc[i] = acc;
+        } else {                 // wd[ci][r*4+s][co], offsets r-1, s-1 in {-1,0,1,2}: {-1}->{2} {0}->{1,2} {1}->{0,1} {2}->{0}
+            long k = i - nfwd;
+            int co = (int)(k % Cout);
+            long r = k / Cout;
+            int rs = (int)(r % 16);
+            int ci = (int)(r / 16);
+            int rr = rs >> 2, ss = rs & 3;
+            int ky0 = rr == 0 ? 2 : (rr == 1 ? 1 : 0), ky1 = rr == 0 ? 2 : (rr == 1 ? 2 : (rr == 2 ? 1 : 0));
+            int kx0 = ss == 0 ? 2 : (ss == 1 ? 1 : 0), kx1 = ss == 0 ? 2 : (ss == 1 ? 2 : (ss == 2 ? 1 : 0));
+            float acc = 0.f;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+            wd[k] = acc;
+        }
     }
-    if (Cout > 32) {
-        if (k32) return launch_fwd<128, 64, 64, 32, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
-        return launch_fwd<128, 64, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+}
+
+bool conv_up2_ok(int Cin, int Cout, long Plow) {
+    return (Cin % 4 == 0) && Cin >= 8 && Cout >= 8 && fits_u32(4 * Plow, Cin, Cout);
+}
+size_t conv_up2_ws_floats(int Cin, int Cout) { return (size_t)32 * Cout * Cin; }
+
+// ws: [4][Cout][4][Cin] forward weights then [Cin][16][Cout] dgrad weights
+int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st) {
+    long n = 32L * Cout * Cin;
+    k_collapse_up_weights<<<stream_grid(n, 256), 256, 0, st>>>(w, ws, ws + 16L * Cout * Cin, Cout, Cin);
+    VQW_LAUNCH_CHECK("collapse_up_weights");
+    return VQW_OK;
+}
+int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
+                 hipStream_t st) {
+    ConvIn in{x_low, nullptr, Cin, 0, 0};
+    ConvGeom g{};
+    g.ntaps = 4;
+    g.out_mode = 1;      // parity = blockIdx.y; tap offsets and the weight block are derived from it in the kernel
+    return dispatch_fwd(in, ws, bias, y, N, h, w, Cout, g, relu, st);
+}
+int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st) {
+    ConvIn in{dy, nullptr, Cout, 0, 0};
+    ConvGeom g{};
+    g.ntaps = 16;
+    g.src_mode = 2;
+    for (int rs = 0; rs < 16; ++rs) {
+        g.dy[rs] = (signed char)((rs >> 2) - 1);
+        g.dx[rs] = (signed char)((rs & 3) - 1);
     }
-    if (k32) return launch_fwd<128, 32, 32, 32, 32>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
-    return launch_fwd<256, 32, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    return dispatch_fwd(in, ws + 16L * Cout * Cin, nullptr, dx_low, N, h, w, Cin, g, 0, st);
 }
 
 // 0 = auto, 1 = per-tap kernel only, (testing / A-B timing)

@@ -169,7 +169,19 @@ class _Conv2d(torch.autograd.Function):
             raise RuntimeError("conv2d: concat source shape %s does not match %s" % (tuple(x1.shape), (N, c1, H, W)))
         if bias is not None:
             bias = _flat(bias)
-        y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
+        # 3x3 over a nearest x2 up-sampled single source: collapsed onto the low-res grid (4/9 of the FLOPs)
+        up_ws = None
+        if up0 and x1 is None and ks == 3 and dilation == 1 and \
+                _L().vqw_conv3x3_up2_supported(Cin, Cout, N, H // 2, W // 2):
+            L = _L()
+            up_ws = _ws(L.vqw_conv3x3_up2_ws_bytes(Cin, Cout), x0)
+            _lib.check(L.vqw_conv3x3_up2_prepare(_p(w), _p(up_ws), up_ws.numel(), Cin, Cout, _st()), "vqw_conv3x3_up2_prepare")
+            y = empty_nhwc(N, Cout, H, W, x0)
+            _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
+                       "vqw_conv3x3_up2_fwd")
+        else:
+            y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
+        ctx.up_ws = up_ws
         ctx.save_for_backward(x0, x1, w, y if relu else None)
         ctx.cfg = (dilation, up0, ks, N, H, W, Cout, bias is not None)
         # leaf parameters get their gradient written out-of-band on the side stream (see _deferred_wgrad)
@@ -195,7 +207,11 @@ class _Conv2d(torch.autograd.Function):
         Cin = C0 + C1
         g0 = g1 = gw = gb = None
         need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        if need0 or (need1 and x1 is not None):
+        if need0 and ctx.up_ws is not None:
+            g0 = torch.empty_like(x0, memory_format=CL)
+            _lib.check(L.vqw_conv3x3_up2_dgrad(_p(gy), _p(ctx.up_ws), _p(g0), N, H // 2, W // 2, Cin, Cout, _st()),
+                       "vqw_conv3x3_up2_dgrad")
+        elif need0 or (need1 and x1 is not None):
             wt = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
             _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(wt), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
             g_full = empty_nhwc(N, Cin, H, W, gy)
