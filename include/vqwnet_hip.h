@@ -73,6 +73,11 @@ int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const float* bias, f
                         int Cout, int relu, void* stream);
 int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
                           void* stream);
+/* weight (and bias) gradient of the same layer on the low-resolution grid (needs w % 16 == 0) */
+int vqw_conv3x3_up2_wgrad_supported(int Cin, int Cout, int N, int h, int w);
+size_t vqw_conv3x3_up2_wgrad_ws_bytes(int Cin, int Cout, int N, int h, int w);
+int vqw_conv3x3_up2_wgrad(const float* x_low, const float* dy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes,
+                          int N, int h, int w, int Cin, int Cout, int accumulate, void* stream);
 /* Gradient of the virtual input: g_full is [N,H,W,Ctot]; takes channels
  * [c_off, c_off+C).  up=1: dst[N,H/2,W/2,C] = 2x2 block sums; up=0: plain slice copy.
  * accumulate=1 adds into dst.                                                      */

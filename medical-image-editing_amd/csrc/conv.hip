@@ -162,3 +162,19 @@ extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_
     ProfScope ps(0, flops, (hipStream_t)stream);
     return conv_up2_dgrad(dy, (const float*)ws, dx_low, N, h, w, Cin, Cout, (hipStream_t)stream);
 }
+
+extern "C" int vqw_conv3x3_up2_wgrad_supported(int Cin, int Cout, int N, int h, int w) {
+    return g_conv_backend == 0 && conv_up2_wgrad_ok(Cin, Cout, N, h, w) ? 1 : 0;
+}
+extern "C" size_t vqw_conv3x3_up2_wgrad_ws_bytes(int Cin, int Cout, int N, int h, int w) {
+    return conv_up2_wgrad_ws_floats(Cin, Cout, N, h, w) * sizeof(float) + 256;
+}
+extern "C" int vqw_conv3x3_up2_wgrad(const float* x_low, const float* dy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes,
+                                     int N, int h, int w, int Cin, int Cout, int accumulate, void* stream) {
+    VQW_CHECK(x_low && dy && dw_ohwi && ws && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_wgrad: bad arguments");
+    VQW_CHECK(conv_up2_wgrad_ok(Cin, Cout, N, h, w), "vqw_conv3x3_up2_wgrad: unsupported shape (query ..._wgrad_supported)");
+    VQW_CHECK(ws_bytes >= vqw_conv3x3_up2_wgrad_ws_bytes(Cin, Cout, N, h, w), "vqw_conv3x3_up2_wgrad: workspace too small");
+    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
+    ProfScope ps(1, flops, (hipStream_t)stream);
+    return conv_up2_wgrad(x_low, dy, dw_ohwi, dbias, (float*)ws, N, h, w, Cin, Cout, accumulate, (hipStream_t)stream);
+}

@@ -32,6 +32,10 @@ int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t s
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
                  hipStream_t st);
 int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st);
+bool conv_up2_wgrad_ok(int Cin, int Cout, int N, int h, int w);
+size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w);
+int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,
+                   int acc, hipStream_t st);
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc);

@@ -727,6 +727,191 @@ static inline int wg9_split_blocks(int Cin, int Cout, long P) {
     return (int)(nb < 1 ? 1 : nb);
 }
 
+// =============================================================================================
+// wgrad of a 3x3 conv over a nearest x2 up-sampled input, collapsed ("wgup")
+// =============================================================================================
+// dW[ky][kx] = sum over the four output parities (py,px) of G[py][px][a(py,ky)][b(px,kx)] with
+//   G[py][px][a][b] = sum_{y,x} dY[2y+py, 2x+px] (x) X_low[y + py-1+a, x + px-1+b]            (4/9 of the direct MFMA work)
+// One wave = one (32co x 32ci tile, row parity py, split): 8 accumulators G[px][a][b] over chunks of 32 consecutive
+// full-resolution pixels of a row Y = 2y+py.  k-steps pair pixels of EQUAL column parity (X, X+2), so both k slots of
+// an MFMA share the same (px, a, b); the dY tile and two 18-pixel halo segments of X_low sit in the wave's private LDS.
+// Slab layout [split][py][Cout][8][Cin]; k_reduce_wgup folds it into dW (and accumulates if asked).
+__global__ void __launch_bounds__(256, 2)
+k_conv_wgrad_up(const float* __restrict__ xlow, const float* __restrict__ dy, float* __restrict__ part, float* __restrict__ bias_part,
+                int N, int h, int w, int Cin, int Cout, int n_ci_t, int ntiles, int nsplit_blocks, unsigned nbx, unsigned nbd) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * (32 * 32 + 2 * 18 * 32)];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float* Ds = smem + wv * (32 * 32 + 2 * 18 * 32);     // [32 px][32 co]
+    float* Xs = Ds + 32 * 32;                            // [2 rows][18 cols][32 ci]
+    int b = blockIdx.x;
+    const int tile = b % ntiles; b /= ntiles;
+    const int py = b & 1;
+    const int sblk = b >> 1;
+    const int co_base = (tile / n_ci_t) * 32, ci_base = (tile % n_ci_t) * 32;
+    const int split = sblk * 4 + wv, nsplits = nsplit_blocks * 4;
+    const int W2 = 2 * w, H2 = 2 * h;
+    const int cpr = W2 >> 5;                              // chunks per full-res row
+    const int nchunks = N * h * cpr;                      // rows of this parity only
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(xlow, nbx), rsd = make_rsrc(dy, nbd);
+    const int d_c = co_base + (lane & 7) * 4;
+    const bool d_ok = d_c < Cout;
+    const int x_c = ci_base + (lane & 7) * 4;
+    const bool x_cok = x_c < Cin;
+    const int lpx = lane >> 3;
+    const bool do_bias = bias_part != nullptr && ci_base == 0;
+
+    float4 rd[4], rx[5], bsum;
+    bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
+    auto load_chunk = [&](int c) {
+        const int kx = c % cpr;
+        const int q = c / cpr;
+        const int y = q % h, n = q / h;
+        const unsigned pfull = ((unsigned)(n * H2 + 2 * y + py) * W2 + (kx << 5));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned p = pfull + lpx + 8 * i;
+            rd[i] = buf_ld4(rsd, d_ok ? (p * (unsigned)Cout + d_c) * 4u : nbd);
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int ps = lpx + 8 * i;                   // pixel slot in [0, 36): row r, column col of the halo stage
+            const int r = ps >= 18;
+            const int col = ps - 18 * r;
+            const int row = y + py - 1 + r, cx = (kx << 4) - 1 + col;
+            const bool ok = ps < 36 && x_cok && (unsigned)row < (unsigned)h && (unsigned)cx < (unsigned)w;
+            rx[i] = buf_ld4(rsx, ok ? (((unsigned)(n * h + row) * w + cx) * (unsigned)Cin + x_c) * 4u : nbx);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(float4*)&Ds[(lane + 64 * i) * 4] = rd[i];
+            bsum.x += rd[i].x; bsum.y += rd[i].y; bsum.z += rd[i].z; bsum.w += rd[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int f = lane + 64 * i;
+            if (f < 2 * 18 * 8) *(float4*)&Xs[f * 4] = rx[i];
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int lcol = lane & 31, lk = lane >> 5;
+    int c = split;
+    if (c < nchunks) load_chunk(c);
+    for (; c < nchunks; c += nsplits) {
+        store_chunk();
+        if (c + nsplits < nchunks) load_chunk(c + nsplits);
+#pragma unroll 2
+        for (int kk = 0; kk < 8; ++kk) {
+            const int pe = 4 * kk + 2 * lk;               // even-column pixel of this lane half; odd one is pe + 1
+            const int xr = 2 * kk + lk;                   // its low-res column (relative); halo column 0 = xl0 - 1
+            const float ae = Ds[pe * 32 + lcol], ao = Ds[(pe + 1) * 32 + lcol];
+            const float* x0 = Xs + xr * 32 + lcol;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float v0 = x0[(a * 18 + 0) * 32], v1 = x0[(a * 18 + 1) * 32], v2 = x0[(a * 18 + 2) * 32];
+                acc[0 * 4 + a * 2 + 0] = MFMA32(ae, v0, acc[0 * 4 + a * 2 + 0]);   // px=0: columns xr + b
+                acc[0 * 4 + a * 2 + 1] = MFMA32(ae, v1, acc[0 * 4 + a * 2 + 1]);
+                acc[1 * 4 + a * 2 + 0] = MFMA32(ao, v1, acc[1 * 4 + a * 2 + 0]);   // px=1: columns xr + 1 + b
+                acc[1 * 4 + a * 2 + 1] = MFMA32(ao, v2, acc[1 * 4 + a * 2 + 1]);
+            }
+        }
+    }
+
+    if (do_bias) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            bsum.x += __shfl_xor(bsum.x, o, 64); bsum.y += __shfl_xor(bsum.y, o, 64);
+            bsum.z += __shfl_xor(bsum.z, o, 64); bsum.w += __shfl_xor(bsum.w, o, 64);
+        }
+        if (lane < 8 && d_ok) *(float4*)&bias_part[((size_t)split * 2 + py) * Cout + d_c] = bsum;
+    }
+    float* o = part + ((size_t)split * 2 + py) * Cout * 8 * Cin;
+    const int ci = ci_base + (lane & 31);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int co = co_base + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (co < Cout && ci < Cin) o[((size_t)co * 8 + t) * Cin + ci] = acc[t][r];
+        }
+    }
+}
+
+// dW[co][ky][kx][ci] (+)= sum_split sum_{py,px} part[split][py][co][px*4 + a(py,ky)*2 + b(px,kx)][ci]
+__global__ void __launch_bounds__(1024) k_reduce_wgup(const float* __restrict__ part, float* __restrict__ dw, int Cout, int Cin,
+                                                      int nsplits, int acc) {
+    __shared__ float sm[16][64];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long n = (long)Cout * 9 * Cin;
+    const long i = (long)blockIdx.x * 64 + cx;
+    float a = 0.f;
+    if (i < n) {
+        const int ci = (int)(i % Cin);
+        const long r = i / Cin;
+        const int t = (int)(r % 9), co = (int)(r / 9);
+        const int ky = t / 3, kx = t % 3;
+        for (int s = g; s < nsplits; s += 16) {
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int aa = py == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    const int bb = px == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+                    a += part[((((long)s * 2 + py) * Cout + co) * 8 + px * 4 + aa * 2 + bb) * Cin + ci];
+                }
+            }
+        }
+    }
+    sm[g][cx] = a;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][cx];
+        dw[i] = acc ? dw[i] + t : t;
+    }
+}
+
+static inline int wgup_split_blocks(int Cin, int Cout, long Plow) {
+    long tiles = (long)ceil_div(Cout, 32) * ceil_div(Cin, 32) * 2;
+    long nchunks = Plow / 8;                              // N*h*(2w/32) chunks per parity, (2w/32) = w/16
+    long nb = ceil_div(768, tiles);                       // ~3 waves per SIMD over the chip
+    long cap = nchunks / 16 > 1 ? nchunks / 16 : 1;
+    if (nb > cap) nb = cap;
+    return (int)(nb < 1 ? 1 : nb);
+}
+bool conv_up2_wgrad_ok(int Cin, int Cout, int N, int h, int w) {
+    return (w % 16 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && Cin >= 8 && Cout >= 8 && fits_u32(4L * N * h * w, Cin, Cout);
+}
+size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) {
+    return (size_t)wgup_split_blocks(Cin, Cout, (long)N * h * w) * 4 * 2 * ((size_t)Cout * 8 * Cin + Cout);
+}
+int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,
+                   int acc, hipStream_t st) {
+    const long Plow = (long)N * h * w;
+    const int n_ci_t = ceil_div(Cin, 32), ntiles = ceil_div(Cout, 32) * n_ci_t;
+    const int nsb = wgup_split_blocks(Cin, Cout, Plow);
+    const unsigned nbx = (unsigned)(Plow * Cin * 4), nbd = (unsigned)(4 * Plow * Cout * 4);
+    float* bpart = dbias ? ws + (size_t)nsb * 4 * 2 * Cout * 8 * Cin : nullptr;
+    k_conv_wgrad_up<<<ntiles * 2 * nsb, 256, 0, st>>>(xlow, dy, ws, bpart, N, h, w, Cin, Cout, n_ci_t, ntiles, nsb, nbx, nbd);
+    VQW_LAUNCH_CHECK("conv_wgrad_up");
+    if (dbias) {
+        int rc = reduce_rows(bpart, dbias, Cout, nsb * 4 * 2, st, acc);
+        if (rc) return rc;
+    }
+    const long n = (long)Cout * 9 * Cin;
+    k_reduce_wgup<<<(unsigned)((n + 63) / 64), 1024, 0, st>>>(ws, dw, Cout, Cin, nsb * 4, acc);
+    VQW_LAUNCH_CHECK("reduce_wgup");
+    return VQW_OK;
+}
+
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks) {
     (void)ks;
     int Cin = in.C0 + in.C1;

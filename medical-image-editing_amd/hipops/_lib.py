@@ -34,6 +34,9 @@ SIGNATURES = {
     "vqw_conv3x3_up2_prepare": (c_i, [c_p, c_p, c_sz, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_conv3x3_up2_wgrad_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "vqw_conv3x3_up2_wgrad_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "vqw_conv3x3_up2_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_input_grad_gather": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_plane_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "vqw_inorm_fwd": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_i, c_p]),

@@ -105,7 +105,21 @@ def _join_side_stream():
         torch.cuda.current_stream(st.device).wait_stream(st)
 
 
-def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout):
+def _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed):
+    """dW / db on the CURRENT stream; `collapsed` selects the low-resolution form for 3x3-over-upsampled layers."""
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    if collapsed and L.vqw_conv3x3_up2_wgrad_supported(C0, Cout, N, H // 2, W // 2):
+        ws = _ws(L.vqw_conv3x3_up2_wgrad_ws_bytes(C0, Cout, N, H // 2, W // 2), gy)
+        _lib.check(L.vqw_conv3x3_up2_wgrad(_p(x0), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), N, H // 2, W // 2, C0, Cout,
+                                           int(acc), _st()), "vqw_conv3x3_up2_wgrad")
+        return
+    ws = _ws(L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks), gy)
+    _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
+                                  N, H, W, Cout, ks, dilation, int(acc), _st()), "vqw_conv2d_wgrad")
+
+
+def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, collapsed=False):
     """Enqueue dW (and db) on the side stream, writing into weight.grad / bias.grad."""
     global _join_queued
     L = _L()
@@ -127,9 +141,7 @@ def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout):
         gw, gb = weight.grad, (bias.grad if bias is not None else None)
         if gw.stride() != weight.stride():
             raise RuntimeError("conv2d: existing weight.grad layout does not match the parameter layout")
-        ws = _ws(L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks), gy)
-        _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
-                                      N, H, W, Cout, ks, dilation, int(acc), _st()), "vqw_conv2d_wgrad")
+        _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed)
         weight._vqw_pending = getattr(weight, "_vqw_pending", 1) - 1
         if weight._vqw_pending <= 0:
             weight._vqw_pending = 0
@@ -231,14 +243,11 @@ class _Conv2d(torch.autograd.Function):
         if ctx.defer and (needw or (needb and has_bias)):
             weight, bias = ctx.params
             _deferred_wgrad(weight, bias if (has_bias and bias.requires_grad) else None, x0, x1, gy, up0, ks, dilation,
-                            N, H, W, Cout)
+                            N, H, W, Cout, collapsed=ctx.up_ws is not None)
         elif needw or (needb and has_bias):
-            nb = L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks)
-            ws = _ws(nb, gy)
             gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
             gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
-            _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
-                                          N, H, W, Cout, ks, dilation, 0, _st()), "vqw_conv2d_wgrad")
+            _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, False, ctx.up_ws is not None)
         return g0, g1, gw, gb, None, None, None
 
 
