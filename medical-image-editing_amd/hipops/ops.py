@@ -105,6 +105,33 @@ def _join_side_stream():
         torch.cuda.current_stream(st.device).wait_stream(st)
 
 
+# Derived weight layouts (dgrad-packed, tap-collapsed) are cached on the parameter until it changes: both views of a
+# step reuse them.  A parameter "changes" when torch bumps its version counter or when hipops.Adam (which updates
+# through raw pointers) advances the epoch below.
+_weight_epoch = 0
+
+
+def bump_weight_epoch():
+    global _weight_epoch
+    _weight_epoch += 1
+
+
+_CACHE_ON = os.environ.get("VQW_WEIGHT_CACHE", "1") != "0"
+
+
+def _cached(weight, key, build):
+    if not _CACHE_ON:
+        return build()
+    cache = weight.__dict__.setdefault("_vqw_cache", {})
+    tag = (weight._version, _weight_epoch, weight.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    val = build()
+    cache[key] = (tag, val)
+    return val
+
+
 def _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed):
     """dW / db on the CURRENT stream; `collapsed` selects the low-resolution form for 3x3-over-upsampled layers."""
     C0 = x0.shape[1]
@@ -186,8 +213,12 @@ class _Conv2d(torch.autograd.Function):
         if up0 and x1 is None and ks == 3 and dilation == 1 and \
                 _L().vqw_conv3x3_up2_supported(Cin, Cout, N, H // 2, W // 2):
             L = _L()
-            up_ws = _ws(L.vqw_conv3x3_up2_ws_bytes(Cin, Cout), x0)
-            _lib.check(L.vqw_conv3x3_up2_prepare(_p(w), _p(up_ws), up_ws.numel(), Cin, Cout, _st()), "vqw_conv3x3_up2_prepare")
+
+            def _collapse():
+                buf = _ws(L.vqw_conv3x3_up2_ws_bytes(Cin, Cout), x0)
+                _lib.check(L.vqw_conv3x3_up2_prepare(_p(w), _p(buf), buf.numel(), Cin, Cout, _st()), "vqw_conv3x3_up2_prepare")
+                return buf
+            up_ws = _cached(weight, "up2", _collapse)
             y = empty_nhwc(N, Cout, H, W, x0)
             _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
                        "vqw_conv3x3_up2_fwd")
@@ -224,8 +255,11 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(L.vqw_conv3x3_up2_dgrad(_p(gy), _p(ctx.up_ws), _p(g0), N, H // 2, W // 2, Cin, Cout, _st()),
                        "vqw_conv3x3_up2_dgrad")
         elif need0 or (need1 and x1 is not None):
-            wt = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
-            _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(wt), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
+            def _pack():
+                buf = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
+                _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
+                return buf
+            wt = _cached(w, "dgrad", _pack)
             g_full = empty_nhwc(N, Cin, H, W, gy)
             _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
                        "vqw_conv2d_fwd(dgrad)")

@@ -9,6 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import ops as _ops
 
 
 class Adam(torch.optim.Optimizer):
@@ -50,4 +51,5 @@ class Adam(torch.optim.Optimizer):
                                            ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()), p.numel(),
                                            group["lr"], b1, b2, group["eps"], group["weight_decay"],
                                            1.0 - b1 ** t, 1.0 - b2 ** t, st), "vqw_adam_step")
+        _ops.bump_weight_epoch()      # parameters changed through raw pointers: invalidate derived weight layouts
         return loss

@@ -50,6 +50,8 @@ CONV_CASES = [
     (2, 32, 32, 32, 16, True, 16, 3, 1, True, False),
     (1, 32, 64, 64, 0, True, 32, 3, 1, True, False),
     (2, 32, 32, 96, 0, False, 80, 3, 2, True, False),
+    (2, 32, 32, 128, 0, True, 64, 3, 1, True, False),     # collapsed up-conv incl. its low-res wgrad (w_low = 16)
+    (1, 64, 32, 32, 0, True, 48, 3, 1, False, True),
 ]
 
 
