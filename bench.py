@@ -126,9 +126,15 @@ def main():
     tr = FirstStepTrainer(device=dev, data_parallel=world > 1)
     pool = [synthetic_batch(args.batch, args.size, 1234 + 1000 * rank + s, dev) for s in range(4)]
 
+    # the dependency chain of the step runs on a high-priority stream, the off-chain weight gradients on the (normal
+    # priority) side stream of hipops: the hardware dispatches chain kernels first and fills the gaps with wgrad
+    prio = os.environ.get("VQW_BENCH_PRIORITY", "1") != "0"
+    chain = torch.cuda.Stream(device=dev, priority=-1) if prio else torch.cuda.current_stream()
+
     def step(i):
         img, noise = pool[i % len(pool)]
-        return tr.training_step({"image": img}, noise=noise)
+        with torch.cuda.stream(chain):
+            return tr.training_step({"image": img}, noise=noise)
 
     for i in range(args.warmup):
         step(i)
@@ -152,9 +158,24 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         print("[bench] %d timed steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3), file=sys.stderr, flush=True)
-    prof = (ctypes.c_double * 12)()
+    prof = (ctypes.c_double * 16)()
     if timing:
         _lib.check(L.vqw_profile_end(prof), "vqw_profile_end")
+    # Second, untimed look at the same kernels WITHOUT concurrency: in the timed region the weight-gradient kernels run
+    # on a side stream next to the chain kernels, which stretches every kernel's own duration.  Two extra steps with
+    # the side stream off give the kernels' exclusive durations (reported as roofline.exclusive).
+    prof_x = (ctypes.c_double * 16)()
+    from hipops import ops as _ops
+    if timing and _ops.WGRAD_ASYNC:
+        _ops.WGRAD_ASYNC = False
+        step(0)
+        torch.cuda.synchronize()
+        _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
+        for i in range(2):
+            step(1 + i)
+        torch.cuda.synchronize()
+        _lib.check(L.vqw_profile_end(prof_x), "vqw_profile_end")
+        _ops.WGRAD_ASYNC = True
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -168,18 +189,35 @@ def main():
         fam = ["conv_mfma_fwd_dgrad", "conv_mfma_wgrad", "conv_generic_fwd", "conv_generic_wgrad"]
         kern = {}
         for f, name in enumerate(fam):
-            n, ms, fl = prof[3 * f], prof[3 * f + 1], prof[3 * f + 2]
+            n, ms, fl, by = prof[4 * f], prof[4 * f + 1], prof[4 * f + 2], prof[4 * f + 3]
             if n > 0:
                 kern[name] = dict(launches_per_step=n / args.steps, ms_per_step=ms / args.steps,
-                                  tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+                                  tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                                  gflop_per_launch=fl / n / 1e9, bytes_per_launch=by / n)
         roofline = None
         if kern:
             dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
             ach = kern[dom]["tflops"]
+            # HBM bytes per launch of that family from the committed PMC passes of this same command
+            # (profiles/r01_hbm_traffic.json, produced by tools/pmc_traffic.py); null when the file is absent
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+                traffic = tj["families"][dom]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s",
-                            frac=ach / (PEAK_FP32_MFMA / 1e12), traffic=None,
+                            frac=ach / (PEAK_FP32_MFMA / 1e12), traffic=traffic,
+                            algorithmic_bytes_per_launch=kern[dom].get("bytes_per_launch"),
                             avg_launch_ms=kern[dom]["ms_per_step"] / kern[dom]["launches_per_step"],
                             kernels=kern)
+            f = fam.index(dom)
+            if prof_x[4 * f] > 0:
+                ax = prof_x[4 * f + 2] / (prof_x[4 * f + 1] * 1e-3) / 1e12
+                roofline["exclusive"] = dict(
+                    achieved=ax, frac=ax / (PEAK_FP32_MFMA / 1e12), avg_launch_ms=prof_x[4 * f + 1] / prof_x[4 * f],
+                    note="same kernel family over 2 extra steps with the weight-gradient side stream disabled "
+                         "(no concurrent kernels); the timed region overlaps wgrad with the chain kernels")
         per_gpu = imgs / world
         scale = (args.size / 256.0) ** 2
         line = {

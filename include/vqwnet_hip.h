@@ -36,8 +36,8 @@ int vqw_abi_version(void);
 /* 0 = auto (MFMA kernels when shapes allow), 1 = force the generic VALU kernels. */
 int vqw_set_conv_backend(int mode);
 /* Measurement aid (bench.py roofline): HIP events recorded on the launch stream around every convolution kernel
- * family between begin and end.  end() synchronises on those events and fills out[4][3] =
- * {launches, total ms, total algorithmic FLOPs} for {MFMA fwd/dgrad, MFMA wgrad, generic fwd, generic wgrad}.
+ * family between begin and end.  end() synchronises on those events and fills out[4][4] =
+ * {launches, total ms, total algorithmic FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA wgrad, generic fwd, generic wgrad}.
  * Not meant for graph capture; off by default.                                                              */
 int vqw_profile_begin(void);
 int vqw_profile_end(double* out);

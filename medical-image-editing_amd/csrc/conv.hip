@@ -16,6 +16,7 @@ static bool g_prof_on = false;
 static int g_prof_n = 0;
 static hipEvent_t* g_prof_ev = nullptr;   // 2 * PROF_MAX events
 static double g_prof_flops[PROF_MAX];
+static double g_prof_bytes[PROF_MAX];
 static int g_prof_family[PROF_MAX];
 
 extern "C" int vqw_profile_begin(void) {
@@ -28,11 +29,12 @@ extern "C" int vqw_profile_begin(void) {
     g_prof_on = true;
     return VQW_OK;
 }
-// out[f] = {launches, total ms, total algorithmic flops} per family.  Synchronises on the recorded events.
-extern "C" int vqw_profile_end(double* out /*[PROF_FAMILIES][3]*/) {
+// out[f] = {launches, total ms, total algorithmic flops, total algorithmic bytes} per family.  Synchronises on the
+// recorded events.
+extern "C" int vqw_profile_end(double* out /*[PROF_FAMILIES][4]*/) {
     g_prof_on = false;
     if (!out) return VQW_OK;
-    for (int i = 0; i < PROF_FAMILIES * 3; ++i) out[i] = 0.0;
+    for (int i = 0; i < PROF_FAMILIES * 4; ++i) out[i] = 0.0;
     for (int i = 0; i < g_prof_n; ++i) {
         float ms = 0.f;
         if (hipEventSynchronize(g_prof_ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]) != hipSuccess) {
@@ -40,20 +42,22 @@ extern "C" int vqw_profile_end(double* out /*[PROF_FAMILIES][3]*/) {
             return VQW_ERR_HIP;
         }
         int f = g_prof_family[i];
-        out[3 * f] += 1.0;
-        out[3 * f + 1] += (double)ms;
-        out[3 * f + 2] += g_prof_flops[i];
+        out[4 * f] += 1.0;
+        out[4 * f + 1] += (double)ms;
+        out[4 * f + 2] += g_prof_flops[i];
+        out[4 * f + 3] += g_prof_bytes[i];
     }
     return VQW_OK;
 }
 struct ProfScope {
     int idx;
     hipStream_t st;
-    ProfScope(int family, double flops, hipStream_t s) : idx(-1), st(s) {
+    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : idx(-1), st(s) {
         if (g_prof_on && g_prof_n < PROF_MAX) {
             idx = g_prof_n++;
             g_prof_family[idx] = family;
             g_prof_flops[idx] = flops;
+            g_prof_bytes[idx] = bytes;
             (void)hipEventRecord(g_prof_ev[2 * idx], st);
         }
     }
@@ -88,11 +92,13 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
     ConvIn in{src0, src1, C0, C1, up0};
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
+    const double px = (double)N * H * W;
+    const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
     if (g_conv_backend == 0 && conv_mfma_fwd_ok(in, Cout, ksize)) {
-        ProfScope ps(0, flops, st);
+        ProfScope ps(0, flops, st, bytes);
         return conv_mfma_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
     }
-    ProfScope ps(2, flops, st);
+    ProfScope ps(2, flops, st, bytes);
     return conv_direct_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
 }
 
@@ -117,8 +123,10 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)ws;
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
+    const double px = (double)N * H * W;
+    const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
     if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
-        ProfScope ps(1, flops, st);
+        ProfScope ps(1, flops, st, bytes);
         int bias_done = 0;
         rc = conv_mfma_wgrad(in, dy, dw_ohwi, dbias, &bias_done, wsf + bias_grad_ws_floats(Cout), N, H, W, Cout, ksize, dil, st,
                              accumulate);
@@ -131,7 +139,7 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
         if (rc) return rc;
         wsf += bias_grad_ws_floats(Cout);
     }
-    ProfScope ps(3, flops, st);
+    ProfScope ps(3, flops, st, bytes);
     return conv_direct_wgrad(in, dy, dw_ohwi, wsf, N, H, W, Cout, ksize, dil, st, accumulate);
 }
 
@@ -151,7 +159,8 @@ extern "C" int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const flo
     VQW_CHECK(x_low && ws && y && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_fwd: bad arguments");
     VQW_CHECK(conv_up2_ok(Cin, Cout, (long)N * h * w), "vqw_conv3x3_up2_fwd: unsupported shape (query vqw_conv3x3_up2_supported)");
     const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;       // 4 parities x 4 taps on the low-res grid
-    ProfScope ps(0, flops, (hipStream_t)stream);
+    const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
+    ProfScope ps(0, flops, (hipStream_t)stream, bytes);
     return conv_up2_fwd(x_low, (const float*)ws, bias, y, N, h, w, Cin, Cout, relu, (hipStream_t)stream);
 }
 extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
@@ -159,7 +168,8 @@ extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_
     VQW_CHECK(dy && ws && dx_low && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_dgrad: bad arguments");
     VQW_CHECK(conv_up2_ok(Cout, Cin, (long)N * h * w), "vqw_conv3x3_up2_dgrad: unsupported shape");
     const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
-    ProfScope ps(0, flops, (hipStream_t)stream);
+    const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
+    ProfScope ps(0, flops, (hipStream_t)stream, bytes);
     return conv_up2_dgrad(dy, (const float*)ws, dx_low, N, h, w, Cin, Cout, (hipStream_t)stream);
 }
 
@@ -175,6 +185,7 @@ extern "C" int vqw_conv3x3_up2_wgrad(const float* x_low, const float* dy, float*
     VQW_CHECK(conv_up2_wgrad_ok(Cin, Cout, N, h, w), "vqw_conv3x3_up2_wgrad: unsupported shape (query ..._wgrad_supported)");
     VQW_CHECK(ws_bytes >= vqw_conv3x3_up2_wgrad_ws_bytes(Cin, Cout, N, h, w), "vqw_conv3x3_up2_wgrad: workspace too small");
     const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
-    ProfScope ps(1, flops, (hipStream_t)stream);
+    const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 9.0 * Cout * Cin);
+    ProfScope ps(1, flops, (hipStream_t)stream, bytes);
     return conv_up2_wgrad(x_low, dy, dw_ohwi, dbias, (float*)ws, N, h, w, Cin, Cout, accumulate, (hipStream_t)stream);
 }

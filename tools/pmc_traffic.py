@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Fold two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into per-kernel HBM
+bytes per launch.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: both counters are in KiB, and on gfx950
+FETCH_SIZE counts exactly half of the bytes of wide coalesced reads, so reads = 2 * FETCH_SIZE * 1024.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_hbm_traffic.json
+"""
+import collections, csv, glob, json, sys
+
+FAMILIES = {"conv_mfma_fwd_dgrad": ("k_conv_mfma_fwd",), "conv_mfma_wgrad": ("k_conv_wgrad9", "k_conv_wgrad_up", "k_conv_mfma_wgrad"),
+            "conv_generic_fwd": ("k_conv_direct_fwd",), "conv_generic_wgrad": ("k_conv_direct_wgrad",)}
+
+
+def load(d, name):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                agg[k][0] += 1
+                agg[k][1] += float(r["Counter_Value"])
+    return agg
+
+
+def main(fetch_dir, write_dir, out):
+    F, Wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in F:
+        n = F[k][0]
+        rd = 2.0 * F[k][1] * 1024 / n
+        wr = Wr[k][1] * 1024 / max(Wr[k][0], 1) if k in Wr else 0.0
+        kernels[k] = dict(launches=n, read_bytes_per_launch=rd, write_bytes_per_launch=wr, hbm_bytes_per_launch=rd + wr)
+    fam = {}
+    for name, pats in FAMILIES.items():
+        sel = [v for k, v in kernels.items() if any(k.startswith(p) for p in pats)]
+        n = sum(v["launches"] for v in sel)
+        if n:
+            fam[name] = dict(launches=n, hbm_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n)
+    json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1`",
+                   correction="reads = 2*FETCH_SIZE*1024 (gfx950 half-count), writes = WRITE_SIZE*1024",
+                   families=fam, kernels=kernels), open(out, "w"), indent=1, sort_keys=True)
+    for k, v in fam.items():
+        print("%-24s %6d launches  %8.1f MB / launch" % (k, v["launches"], v["hbm_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
