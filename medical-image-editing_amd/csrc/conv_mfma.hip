@@ -66,7 +66,7 @@ struct ConvGeom {
 // =============================================================================================
 // Index arithmetic is 32-bit (the host checks numel < 2^31) and hoisted: pixel coordinates once per thread,
 // bounds / base offsets once per TAP, only an add per channel chunk.
-template <int BM, int BN, int WM, int WN, int KC>
+template <int BM, int BN, int WM, int WN, int KC, bool DEEP>
 __global__ void __launch_bounds__(256, 2)
 k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int N, int H,
                 int W, int Cout, ConvGeom geo, int ntn, int relu, unsigned nb0, unsigned nb1, unsigned nbw) {
@@ -155,8 +155,10 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
             t_off1[j] = ok ? (pix * (unsigned)C1 + a_c) * 4u : nb1;
         }
     };
-    float4 ra[LA], rb[LB];
-    auto load_chunk = [&]() {     // loads chunk (l_t, l_cc) into registers, then advances the loader state
+    // Two register sets: a chunk's global loads are issued two iterations before they are written to LDS, so HBM/L2
+    // latency is covered by two chunk-times of MFMA work (the LDS itself stays double-buffered).
+    float4 ra0[LA], rb0[LB], ra1[LA], rb1[LB];
+    auto load_chunk = [&](float4 (&ra)[LA], float4 (&rb)[LB]) {   // loads chunk (l_t, l_cc), then advances the loader state
         // a chunk never straddles the two sources (C0 % KC == 0 is required when C1 > 0), so the choice is uniform;
         // channels beyond Cin (ragged last chunk) fall off the end of the pixel row: masked by the offset below
         const bool tail = (l_cc + a_c) >= Cin;
@@ -182,7 +184,7 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
             if (l_t < taps) setup_tap();
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const float4 (&ra)[LA], const float4 (&rb)[LB]) {
 #pragma unroll
         for (int j = 0; j < LA; ++j) *(float4*)&As[buf][(a_row + j * RSTEP) * LDK + a_c] = ra[j];
 #pragma unroll
@@ -204,13 +206,7 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
     const int lrow = lane & 31, lk = (lane >> 5) * 4;
     const int nchunks = taps * ((Cin + KC - 1) / KC);
 
-    setup_tap();
-    load_chunk();
-    store_chunk(0);
-    __syncthreads();
-    for (int it = 0; it < nchunks; ++it) {
-        const int cur = it & 1;
-        if (it + 1 < nchunks) load_chunk();
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int kg = 0; kg < KC / 8; ++kg) {
             float4 a[TM], b[TN];
@@ -228,8 +224,39 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
                     acc[i][j] = MFMA32(a[i].w, b[j].w, acc[i][j]);
                 }
         }
-        if (it + 1 < nchunks) store_chunk(cur ^ 1);
+    };
+
+    setup_tap();
+    load_chunk(ra0, rb0);
+    store_chunk(0, ra0, rb0);
+    if constexpr (DEEP) {
+        // prologue: chunk 0 -> LDS buffer 0; chunks 1 and 2 in flight in the two register sets
+        if (nchunks > 1) load_chunk(ra0, rb0);
+        if (nchunks > 2) load_chunk(ra1, rb1);
         __syncthreads();
+        // steady state, unrolled by two so the register sets are named statically.  At the top of iteration `it`:
+        //   LDS[it&1] = chunk it, set A = chunk it+1 (issued two iterations ago), set B = chunk it+2.
+        for (int it = 0; it < nchunks; it += 2) {
+            if (it + 1 < nchunks) store_chunk(1, ra0, rb0);
+            if (it + 3 < nchunks) load_chunk(ra0, rb0);
+            compute(0);
+            __syncthreads();
+            if (it + 1 >= nchunks) break;
+            if (it + 2 < nchunks) store_chunk(0, ra1, rb1);
+            if (it + 4 < nchunks) load_chunk(ra1, rb1);
+            compute(1);
+            __syncthreads();
+        }
+    } else {
+        // short K loops (few chunks per tile): one chunk of look-ahead, less prologue and fewer registers
+        __syncthreads();
+        for (int it = 0; it < nchunks; ++it) {
+            const int cur = it & 1;
+            if (it + 1 < nchunks) load_chunk(ra0, rb0);
+            compute(cur);
+            if (it + 1 < nchunks) store_chunk(cur ^ 1, ra0, rb0);
+            __syncthreads();
+        }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
@@ -284,7 +311,7 @@ static ConvGeom plain_geom(int ks, int dil) {
     return g;
 }
 
-template <int BM, int BN, int WM, int WN, int KC>
+template <int BM, int BN, int WM, int WN, int KC, bool DEEP>
 static int launch_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
                       const ConvGeom& geo, int relu, hipStream_t st) {
     long P = (long)N * H * W;
@@ -292,7 +319,7 @@ static int launch_fwd(const ConvIn& in, const float* w, const float* bias, float
     const long src_px = geo.src_mode == 2 ? 4 * P : (in.up0 ? P / 4 : P);
     const unsigned nb0 = (unsigned)(src_px * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
     const unsigned nbw = (unsigned)((long)Cout * geo.ntaps * (in.C0 + in.C1) * 4);
-    k_conv_mfma_fwd<BM, BN, WM, WN, KC><<<dim3(ntm * ntn, geo.out_mode == 1 ? 4 : 1), 256, 0, st>>>(
+    k_conv_mfma_fwd<BM, BN, WM, WN, KC, DEEP><<<dim3(ntm * ntn, geo.out_mode == 1 ? 4 : 1), 256, 0, st>>>(
         in, w, bias, y, N, H, W, Cout, geo, ntn, relu, nb0, nb1, nbw);
     VQW_LAUNCH_CHECK("conv_mfma_fwd");
     return VQW_OK;
@@ -302,16 +329,21 @@ static int dispatch_fwd(const ConvIn& in, const float* w, const float* bias, flo
                         const ConvGeom& geo, int relu, hipStream_t st) {
     const int Cin = in.C0 + in.C1;
     const bool k32 = (Cin % 32 == 0);
-    if (Cout > 64) {
-        if (k32) return launch_fwd<128, 128, 64, 64, 32>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
-        return launch_fwd<128, 128, 64, 64, 16>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    // N tile: the one that pads Cout least, weighted by how well each tile runs (wider tiles reuse A fragments more)
+    auto cost = [&](int bn, double eff) { return (double)ceil_div(Cout, bn) * bn / eff; };
+    const double c128 = cost(128, 1.0), c64 = cost(64, 0.82), c32 = cost(32, 0.70);
+    const bool deep = geo.ntaps * ceil_div(Cin, k32 ? 32 : 16) >= 12;      // enough chunks to amortise the deeper prologue
+    if (c128 <= c64 && c128 <= c32) {
+        if (k32) return launch_fwd<128, 128, 64, 64, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+        return launch_fwd<128, 128, 64, 64, 16, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
     }
-    if (Cout > 32) {
-        if (k32) return launch_fwd<128, 64, 64, 32, 32>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
-        return launch_fwd<128, 64, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    if (c64 <= c32) {
+        if (k32 && deep) return launch_fwd<128, 64, 64, 32, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+        if (k32) return launch_fwd<128, 64, 64, 32, 32, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+        return launch_fwd<128, 64, 64, 32, 16, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
     }
-    if (k32) return launch_fwd<128, 32, 32, 32, 32>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
-    return launch_fwd<256, 32, 64, 32, 16>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    if (k32) return launch_fwd<128, 32, 32, 32, 32, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    return launch_fwd<256, 32, 64, 32, 16, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
 }
 
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
