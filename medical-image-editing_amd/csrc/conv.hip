@@ -94,6 +94,14 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
     const double px = (double)N * H * W;
     const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
+    if (g_conv_backend == 0 && conv_stem_ok(in, Cout, ksize)) {
+        ProfScope ps(2, flops, st, bytes);
+        return conv_stem_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
+    }
+    if (g_conv_backend == 0 && conv_head_ok(in, Cout, ksize)) {
+        ProfScope ps(2, flops, st, bytes);
+        return conv_head_fwd(in, w_ohwi, bias, y, (long)N * H * W, relu, st);
+    }
     if (g_conv_backend == 0 && conv_mfma_fwd_ok(in, Cout, ksize)) {
         ProfScope ps(0, flops, st, bytes);
         return conv_mfma_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
@@ -109,6 +117,8 @@ extern "C" size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W,
     size_t direct = (size_t)conv_direct_wgrad_splits(nout, P) * nout;
     size_t mfma = conv_mfma_wgrad_ws_floats(Cin, Cout, ksize, P);
     size_t f = direct > mfma ? direct : mfma;
+    size_t thin = conv_stem_wgrad_ws_floats(Cout) + conv_head_wgrad_ws_floats(Cin);
+    if (thin > f) f = thin;
     return (f + bias_grad_ws_floats(Cout)) * sizeof(float) + 256;
 }
 
@@ -125,6 +135,14 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
     const double px = (double)N * H * W;
     const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
+    if (g_conv_backend == 0 && conv_stem_ok(in, Cout, ksize) && Cout == 16) {
+        ProfScope ps(3, flops, st, bytes);
+        return conv_stem_wgrad(in, dy, dw_ohwi, dbias, wsf, N, H, W, Cout, ksize, dil, accumulate, st);
+    }
+    if (g_conv_backend == 0 && conv_head_ok(in, Cout, ksize)) {
+        ProfScope ps(3, flops, st, bytes);
+        return conv_head_wgrad(in, dy, dw_ohwi, dbias, wsf, (long)N * H * W, accumulate, st);
+    }
     if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
         ProfScope ps(1, flops, st, bytes);
         int bias_done = 0;

@@ -39,3 +39,15 @@ int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, 
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc);
+
+// thin-channel streams (conv_thin.hip): 1-channel stem, 1-channel 1x1 head
+bool conv_stem_ok(const ConvIn& in, int Cout, int ks);
+int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
+                  int relu, hipStream_t st);
+size_t conv_stem_wgrad_ws_floats(int Cout);
+int conv_stem_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, float* ws, int N, int H, int W, int Cout, int ks,
+                    int dil, int acc, hipStream_t st);
+bool conv_head_ok(const ConvIn& in, int Cout, int ks);
+int conv_head_fwd(const ConvIn& in, const float* w, const float* bias, float* y, long P, int relu, hipStream_t st);
+size_t conv_head_wgrad_ws_floats(int Cin);
+int conv_head_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, float* ws, long P, int acc, hipStream_t st);

@@ -1,0 +1,204 @@
+// Thin-channel convolutions: the 1-channel stem (Cin == 1, k in {1,3}) and the 1-channel head (Cout == 1, 1x1).
+// These are HBM-bound streams, not GEMMs: one thread per pixel, weights in registers/LDS, float4 I/O.
+#include "common.h"
+#include "conv_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// stem forward: y[p][0..Cout) = b + sum_t x[p + shift(t)] * w[co][t]          (Cin == 1, Cout % 4 == 0, Cout <= 64)
+template <int CO>
+__global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                  float* __restrict__ y, int N, int H, int W, int ks, int dil, int relu) {
+    __shared__ float sw[CO * 9 + CO];
+    const int taps = ks * ks, half = ks >> 1;
+    for (int i = threadIdx.x; i < CO * taps; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < CO; i += 256) sw[CO * 9 + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const long P = (long)N * H * W;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        int xw = (int)(p % W);
+        long q = p / W;
+        int yh = (int)(q % H);
+        float v[9];
+        for (int t = 0; t < taps; ++t) {
+            int hy = yh + (t / ks - half) * dil, wx = xw + (t % ks - half) * dil;
+            v[t] = (hy >= 0 && hy < H && wx >= 0 && wx < W) ? x[p + (long)(hy - yh) * W + (wx - xw)] : 0.f;
+        }
+        float4* out = (float4*)(y + p * CO);
+#pragma unroll
+        for (int c4 = 0; c4 < CO / 4; ++c4) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int co = c4 * 4 + k;
+                float a = sw[CO * 9 + co];
+                for (int t = 0; t < taps; ++t) a = fmaf(v[t], sw[co * taps + t], a);
+                r[k] = relu ? fmaxf(a, 0.f) : a;
+            }
+            float4 o;
+            o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+            out[c4] = o;
+        }
+    }
+}
+
+// stem wgrad: dW[co][t] = sum_p dy[p][co] * x[p + shift(t)], db[co] = sum_p dy[p][co].  Thread keeps CO x (taps+1)
+// partial sums over its pixels; block tree-reduces through LDS; per-block partials are summed by reduce_rows.
+template <int CO>
+__global__ void __launch_bounds__(256) k_stem_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                    int N, int H, int W, int ks, int dil) {
+    constexpr int NA = 10;                     // 9 taps + bias
+    __shared__ float sred[4][CO * NA];
+    const int taps = ks * ks, half = ks >> 1;
+    float acc[CO][NA];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int t = 0; t < NA; ++t) acc[c][t] = 0.f;
+    const long P = (long)N * H * W;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        int xw = (int)(p % W);
+        long q = p / W;
+        int yh = (int)(q % H);
+        float v[NA];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int hy = yh + (t / ks - half) * dil, wx = xw + (t % ks - half) * dil;
+            v[t] = (t < taps && hy >= 0 && hy < H && wx >= 0 && wx < W) ? x[p + (long)(hy - yh) * W + (wx - xw)] : 0.f;
+        }
+        v[9] = 1.f;
+        const float4* g = (const float4*)(dy + p * CO);
+#pragma unroll
+        for (int c4 = 0; c4 < CO / 4; ++c4) {
+            float4 d = g[c4];
+            float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int t = 0; t < NA; ++t) acc[c4 * 4 + k][t] = fmaf(dv[k], v[t], acc[c4 * 4 + k][t]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int t = 0; t < NA; ++t) {
+            float s = wave_sum(acc[c][t]);
+            if (lane == 0) sred[wv][c * NA + t] = s;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CO * NA; i += 256)
+        part[(long)blockIdx.x * CO * NA + i] = (sred[0][i] + sred[1][i]) + (sred[2][i] + sred[3][i]);
+}
+// partial rows [nb][CO][10] -> dw [CO][taps] (+ db [CO])
+__global__ void k_stem_wgrad_finalize(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nb, int CO,
+                                      int taps, int acc) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= CO * 10) return;
+    int c = i / 10, t = i % 10;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += part[(long)b * CO * 10 + i];
+    if (t < taps) dw[c * taps + t] = acc ? dw[c * taps + t] + s : s;
+    else if (t == 9 && db) db[c] = acc ? db[c] + s : s;
+}
+
+bool conv_stem_ok(const ConvIn& in, int Cout, int ks) {
+    return in.C0 == 1 && in.C1 == 0 && !in.up0 && (ks == 1 || ks == 3) && (Cout == 16 || Cout == 32 || Cout == 64);
+}
+int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
+                  int relu, hipStream_t st) {
+    int g = stream_grid((long)N * H * W, 256);
+    if (Cout == 16) k_stem_fwd<16><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
+    else if (Cout == 32) k_stem_fwd<32><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
+    else k_stem_fwd<64><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
+    VQW_LAUNCH_CHECK("conv_stem_fwd");
+    return VQW_OK;
+}
+#define STEM_WG_BLOCKS 512
+size_t conv_stem_wgrad_ws_floats(int Cout) { return (size_t)STEM_WG_BLOCKS * Cout * 10; }
+int conv_stem_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, float* ws, int N, int H, int W, int Cout, int ks,
+                    int dil, int acc, hipStream_t st) {
+    int nb = imin(STEM_WG_BLOCKS, imax(1, (int)(((long)N * H * W + 255) / 256)));
+    if (Cout != 16) { vqw_set_error("conv_stem_wgrad: only Cout == 16"); return VQW_ERR_ARG; }
+    k_stem_wgrad<16><<<nb, 256, 0, st>>>(in.src0, dy, ws, N, H, W, ks, dil);
+    k_stem_wgrad_finalize<<<ceil_div(Cout * 10, 256), 256, 0, st>>>(ws, dw, dbias, nb, Cout, ks * ks, acc);
+    VQW_LAUNCH_CHECK("conv_stem_wgrad");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: Cout == 1, 1x1, Cin % 4 == 0 (unet_decoder.py:105 conv1x1).  Also serves its dgrad (Cin == 1 -> Cout, 1x1).
+__global__ void __launch_bounds__(256) k_head_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                  float* __restrict__ y, long P, int Cin, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float swh[];
+    for (int i = threadIdx.x; i < Cin; i += 256) swh[i] = w[i];
+    __syncthreads();
+    const float b = bias ? bias[0] : 0.f;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const float4* xr = (const float4*)(x + p * Cin);
+        float a = b;
+        for (int c4 = 0; c4 < Cin / 4; ++c4) {
+            float4 v = xr[c4];
+            a = fmaf(v.x, swh[4 * c4], a); a = fmaf(v.y, swh[4 * c4 + 1], a);
+            a = fmaf(v.z, swh[4 * c4 + 2], a); a = fmaf(v.w, swh[4 * c4 + 3], a);
+        }
+        y[p] = relu ? fmaxf(a, 0.f) : a;
+    }
+}
+// dw[ci] = sum_p dy[p] * x[p][ci]; db = sum_p dy[p]
+__global__ void __launch_bounds__(256) k_head_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                    long P, int Cin) {
+    // thread = (pixel row group, channel quad): C4 = Cin/4 lanes per pixel
+    __shared__ float sacc[256 * 4 + 256];
+    const int C4 = Cin >> 2;
+    const int tc = threadIdx.x % C4, tr = threadIdx.x / C4, rows = 256 / C4;
+    float4 a;
+    a.x = a.y = a.z = a.w = 0.f;
+    float bs = 0.f;
+    const long per = (P + gridDim.x - 1) / gridDim.x;
+    const long p0 = blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
+    if (tr < rows)
+        for (long p = p0 + tr; p < p1; p += rows) {
+            float g = dy[p];
+            float4 v = ((const float4*)(x + p * Cin))[tc];
+            a.x = fmaf(g, v.x, a.x); a.y = fmaf(g, v.y, a.y); a.z = fmaf(g, v.z, a.z); a.w = fmaf(g, v.w, a.w);
+            if (tc == 0) bs += g;
+        }
+    sacc[threadIdx.x * 4] = a.x; sacc[threadIdx.x * 4 + 1] = a.y; sacc[threadIdx.x * 4 + 2] = a.z; sacc[threadIdx.x * 4 + 3] = a.w;
+    sacc[1024 + threadIdx.x] = bs;
+    __syncthreads();
+    if (tr == 0) {
+        for (int r = 1; r < rows; ++r) {
+            int t = r * C4 + tc;
+            a.x += sacc[t * 4]; a.y += sacc[t * 4 + 1]; a.z += sacc[t * 4 + 2]; a.w += sacc[t * 4 + 3];
+            if (tc == 0) bs += sacc[1024 + t];
+        }
+        float* o = part + (long)blockIdx.x * (Cin + 1);
+        o[tc * 4] = a.x; o[tc * 4 + 1] = a.y; o[tc * 4 + 2] = a.z; o[tc * 4 + 3] = a.w;
+        if (tc == 0) o[Cin] = bs;
+    }
+}
+__global__ void k_head_wgrad_finalize(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nb, int Cin, int acc) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > Cin) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += part[(long)b * (Cin + 1) + i];
+    if (i < Cin) dw[i] = acc ? dw[i] + s : s;
+    else if (db) db[0] = acc ? db[0] + s : s;
+}
+bool conv_head_ok(const ConvIn& in, int Cout, int ks) {
+    return Cout == 1 && ks == 1 && in.C1 == 0 && !in.up0 && (in.C0 % 4 == 0) && in.C0 >= 4 && in.C0 <= 256 && (256 % (in.C0 / 4) == 0);
+}
+int conv_head_fwd(const ConvIn& in, const float* w, const float* bias, float* y, long P, int relu, hipStream_t st) {
+    k_head_fwd<<<stream_grid(P, 256), 256, in.C0 * sizeof(float), st>>>(in.src0, w, bias, y, P, in.C0, relu);
+    VQW_LAUNCH_CHECK("conv_head_fwd");
+    return VQW_OK;
+}
+#define HEAD_WG_BLOCKS 1024
+size_t conv_head_wgrad_ws_floats(int Cin) { return (size_t)HEAD_WG_BLOCKS * (Cin + 1); }
+int conv_head_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, float* ws, long P, int acc, hipStream_t st) {
+    int nb = (int)imin(HEAD_WG_BLOCKS, imax(1, (int)(P / 2048)));
+    k_head_wgrad<<<nb, 256, 0, st>>>(in.src0, dy, ws, P, in.C0);
+    k_head_wgrad_finalize<<<1, 512, 0, st>>>(ws, dw, dbias, nb, in.C0, acc);
+    VQW_LAUNCH_CHECK("conv_head_wgrad");
+    return VQW_OK;
+}
