@@ -129,10 +129,11 @@ struct FInBwd4 {
     const float4* x;
     const float* mr;
     const float4* gy;
-    int C;
+    int C, gcs4, gco4;
     __device__ void operator()(long i4, int n, int c, float* a, float* b) const {
         const float4* m = (const float4*)(mr + 2 * ((long)n * C + c));
-        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[i4];
+        const int C4 = C >> 2;
+        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[(i4 / C4) * gcs4 + gco4 + (i4 % C4)];
         float xh[4] = {(v.x - m0.x) * m0.y, (v.y - m0.z) * m0.w, (v.z - m1.x) * m1.y, (v.w - m1.z) * m1.w};
         float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -217,7 +218,7 @@ __global__ void k_inorm_apply(const float* __restrict__ x, const float* __restri
 // float4 variants for C % 4 == 0 and un-sliced tensors (the common case): 16 B per lane streams
 template <int RELU>
 __global__ void k_inorm_apply4(const float4* __restrict__ x, const float* __restrict__ mr, float4* __restrict__ y, long total4,
-                               int HW, int C4) {
+                               int HW, int C4, int ycs4, int yco4) {
     long stride = (long)gridDim.x * blockDim.x;
     long plane4 = (long)HW * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -228,12 +229,13 @@ __global__ void k_inorm_apply4(const float4* __restrict__ x, const float* __rest
         float4 v = x[i], r;
         r.x = (v.x - m0.x) * m0.y; r.y = (v.y - m0.z) * m0.w; r.z = (v.z - m1.x) * m1.y; r.w = (v.w - m1.z) * m1.w;
         if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
-        y[i] = r;
+        y[(i / C4) * ycs4 + yco4 + (i % C4)] = r;
     }
 }
 template <int RELU>
 __global__ void k_inorm_bwd_apply4(const float4* __restrict__ x, const float* __restrict__ mr, const float4* __restrict__ gy,
-                                   const float* __restrict__ means, float4* __restrict__ gx, long total4, int HW, int C4) {
+                                   const float* __restrict__ means, float4* __restrict__ gx, long total4, int HW, int C4,
+                                   int gcs4, int gco4) {
     long stride = (long)gridDim.x * blockDim.x;
     long plane4 = (long)HW * C4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
@@ -243,7 +245,7 @@ __global__ void k_inorm_bwd_apply4(const float4* __restrict__ x, const float* __
         const float4* m = (const float4*)(mr + k);
         const float4* e = (const float4*)(means + k);
         float4 m0 = m[0], m1 = m[1], e0 = e[0], e1 = e[1];
-        float4 v = x[i], g = gy[i], o;
+        float4 v = x[i], g = gy[(i / C4) * gcs4 + gco4 + (i % C4)], o;
         float xh, gg;
         xh = (v.x - m0.x) * m0.y; gg = (RELU && !(xh > 0.f)) ? 0.f : g.x; o.x = m0.y * (gg - e0.x - xh * e0.y);
         xh = (v.y - m0.z) * m0.w; gg = (RELU && !(xh > 0.f)) ? 0.f : g.y; o.y = m0.w * (gg - e0.z - xh * e0.w);
@@ -270,10 +272,10 @@ extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff
     k_inorm_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>((const double*)ws, mean_rstd, N * C, C, splits,
                                                                  1.0 / (double)HW, eps);
     long total = (long)N * HW * C;
-    if ((C & 3) == 0 && y_cstride == C && y_coff == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
+    if ((C & 3) == 0 && (y_cstride & 3) == 0 && (y_coff & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
         long t4 = total / 4;
-        if (relu) k_inorm_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4);
-        else k_inorm_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4);
+        if (relu) k_inorm_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
+        else k_inorm_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
     } else if (relu) k_inorm_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     else k_inorm_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     VQW_LAUNCH_CHECK("vqw_inorm_fwd");
@@ -341,12 +343,12 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
     double* part = (double*)ws;
     float* means = (float*)((char*)ws + plane_part_bytes(N, C));
     long total = (long)N * HW * C;
-    const bool vec = (C & 3) == 0 && gy_cstride == C && gy_coff == 0 && al16(x) && al16(gy) && al16(mean_rstd);
+    const bool vec = (C & 3) == 0 && (gy_cstride & 3) == 0 && (gy_coff & 3) == 0 && al16(x) && al16(gy) && al16(mean_rstd);
     if (vec && relu) {
-        FInBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gy, C};
+        FInBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gy, C, gy_cstride / 4, gy_coff / 4};
         k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
     } else if (vec) {
-        FInBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gy, C};
+        FInBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gy, C, gy_cstride / 4, gy_coff / 4};
         k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
     } else if (relu) {
         FInBwd<1> f{x, mean_rstd, gy, C, gy_cstride, gy_coff};
@@ -356,11 +358,11 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
     }
     k_plane_sum_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, means, N * C, C, splits, 1.0 / (double)HW);
-    if ((C & 3) == 0 && gy_cstride == C && gy_coff == 0 &&
+    if ((C & 3) == 0 && (gy_cstride & 3) == 0 && (gy_coff & 3) == 0 &&
         ((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)mean_rstd | (uintptr_t)means) & 15) == 0)) {
         long t4 = total / 4;
-        if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4);
-        else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4);
+        if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4, gy_cstride / 4, gy_coff / 4);
+        else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4, gy_cstride / 4, gy_coff / 4);
     } else if (relu) k_inorm_bwd_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
     else k_inorm_bwd_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
     VQW_LAUNCH_CHECK("vqw_inorm_bwd");
