@@ -8,7 +8,8 @@ FETCH_SIZE counts exactly half of the bytes of wide coalesced reads, so reads = 
 import collections, csv, glob, json, sys
 
 FAMILIES = {"conv_mfma_fwd_dgrad": ("k_conv_mfma_fwd",), "conv_mfma_wgrad": ("k_conv_wgrad9", "k_conv_wgrad_up", "k_conv_mfma_wgrad"),
-            "conv_generic_fwd": ("k_conv_direct_fwd",), "conv_generic_wgrad": ("k_conv_direct_wgrad",)}
+            "conv_generic_fwd": ("k_conv_direct_fwd", "k_stem_fwd", "k_head_fwd"),
+            "conv_generic_wgrad": ("k_conv_direct_wgrad", "k_stem_wgrad", "k_head_wgrad")}
 
 
 def load(d, name):
