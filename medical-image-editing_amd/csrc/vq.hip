@@ -6,6 +6,7 @@
 // chain over d ascending; arg-max over k with ties to the LOWEST index.  The K x N score matrix, the N x K
 // one-hot and the D x N x K "embed_sum" GEMM of the reference are never materialised.
 #include "common.h"
+#include "conv_common.h"
 #include "../../include/vqwnet_hip.h"
 
 #define VQ_BLOCK 256
@@ -16,7 +17,18 @@ static inline int vq_blocks(long Npix) { return (int)imin(2048, ceil_div(Npix, V
 static inline bool vq_lds_codebook(int D, int K) { return (long)K * D + K <= VQ_LDS_FLOATS; }
 static inline bool vq_lds_stats(int D, int K) { return (long)K * D + K + (long)K * (D + 1) <= VQ_LDS_FLOATS; }
 
+// ---- large codebooks (BASELINE config 4: K = 1024, D = 256): score GEMM on the matrix cores + wave-per-pixel select
+#define VQ_GEMM_CHUNK 65536L          // pixels per score chunk (the K x N matrix is never held whole)
+static inline bool vq_use_gemm(int D, int K) { return !vq_lds_codebook(D, K) && K >= 64 && (K % 4 == 0) && (D % 4 == 0) && D >= 8; }
+static inline long vq_gemm_chunk(long Npix) { return Npix < VQ_GEMM_CHUNK ? Npix : VQ_GEMM_CHUNK; }
+static inline size_t vq_gemm_ws_bytes(long Npix, int D, int K) {
+    size_t cpart = (((size_t)(Npix + 3) / 4) * sizeof(double) + 255) / 256 * 256;
+    size_t accum = ((size_t)K * (D + 1) + K) * sizeof(float) + 256;
+    return cpart + accum + (size_t)vq_gemm_chunk(Npix) * K * sizeof(float) + 256;
+}
+
 extern "C" size_t vqw_vq_ws_bytes(long Npix, int D, int K) {
+    if (vq_use_gemm(D, K)) return vq_gemm_ws_bytes(Npix, D, K);
     size_t nb = (size_t)vq_blocks(Npix);
     // per-block commit partial (double) + per-block stats partials (float) or ONE global float accumulator
     size_t rows = vq_lds_stats(D, K) ? nb : 1;
@@ -152,6 +164,127 @@ __global__ void k_vq_finalize(const double* __restrict__ commit_part, const floa
     }
 }
 
+__global__ void k_vq_enorm(const float* __restrict__ embed, float* __restrict__ enorm, int D, int K) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    float n2 = 0.f;
+    for (int d = 0; d < D; ++d) { float e = embed[(long)k * D + d]; n2 = fmaf(e, e, n2); }
+    enorm[k] = n2;
+}
+
+// One wave per pixel: final scores ((2*dot - |e|^2) - |x|^2), arg-max with ties to the lowest index, gather, commitment
+// partial, EMA statistics by float atomics into a [counts K | sums K x D] accumulator (contiguous 4*D bytes per code).
+__global__ void __launch_bounds__(256) k_vq_select(const float* __restrict__ scores, const float* __restrict__ x,
+                                                   const float* __restrict__ embed, const float* __restrict__ enorm,
+                                                   int64_t* __restrict__ ids, float* __restrict__ q, double* __restrict__ cpart,
+                                                   float* __restrict__ accum, long p0, long pn, int D, int K, int id_base) {
+    __shared__ float s_c[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long pl = (long)blockIdx.x * 4 + wv;          // pixel inside the chunk
+    float csum = 0.f;
+    if (pl < pn) {
+        const long p = p0 + pl;
+        const float* xr = x + p * D;
+        float x2 = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
+            float4 v = *(const float4*)(xr + d);
+            x2 = fmaf(v.x, v.x, x2); x2 = fmaf(v.y, v.y, x2); x2 = fmaf(v.z, v.z, x2); x2 = fmaf(v.w, v.w, x2);
+        }
+        x2 = wave_sum(x2);
+        const float* sr = scores + pl * K;
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int k = lane * 4; k < K; k += 256) {
+            float4 sv = *(const float4*)(sr + k);
+            float4 en = *(const float4*)(enorm + k);
+            float c0 = (2.f * sv.x - en.x) - x2, c1 = (2.f * sv.y - en.y) - x2, c2 = (2.f * sv.z - en.z) - x2, c3 = (2.f * sv.w - en.w) - x2;
+            if (c0 > best) { best = c0; bi = k; }
+            if (c1 > best) { best = c1; bi = k + 1; }
+            if (c2 > best) { best = c2; bi = k + 2; }
+            if (c3 > best) { best = c3; bi = k + 3; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) ids[p] = (int64_t)(bi + id_base);
+        const float* e = embed + (long)bi * D;
+        float* qr = q + p * D;
+        float c = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
+            float4 ev = *(const float4*)(e + d), xv = *(const float4*)(xr + d);
+            *(float4*)(qr + d) = ev;
+            float a0 = xv.x - ev.x, a1 = xv.y - ev.y, a2 = xv.z - ev.z, a3 = xv.w - ev.w;
+            c = fmaf(a0, a0, c); c = fmaf(a1, a1, c); c = fmaf(a2, a2, c); c = fmaf(a3, a3, c);
+            if (accum) {
+                float* ar = accum + K + (long)bi * D + d;
+                atomicAdd(ar, xv.x); atomicAdd(ar + 1, xv.y); atomicAdd(ar + 2, xv.z); atomicAdd(ar + 3, xv.w);
+            }
+        }
+        if (accum && lane == 0) atomicAdd(accum + bi, 1.f);
+        csum = wave_sum(c);
+    }
+    if (lane == 0) s_c[wv] = csum;
+    __syncthreads();
+    if (threadIdx.x == 0) cpart[p0 / 4 + blockIdx.x] = (double)s_c[0] + (double)s_c[1] + (double)s_c[2] + (double)s_c[3];
+}
+
+// commit = sum(cpart)/numel; stats[k] = counts, stats[K + d*K + k] = sums[k][d]  (the reference's embed_avg layout)
+__global__ void k_vq_gemm_finalize(const double* __restrict__ cpart, long ncp, const float* __restrict__ accum, float* __restrict__ commit,
+                                   double* __restrict__ stats, int D, int K, double inv_numel) {
+    __shared__ double s_red[4];
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0) {
+        double a = 0.0;
+        for (long i = t; i < ncp; i += blockDim.x) a += cpart[i];
+        a = wave_sum_d(a);
+        if ((t & 63) == 0) s_red[t >> 6] = a;
+        __syncthreads();
+        if (t == 0) commit[0] = (float)((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_numel);
+    }
+    if (stats) {
+        const long n = (long)K * (D + 1);
+        for (long i = (long)blockIdx.x * blockDim.x + t; i < n; i += (long)gridDim.x * blockDim.x) {
+            if (i < K) stats[i] = (double)accum[i];
+            else {
+                long r = i - K;
+                int d = (int)(r / K), k = (int)(r % K);
+                stats[i] = (double)accum[K + (long)k * D + d];
+            }
+        }
+    }
+}
+
+static int vq_fwd_gemm(const float* x, const float* embed, int64_t* ids, int id_base, float* q, float* commit, double* stats,
+                       void* ws, long Npix, int D, int K, hipStream_t st) {
+    const size_t cp_bytes = (((size_t)(Npix + 3) / 4) * sizeof(double) + 255) / 256 * 256;
+    double* cpart = (double*)ws;
+    float* accum = (float*)((char*)ws + cp_bytes);                       // [K] counts, [K][D] sums, then [K] code norms
+    float* enorm = accum + (size_t)K * (D + 1);
+    float* scores = (float*)((char*)accum + (((size_t)K * (D + 1) + K) * sizeof(float) + 255) / 256 * 256);
+    if (stats && hipMemsetAsync(accum, 0, (size_t)K * (D + 1) * sizeof(float), st) != hipSuccess) {
+        vqw_set_error("vqw_vq_fwd: memset failed");
+        return VQW_ERR_HIP;
+    }
+    k_vq_enorm<<<ceil_div(K, 256), 256, 0, st>>>(embed, enorm, D, K);
+    const long PC = vq_gemm_chunk(Npix);
+    for (long p0 = 0; p0 < Npix; p0 += PC) {
+        const long pn = Npix - p0 < PC ? Npix - p0 : PC;
+        // scores[p][k] = x_p . e_k  == a 1x1 convolution with Cout = K over the pixel chunk (fp32 MFMA implicit GEMM)
+        ConvIn in{x + p0 * D, nullptr, D, 0, 0};
+        int rc = conv_mfma_fwd(in, embed, nullptr, scores, 1, 1, (int)pn, K, 1, 1, 0, st);
+        if (rc) return rc;
+        k_vq_select<<<(unsigned)((pn + 3) / 4), 256, 0, st>>>(scores, x, embed, enorm, ids, q, cpart, stats ? accum : nullptr, p0, pn, D,
+                                                              K, id_base);
+    }
+    VQW_LAUNCH_CHECK("vqw_vq_fwd(gemm)");
+    k_vq_gemm_finalize<<<stats ? 256 : 1, 256, 0, st>>>(cpart, (Npix + 3) / 4, accum, commit, stats, D, K, 1.0 / ((double)Npix * D));
+    VQW_LAUNCH_CHECK("vqw_vq_gemm_finalize");
+    return VQW_OK;
+}
+
 template <int DT>
 static int launch_vq(const float* x, const float* embed, int64_t* ids, float* q, double* cpart, float* spart, float* sglob,
                      long Npix, int D, int K, int want, int id_base, bool lds_cb, bool lds_st, int nb, size_t lds_bytes,
@@ -168,6 +301,8 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
     VQW_CHECK(ws_bytes >= vqw_vq_ws_bytes(Npix, D, K), "vqw_vq_fwd: workspace too small");
     VQW_CHECK(K <= 8192, "vqw_vq_fwd: dict_size %d exceeds the supported 8192", K);
     hipStream_t st = (hipStream_t)stream;
+    VQW_CHECK((((uintptr_t)x | (uintptr_t)q) & 15) == 0, "vqw_vq_fwd: x and q must be 16-byte aligned");
+    if (vq_use_gemm(D, K)) return vq_fwd_gemm(x, embed, ids, id_base, q, commit, stats, ws, Npix, D, K, st);
     const int nb = vq_blocks(Npix);
     const int KD1 = K * (D + 1);
     double* cpart = (double*)ws;

@@ -253,6 +253,35 @@ def test_vq_golden(golden, tag):
     assert_close(look, g[tag + "/lookup_eval"], 1e-4, "lookup")
 
 
+def test_vq_large_codebook_vs_oracle():
+    """BASELINE config 4 shape class (K = 1024, D = 256): MFMA score GEMM + select path against the CPU oracle."""
+    from oracle import vqwnet_ref as O
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    K, D, B, S = 1024, 256, 1, 48
+    embed = torch.randn(K, D, generator=g)
+    x = (torch.randn(B, D, S, S, generator=g) * 1.1).requires_grad_(True)
+    V = dict(embed=embed.clone(), cluster_size=torch.full((K,), 3.0), embed_avg=(embed * 3.0).t().contiguous())
+    q, commit, ids, gap = O.vq_forward(V, x, True, 0.99)
+    r = torch.randn(B, D, S, S, generator=g)
+    ((q * r).sum() + commit).backward()
+    dx = x.detach().to(DEV).requires_grad_(True)
+    e = embed.to(DEV).clone(); cs = torch.full((K,), 3.0, device=DEV); ea = (embed * 3.0).t().contiguous().to(DEV)
+    dq, dc, dids = ops.vq_quantize(dx, e, cs, ea, True, 0.99, 1e-5)
+    ((dq * r.to(DEV)).sum() + dc).backward()
+    gp = gap.numpy()
+    clear = gp > 1e-4 * (1 + np.abs(gp))
+    assert clear.mean() > 0.98
+    assert np.array_equal(dids.cpu().numpy()[clear], ids.numpy()[clear])
+    assert_close(dc, commit, 1e-5, "commit")
+    assert_close(dx.grad, x.grad, 1e-5, "gx")
+    assert abs(float(cs.sum()) - float(V["cluster_size"].sum())) < 1e-3 * float(V["cluster_size"].sum())
+    same = torch.from_numpy(dids.cpu().numpy() == ids.numpy()).all()
+    if bool(same):
+        assert_close(ea, V["embed_avg"], 2e-5, "embed_avg")
+        assert_close(e, V["embed"], 2e-5, "embed")
+
+
 def test_vq_conservation_and_ties():
     """Properties: sum of counts == N pixels; all-equal scores resolve to the lowest index; ids in range."""
     ops = _ops()
