@@ -534,3 +534,58 @@ def test_extras_golden(golden):
         l.backward()
         assert_close(l, gl["seg/" + name], 1e-5, name)
         assert_close(z.grad, gl["seg/g_" + name], 1e-4, "g_" + name)
+
+
+# --------------------------------------------------------------------------------------------------
+# edge cases
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,S", [(1, 16), (3, 32), (1, 64)])
+def test_edge_sizes_forward_vs_oracle(B, S):
+    """Batch 1 / odd batch and the smallest legal map (16x16: the deepest level is 1x1, InstanceNorm over one pixel
+    gives exactly 0): train-mode forward of encoder + decoder against the oracle."""
+    from oracle import vqwnet_ref as O
+    from networks import UNetEncoder, UNetDecoder
+    torch.manual_seed(9)
+    K = 6
+    enc = UNetEncoder(1, [16, 16, 32, 32, 32], K, 0.9, 'torch', False, 1, True)
+    dec = UNetDecoder(16, 1, [16, 32, 32, 32, 64], use_dropblock=False, dropped_skip_layers=[1], use_pixel_shuffle=False)
+    with torch.no_grad():
+        enc.vq.embed.mul_(0.5)
+        enc.vq.cluster_size.fill_(B * S * S / K)
+        enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
+    PE = {k: v.detach().clone().contiguous() for k, v in enc.state_dict().items()}
+    PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
+    img, _ = O.synthetic_slices(B, S, 21)
+    with torch.no_grad():
+        qr, cr, idr, gap = O.encoder_forward(PE, img, True, 0.9)
+        rr = O.decoder_forward(PD, qr, True, dropped_skip_layers=(1,))
+    enc.to(DEV).train(); dec.to(DEV).train()
+    with torch.no_grad():
+        q, c, ids = enc(img.to(DEV))
+        rec = dec(q)
+    clear = gap.numpy() > 1e-3 * (1 + np.abs(gap.numpy()))
+    assert np.array_equal(ids.cpu().numpy()[clear], idr.numpy()[clear])
+    assert torch.isfinite(rec).all()
+    if np.array_equal(ids.cpu().numpy(), idr.numpy()):
+        assert_close(c, cr, 1e-4, "commit")
+        assert_close(rec, rr, 2e-3, "recon", atol=1e-5)
+
+
+def test_rejects_bad_arguments():
+    """Shape / dtype / layout violations surface as RuntimeError before anything is launched."""
+    ops = _ops()
+    x = torch.randn(1, 16, 8, 8, device=DEV)
+    w = torch.randn(8, 12, 3, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="do not match"):
+        ops.conv2d(x, w)
+    with pytest.raises(RuntimeError, match="fp32"):
+        ops.instance_norm(x.double())
+    from networks.vq import VQ
+    vq = VQ(16, 10, 0.99, 1e-5, "torch").to(DEV)
+    with pytest.raises(RuntimeError, match="square"):
+        vq(torch.randn(1, 16, 8, 4, device=DEV))
+    with pytest.raises(RuntimeError, match="does not match"):
+        ops.conv2d(torch.randn(1, 16, 3, 3, device=DEV), torch.randn(8, 32, 3, 3, device=DEV), up2x=True,
+                   skip=torch.randn(1, 16, 7, 7, device=DEV))
+    with pytest.raises(RuntimeError, match="vqw_maxpool2_fwd"):      # rejected by the C ABI's own argument check
+        ops.maxpool2(torch.randn(1, 16, 1, 8, device=DEV))
