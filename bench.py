@@ -168,6 +168,7 @@ def main():
     from hipops import ops as _ops
     if timing and _ops.WGRAD_ASYNC:
         _ops.WGRAD_ASYNC = False
+        cv, tr.concurrent_views = tr.concurrent_views, False
         step(0)
         torch.cuda.synchronize()
         _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
@@ -176,6 +177,7 @@ def main():
         torch.cuda.synchronize()
         _lib.check(L.vqw_profile_end(prof_x), "vqw_profile_end")
         _ops.WGRAD_ASYNC = True
+        tr.concurrent_views = cv
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,8 +218,9 @@ def main():
                 ax = prof_x[4 * f + 2] / (prof_x[4 * f + 1] * 1e-3) / 1e12
                 roofline["exclusive"] = dict(
                     achieved=ax, frac=ax / (PEAK_FP32_MFMA / 1e12), avg_launch_ms=prof_x[4 * f + 1] / prof_x[4 * f],
-                    note="same kernel family over 2 extra steps with the weight-gradient side stream disabled "
-                         "(no concurrent kernels); the timed region overlaps wgrad with the chain kernels")
+                    note="same kernel family over 2 extra steps with the weight-gradient side stream and the "
+                         "two-view streams disabled (no concurrent kernels); the timed region overlaps the two views' "
+                         "chains and the wgrad stream")
         per_gpu = imgs / world
         scale = (args.size / 256.0) ** 2
         line = {

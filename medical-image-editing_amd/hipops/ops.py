@@ -82,6 +82,20 @@ _join_queued = False
 grad_ready_listeners = []      # callables(param): the param's gradient is final and enqueued on the side stream
 
 
+def _order_begin(token):
+    """In-place updates of a module buffer (BN running stats, VQ codebook) keep host program order even when the two
+    views of a step run on different streams: wait for the event the previous updater left on the buffer."""
+    prev = token.__dict__.get("_vqw_order")
+    cur = torch.cuda.current_stream()
+    if prev is not None and prev[1] != cur:
+        cur.wait_event(prev[0])
+    return cur
+
+
+def _order_end(token, cur):
+    token.__dict__["_vqw_order"] = (cur.record_event(), cur)
+
+
 def reset_pending(params):
     """Forget forward passes that were never back-propagated (call before the forwards of a training step)."""
     for p in params:
@@ -124,11 +138,14 @@ def _cached(weight, key, build):
         return build()
     cache = weight.__dict__.setdefault("_vqw_cache", {})
     tag = (weight._version, _weight_epoch, weight.data_ptr())
+    cur = torch.cuda.current_stream()
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
+        if hit[3] != cur:            # built on another stream (the other view): order this stream after the build
+            cur.wait_event(hit[2])
         return hit[1]
     val = build()
-    cache[key] = (tag, val)
+    cache[key] = (tag, val, cur.record_event(), cur)
     return val
 
 
@@ -385,7 +402,7 @@ def _dist_on():
 
 class _Spade(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt):
         _dev(x, gamma, beta)
         x, gamma, beta = nhwc(x), nhwc(gamma), nhwc(beta)
         N, C, H, W = x.shape
@@ -401,8 +418,12 @@ class _Spade(torch.autograd.Function):
                 # Every rank holds the same per-rank batch (weak scaling), so the count needs no exchange.
                 dist.all_reduce(sums)
                 count *= dist.get_world_size()
+            cur = _order_begin(running_mean)
             _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
                        "vqw_bn_finalize")
+            if nbt is not None:
+                nbt.add_(1)
+            _order_end(running_mean, cur)
         else:
             _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
         y = torch.empty_like(x, memory_format=CL)
@@ -429,12 +450,13 @@ class _Spade(torch.autograd.Function):
             dist.all_reduce(sums)
         _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(sums), count, _p(gx), N * H * W, C,
                                          int(relu), int(training), _st()), "vqw_spade_bwd_apply")
-        return gx, dgamma, dbeta, None, None, None, None, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def spade_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, sync=True):
+def spade_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, sync=True,
+               num_batches_tracked=None):
     return _Spade.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu),
-                        bool(sync))
+                        bool(sync), num_batches_tracked)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -608,6 +630,7 @@ class _VQ(torch.autograd.Function):
         ws = _ws(L.vqw_vq_ws_bytes(npix, D, K), x)
         if not (embed.is_contiguous() and cluster_size.is_contiguous() and embed_avg.is_contiguous()):
             raise RuntimeError("VQ buffers must be contiguous")
+        cur = _order_begin(embed)        # the codebook read AND its EMA update stay in program order across streams
         _lib.check(L.vqw_vq_fwd(_p(x), _p(embed), _p(ids), int(id_base), _p(q), _p(commit), _p(stats), _p(ws), ws.numel(), npix, D, K, _st()),
                    "vqw_vq_fwd")
         if training:
@@ -624,6 +647,7 @@ class _VQ(torch.autograd.Function):
                     raise RuntimeError("unknown VQ dist_mode %r" % dist_mode)
             _lib.check(L.vqw_vq_ema_update(_p(stats), _p(embed), _p(cluster_size), _p(embed_avg), momentum, eps, scale, D, K, _st()),
                        "vqw_vq_ema_update")
+        _order_end(embed, cur)
         ctx.save_for_backward(x, q)
         ctx.mark_non_differentiable(ids)
         return q, commit, ids

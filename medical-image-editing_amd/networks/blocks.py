@@ -117,11 +117,9 @@ class StyledDenorm(nn.Module):
         actv = self.mlp_shared[0](style, relu=True)
         gamma = self.mlp_gamma(actv)
         beta = self.mlp_beta(actv)
-        out = ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
-                             momentum=bn.momentum, eps=bn.eps, relu=relu)
-        if self.training:
-            bn.num_batches_tracked += 1
-        return out
+        return ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
+                              momentum=bn.momentum, eps=bn.eps, relu=relu,
+                              num_batches_tracked=bn.num_batches_tracked if self.training else None)
 
 
 class PixelShuffle(nn.Module):

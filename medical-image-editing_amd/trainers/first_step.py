@@ -40,7 +40,7 @@ class FirstStepTrainer:
     def __init__(self, in_channels=1, enc_filters=(16, 32, 64, 128, 256), dec_filters=(32, 64, 128, 256, 512),
                  dict_size=10, momentum=0.999, margin=0.5, loss_weight=None, lr=1e-4, betas=(0.5, 0.999),
                  weight_decay=0.0, use_pixel_shuffle=False, dropped_skip_layers=(), views=None, device="cuda",
-                 encoder=None, decoder=None, data_parallel=False, use_onehot=False):
+                 encoder=None, decoder=None, data_parallel=False, use_onehot=False, concurrent_views=None):
         self.device = torch.device(device)
         self.encoder = encoder if encoder is not None else UNetEncoder(
             in_channels, list(enc_filters), dict_size, momentum, 'torch', False, 1, True)
@@ -60,6 +60,14 @@ class FirstStepTrainer:
                               weight_decay=weight_decay)
         self.dec_optim = Adam([p for p in self.decoder.parameters() if p.requires_grad], lr=lr, betas=betas,
                               weight_decay=weight_decay)
+        # the two views are independent chains (coupled only through in-order VQ / BN buffer updates, which the ops
+        # order with events): running them on two streams lets HBM-bound kernels of one overlap MFMA-bound kernels of
+        # the other.  VQW_CONCURRENT_VIEWS=0/1 overrides the default.
+        if concurrent_views is None:
+            import os
+            concurrent_views = os.environ.get("VQW_CONCURRENT_VIEWS", "1") != "0"
+        self.concurrent_views = bool(concurrent_views) and self.device.type == "cuda"
+        self._s2 = None
         self.reducer = None
         self._params = list(self.encoder.parameters()) + list(self.decoder.parameters())
         if data_parallel:
@@ -67,8 +75,52 @@ class FirstStepTrainer:
                      [p for p in self.encoder.parameters() if p.requires_grad][::-1]
             self.reducer = GradientAllReducer(params)      # buckets in backward order: decoder tail first
 
+    def _forward_losses_two_streams(self, image, noise):
+        """Same arithmetic as forward_losses; view 1 on the current stream, view 2 on a second stream."""
+        w = self.w
+        s1 = torch.cuda.current_stream()
+        if self._s2 is None:
+            self._s2 = torch.cuda.Stream(device=self.device, priority=-1)
+        s2 = self._s2
+        (noised_1, clear_1), (noised_2, clear_2) = self.views(image, noise)
+        s2.wait_event(s1.record_event())
+        for t in (noised_2, clear_2):
+            t.record_stream(s2)
+        with torch.cuda.stream(s2):
+            feat_2 = self.encoder.feature_extraction(noised_2)
+        embed_1, l_commit_1, ids_1 = self.encoder(noised_1)
+        r_ids_1 = self.views.cross_ids(ids_1)
+        with torch.cuda.stream(s2):
+            embed_2, l_commit_2, ids_2 = self.encoder.vq(feat_2, id_base=1)       # ordered after view 1's update
+            ids_2 = torch.transpose(ids_2, 1, 2)
+            r_ids_2 = self.views.cross_ids(ids_2)
+            ev2 = s2.record_event()
+        s1.wait_event(ev2)
+        for t in (embed_2, r_ids_2, ids_2):
+            t.record_stream(s1)
+        s2.wait_event(s1.record_event())          # r_ids_1 / embed_1 are read on s2 only through autograd; keep order simple
+        codebook = self.encoder.vq.get_codebook()
+        l_cross, l_dist, l_reg = self.embed_loss.forward_labels(embed_1, r_ids_1, embed_2, r_ids_2, codebook)
+        recon_1 = self.decoder(embed_1)
+        l_rec_1 = ops.mse_loss(recon_1, clear_1)
+        with torch.cuda.stream(s2):
+            recon_2 = self.decoder(embed_2)
+            l_rec_2 = ops.mse_loss(recon_2, clear_2)
+            ev2 = s2.record_event()
+        s1.wait_event(ev2)
+        for t in (l_rec_2, l_commit_2, recon_2):
+            t.record_stream(s1)
+        l_total = ops.weighted_sum(
+            [l_commit_1, l_commit_2, l_cross, l_dist, l_reg, l_rec_1, l_rec_2],
+            [w.commit, w.commit, w.cross, w.dist, w.reg, w.recon, w.recon])
+        return dict(total=l_total, commit_1=l_commit_1, commit_2=l_commit_2, cross=l_cross, dist=l_dist, reg=l_reg,
+                    recon_l1=l_rec_1, recon_l2=l_rec_2, ids_1=ids_1, ids_2=ids_2, recon_1=recon_1, recon_2=recon_2,
+                    embed_1=embed_1, embed_2=embed_2)
+
     def forward_losses(self, image, noise=None):
         """Lines 73-137 of the reference step.  `image` is in [-1, 1] (dataloader convention)."""
+        if self.concurrent_views and not self.use_onehot:
+            return self._forward_losses_two_streams(image, noise)
         w = self.w
         (noised_1, clear_1), (noised_2, clear_2) = self.views(image, noise)
         embed_1, l_commit_1, ids_1 = self.encoder(noised_1)
@@ -103,6 +155,8 @@ class FirstStepTrainer:
         if self.reducer is not None:
             self.reducer.prepare()
         out["total"].backward()
+        if self._s2 is not None:
+            torch.cuda.current_stream().wait_stream(self._s2)
         if self.reducer is not None:
             self.reducer.finish()
         self.enc_optim.step()
