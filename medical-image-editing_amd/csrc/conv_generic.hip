@@ -136,7 +136,30 @@ __global__ void __launch_bounds__(1024) k_reduce_rows(const float* __restrict__ 
     }
 }
 
+// few rows (the wide layers have 8..32 slabs): one lane per float4 column walks the rows; same summation order per column
+__global__ void __launch_bounds__(256) k_reduce_rows_few(const float4* __restrict__ part, float4* __restrict__ out, long n4, int rows,
+                                                         int acc) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = part[i];
+        for (int r = 1; r < rows; ++r) {
+            float4 v = part[(long)r * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (acc) {
+            float4 o = out[i];
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        out[i] = a;
+    }
+}
+
 int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st, int acc) {
+    if (rows <= 48 && (n & 3) == 0 && n >= 4096 && ((((uintptr_t)part | (uintptr_t)out) & 15) == 0)) {
+        k_reduce_rows_few<<<stream_grid(n / 4, 256), 256, 0, st>>>((const float4*)part, (float4*)out, n / 4, rows, acc);
+        VQW_LAUNCH_CHECK("reduce_rows_few");
+        return VQW_OK;
+    }
     k_reduce_rows<<<(unsigned)((n + 63) / 64), 1024, 0, st>>>(part, out, n, rows, acc);
     VQW_LAUNCH_CHECK("reduce_rows");
     return VQW_OK;

@@ -80,7 +80,8 @@ class FirstStepTrainer:
         w = self.w
         s1 = torch.cuda.current_stream()
         if self._s2 is None:
-            self._s2 = torch.cuda.Stream(device=self.device, priority=-1)
+            import os
+            self._s2 = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("VQW_S2_PRIORITY", "-1")))
         s2 = self._s2
         (noised_1, clear_1), (noised_2, clear_2) = self.views(image, noise)
         s2.wait_event(s1.record_event())
