@@ -33,7 +33,8 @@ extern "C" {
 
 const char* vqw_last_error(void);
 int vqw_abi_version(void);
-/* 0 = auto (MFMA kernels when shapes allow), 1 = force the generic VALU kernels. */
+/* 0 = auto (MFMA kernels when shapes allow), 1 = force the generic VALU kernels, 2 = MFMA kernels but
+ * never the LDS-resident halo-tile forward (A/B timing, tests).  Returns the previous mode. */
 int vqw_set_conv_backend(int mode);
 /* Measurement aid (bench.py roofline): HIP events recorded on the launch stream around every convolution kernel
  * family between begin and end.  end() synchronises on those events and fills out[4][4] =
@@ -104,15 +105,19 @@ int vqw_bn_finalize(const double* sums /*[C][2]*/, double count, float* mean_rst
                     int C, void* stream);
 int vqw_bn_eval_stats(const float* running_mean, const float* running_var, float* mean_rstd,
                       float eps, int C, void* stream);
+/* gamma / beta (and dgamma / dbeta) are addressed as ptr[pixel * gb_stride + c]: gb_stride = C for two dense
+ * maps, 2C when mlp_gamma and mlp_beta were evaluated as one conv with concatenated output channels
+ * (gamma = gb, beta = gb + C). */
 int vqw_spade_fwd(const float* x, const float* mean_rstd /*[C][2]*/, const float* gamma,
-                  const float* beta, float* y, long P, int C, int relu, void* stream);
+                  const float* beta, int gb_stride, float* y, long P, int C, int relu, void* stream);
 /* backward, phase 1: dgamma, dbeta and per-channel sums [sum dxhat, sum dxhat*xhat] */
 int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
-                         const float* gy, float* dgamma, float* dbeta, double* sums /*[C][2]*/,
-                         void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
+                         const float* gy, float* dgamma, float* dbeta, int gb_stride,
+                         double* sums /*[C][2]*/, void* ws, size_t ws_bytes, int N, int HW, int C,
+                         int relu, void* stream);
 /* phase 2: dx (training: sums/count terms; training=0: dx = dxhat*rstd) */
 int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
-                        const float* gy, const double* sums, double count, float* gx,
+                        int gb_stride, const float* gy, const double* sums, double count, float* gx,
                         long P, int C, int relu, int training, void* stream);
 
 /* ---- element-wise / pooling: blocks.py:29-30,34-36 (add, ReLU, MaxPool2d(2)), 134; unet_decoder.py:107,159-163 */

@@ -66,8 +66,9 @@ struct ProfScope {
     }
 };
 extern "C" int vqw_set_conv_backend(int mode) {
-    int old = g_conv_backend;
-    g_conv_backend = mode;
+    int old = g_conv_backend == 1 ? 1 : (g_halo_mode ? 2 : 0);
+    g_conv_backend = mode == 1 ? 1 : 0;
+    g_halo_mode = mode == 2 ? 1 : 0;
     return old;
 }
 
@@ -104,6 +105,7 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
     }
     if (g_conv_backend == 0 && conv_mfma_fwd_ok(in, Cout, ksize)) {
         ProfScope ps(0, flops, st, bytes);
+        if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, relu, st);
         return conv_mfma_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
     }
     ProfScope ps(2, flops, st, bytes);

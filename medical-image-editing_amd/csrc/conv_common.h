@@ -25,6 +25,11 @@ bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks);
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
                   int relu, hipStream_t st);
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
+// LDS-resident halo tiles for 3x3 layers with a narrow cout tile (conv_halo.hip)
+extern int g_halo_mode;
+bool conv_halo_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
+int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
+                  hipStream_t st);
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
 bool conv_up2_ok(int Cin, int Cout, long Plow);
 size_t conv_up2_ws_floats(int Cin, int Cout);

@@ -1,0 +1,28 @@
+// Device helpers shared by the MFMA convolution kernels (conv_mfma.hip, conv_halo.hip).
+#pragma once
+#include "common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// Bijective XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run
+// of tiles (neighbouring pixel tiles share halo rows and all N tiles of a pixel tile share the A operand in L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7;
+    int xcd = bid & 7, idx = bid >> 3;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// Raw buffer loads: 32-bit byte offsets against a wave-uniform descriptor; an offset >= num_records returns 0 in
+// hardware, which is the conv zero padding / tile masking for free (no exec-mask branches, no 64-bit address math).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned nbytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nbytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    float4 f;     // (index, then convert: __builtin_bit_cast on a vector element mis-reads element 0 with this clang)
+    unsigned a = v[0], b = v[1], c = v[2], d = v[3];
+    f.x = __uint_as_float(a); f.y = __uint_as_float(b); f.z = __uint_as_float(c); f.w = __uint_as_float(d);
+    return f;
+}

@@ -153,9 +153,11 @@ struct FSpadeBwd4 {
     const float4* gy;
     float4* dgamma;
     float4* dbeta;
+    int C4, gbs4;     // channels / 4, gamma-beta pixel stride / 4
     __device__ void operator()(long i4, int, int c, float* a, float* b) const {
         const float4* m = (const float4*)(mr + 2 * c);
-        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[i4], ga = gamma[i4], be = beta[i4];
+        const long j4 = (i4 / C4) * gbs4 + (i4 % C4);
+        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[i4], ga = gamma[j4], be = beta[j4];
         float xh[4] = {(v.x - m0.x) * m0.y, (v.y - m0.z) * m0.w, (v.z - m1.x) * m1.y, (v.w - m1.z) * m1.w};
         float gg[4] = {g.x, g.y, g.z, g.w}, gm[4] = {1.f + ga.x, 1.f + ga.y, 1.f + ga.z, 1.f + ga.w};
         float bb[4] = {be.x, be.y, be.z, be.w}, dg[4], db[4];
@@ -172,8 +174,8 @@ struct FSpadeBwd4 {
         float4 o1, o2;
         o1.x = dg[0]; o1.y = dg[1]; o1.z = dg[2]; o1.w = dg[3];
         o2.x = db[0]; o2.y = db[1]; o2.z = db[2]; o2.w = db[3];
-        dgamma[i4] = o1;
-        dbeta[i4] = o2;
+        dgamma[j4] = o1;
+        dbeta[j4] = o2;
     }
 };
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -453,21 +455,45 @@ extern "C" int vqw_bn_eval_stats(const float* running_mean, const float* running
 
 template <int RELU>
 __global__ void k_spade_fwd(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gamma,
-                            const float* __restrict__ beta, float* __restrict__ y, long total, int C) {
+                            const float* __restrict__ beta, float* __restrict__ y, long total, int C, int gbs) {
     long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int c = (int)(i % C);
+        long j = (i / C) * gbs + c;
         float xh = (x[i] - mr[2 * c]) * mr[2 * c + 1];
-        float v = xh * (1.f + gamma[i]) + beta[i];
+        float v = xh * (1.f + gamma[j]) + beta[j];
         y[i] = RELU ? fmaxf(v, 0.f) : v;
     }
 }
-extern "C" int vqw_spade_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, float* y,
-                             long P, int C, int relu, void* stream) {
-    VQW_CHECK(x && mean_rstd && gamma && beta && y && P > 0 && C > 0, "vqw_spade_fwd: bad arguments");
+template <int RELU>
+__global__ void __launch_bounds__(256) k_spade_fwd4(const float4* __restrict__ x, const float* __restrict__ mr,
+                                                    const float4* __restrict__ gamma, const float4* __restrict__ beta,
+                                                    float4* __restrict__ y, long total4, int C4, int gbs4) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        int c4 = (int)(i % C4);
+        long j = (i / C4) * gbs4 + c4;
+        const float4* m = (const float4*)(mr + 8 * c4);
+        float4 m0 = m[0], m1 = m[1], v = x[i], ga = gamma[j], be = beta[j], o;
+        o.x = (v.x - m0.x) * m0.y * (1.f + ga.x) + be.x;
+        o.y = (v.y - m0.z) * m0.w * (1.f + ga.y) + be.y;
+        o.z = (v.z - m1.x) * m1.y * (1.f + ga.z) + be.z;
+        o.w = (v.w - m1.z) * m1.w * (1.f + ga.w) + be.w;
+        if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        y[i] = o;
+    }
+}
+extern "C" int vqw_spade_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
+                             float* y, long P, int C, int relu, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && y && P > 0 && C > 0 && gb_stride >= C, "vqw_spade_fwd: bad arguments");
     long total = P * C;
-    if (relu) k_spade_fwd<1><<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, mean_rstd, gamma, beta, y, total, C);
-    else k_spade_fwd<0><<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, mean_rstd, gamma, beta, y, total, C);
+    hipStream_t st = (hipStream_t)stream;
+    if ((C & 3) == 0 && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(y) && al16(mean_rstd)) {
+        long t4 = total / 4;
+        if (relu) k_spade_fwd4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4);
+        else k_spade_fwd4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4);
+    } else if (relu) k_spade_fwd<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gamma, beta, y, total, C, gb_stride);
+    else k_spade_fwd<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gamma, beta, y, total, C, gb_stride);
     VQW_LAUNCH_CHECK("vqw_spade_fwd");
     return VQW_OK;
 }
@@ -483,41 +509,43 @@ struct FSpadeBwd {
     const float* gy;
     float* dgamma;
     float* dbeta;
+    int C, gbs;
     __device__ void operator()(long i, int, int c, float& a, float& b) const {
+        const long j = (i / C) * gbs + c;
         float xh = (x[i] - mr[2 * c]) * mr[2 * c + 1];
-        float ga = 1.f + gamma[i];
+        float ga = 1.f + gamma[j];
         float g = gy[i];
         if (RELU) {
-            float out = xh * ga + beta[i];
+            float out = xh * ga + beta[j];
             if (!(out > 0.f)) g = 0.f;
         }
-        dgamma[i] = g * xh;
-        dbeta[i] = g;
+        dgamma[j] = g * xh;
+        dbeta[j] = g;
         float dxh = g * ga;
         a = dxh;
         b = dxh * xh;
     }
 };
 extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
-                                    const float* gy, float* dgamma, float* dbeta, double* sums, void* ws,
+                                    const float* gy, float* dgamma, float* dbeta, int gb_stride, double* sums, void* ws,
                                     size_t ws_bytes, int N, int HW, int C, int relu, void* stream) {
-    VQW_CHECK(x && mean_rstd && gamma && beta && gy && dgamma && dbeta && sums && ws && N > 0 && HW > 0 && C > 0,
-              "vqw_spade_bwd_reduce: bad arguments");
+    VQW_CHECK(x && mean_rstd && gamma && beta && gy && dgamma && dbeta && sums && ws && N > 0 && HW > 0 && C > 0 &&
+                  gb_stride >= C, "vqw_spade_bwd_reduce: bad arguments");
     VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_spade_bwd_reduce: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     int splits = plane_splits(N, HW);
-    const bool vec = (C & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(gy) && al16(dgamma) && al16(dbeta) && al16(mean_rstd);
+    const bool vec = (C & 3) == 0 && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(gy) && al16(dgamma) && al16(dbeta) && al16(mean_rstd);
     if (vec && relu) {
-        FSpadeBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta};
+        FSpadeBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta, C / 4, gb_stride / 4};
         k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     } else if (vec) {
-        FSpadeBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta};
+        FSpadeBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta, C / 4, gb_stride / 4};
         k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     } else if (relu) {
-        FSpadeBwd<1> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta};
+        FSpadeBwd<1> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta, C, gb_stride};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     } else {
-        FSpadeBwd<0> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta};
+        FSpadeBwd<0> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta, C, gb_stride};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     }
     k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
@@ -528,16 +556,17 @@ extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, cons
 template <int RELU, int TRAIN>
 __global__ void k_spade_bwd_apply(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const float* __restrict__ gy, const double* __restrict__ sums,
-                                  double inv_count, float* __restrict__ gx, long total, int C) {
+                                  double inv_count, float* __restrict__ gx, long total, int C, int gbs) {
     long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         int c = (int)(i % C);
+        long j = (i / C) * gbs + c;
         float r = mr[2 * c + 1];
         float xh = (x[i] - mr[2 * c]) * r;
-        float ga = 1.f + gamma[i];
+        float ga = 1.f + gamma[j];
         float g = gy[i];
         if (RELU) {
-            float out = xh * ga + beta[i];
+            float out = xh * ga + beta[j];
             if (!(out > 0.f)) g = 0.f;
         }
         float dxh = g * ga;
@@ -550,19 +579,67 @@ __global__ void k_spade_bwd_apply(const float* __restrict__ x, const float* __re
         }
     }
 }
-extern "C" int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+// float4 form: same per-element arithmetic, four channels per lane
+template <int RELU, int TRAIN>
+__global__ void __launch_bounds__(256) k_spade_bwd_apply4(const float4* __restrict__ x, const float* __restrict__ mr,
+                                                          const float4* __restrict__ gamma, const float4* __restrict__ beta,
+                                                          const float4* __restrict__ gy, const double* __restrict__ sums,
+                                                          double inv_count, float4* __restrict__ gx, long total4, int C4, int gbs4) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        int c4 = (int)(i % C4);
+        long j = (i / C4) * gbs4 + c4;
+        const float4* m = (const float4*)(mr + 8 * c4);
+        float4 m0 = m[0], m1 = m[1], v = x[i], ga4 = gamma[j], g4 = gy[i], be4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (RELU) be4 = beta[j];
+        float mean[4] = {m0.x, m0.z, m1.x, m1.z}, rs[4] = {m0.y, m0.w, m1.y, m1.w};
+        float xv[4] = {v.x, v.y, v.z, v.w}, gav[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        float bev[4] = {be4.x, be4.y, be4.z, be4.w}, o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r = rs[k];
+            float xh = (xv[k] - mean[k]) * r;
+            float ga = 1.f + gav[k];
+            float g = gv[k];
+            if (RELU) {
+                float out = xh * ga + bev[k];
+                if (!(out > 0.f)) g = 0.f;
+            }
+            float dxh = g * ga;
+            if (TRAIN) {
+                float s1 = (float)(sums[2 * (4 * c4 + k)] * inv_count);
+                float s2 = (float)(sums[2 * (4 * c4 + k) + 1] * inv_count);
+                o[k] = r * (dxh - s1 - xh * s2);
+            } else {
+                o[k] = r * dxh;
+            }
+        }
+        gx[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+extern "C" int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
                                    const float* gy, const double* sums, double count, float* gx, long P, int C,
                                    int relu, int training, void* stream) {
-    VQW_CHECK(x && mean_rstd && gamma && beta && gy && gx && P > 0 && C > 0, "vqw_spade_bwd_apply: bad arguments");
+    VQW_CHECK(x && mean_rstd && gamma && beta && gy && gx && P > 0 && C > 0 && gb_stride >= C, "vqw_spade_bwd_apply: bad arguments");
     VQW_CHECK(!training || (sums && count > 0), "vqw_spade_bwd_apply: training needs sums and count");
     long total = P * C;
     hipStream_t st = (hipStream_t)stream;
-    int g = stream_grid(total, 256);
     double ic = training ? 1.0 / count : 0.0;
-    if (relu && training) k_spade_bwd_apply<1, 1><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
-    else if (relu) k_spade_bwd_apply<1, 0><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
-    else if (training) k_spade_bwd_apply<0, 1><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
-    else k_spade_bwd_apply<0, 0><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C);
+    if ((C & 3) == 0 && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(gy) && al16(gx) && al16(mean_rstd)) {
+        long t4 = total / 4;
+        int g = stream_grid(t4, 256), C4 = C / 4, s4 = gb_stride / 4;
+        const float4 *x4 = (const float4*)x, *ga4 = (const float4*)gamma, *be4 = (const float4*)beta, *gy4 = (const float4*)gy;
+        if (relu && training) k_spade_bwd_apply4<1, 1><<<g, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, t4, C4, s4);
+        else if (relu) k_spade_bwd_apply4<1, 0><<<g, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, t4, C4, s4);
+        else if (training) k_spade_bwd_apply4<0, 1><<<g, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, t4, C4, s4);
+        else k_spade_bwd_apply4<0, 0><<<g, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, t4, C4, s4);
+    } else {
+        int g = stream_grid(total, 256);
+        if (relu && training) k_spade_bwd_apply<1, 1><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C, gb_stride);
+        else if (relu) k_spade_bwd_apply<1, 0><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C, gb_stride);
+        else if (training) k_spade_bwd_apply<0, 1><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C, gb_stride);
+        else k_spade_bwd_apply<0, 0><<<g, 256, 0, st>>>(x, mean_rstd, gamma, beta, gy, sums, ic, gx, total, C, gb_stride);
+    }
     VQW_LAUNCH_CHECK("vqw_spade_bwd_apply");
     return VQW_OK;
 }

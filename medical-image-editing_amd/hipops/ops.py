@@ -133,11 +133,12 @@ def bump_weight_epoch():
 _CACHE_ON = os.environ.get("VQW_WEIGHT_CACHE", "1") != "0"
 
 
-def _cached(weight, key, build):
+def _cached(weight, key, build, deps=()):
+    """`deps`: further tensors the derived value is built from (concatenated convs)."""
     if not _CACHE_ON:
         return build()
     cache = weight.__dict__.setdefault("_vqw_cache", {})
-    tag = (weight._version, _weight_epoch, weight.data_ptr())
+    tag = (weight._version, _weight_epoch, weight.data_ptr()) + tuple((d._version, d.data_ptr()) for d in deps)
     cur = torch.cuda.current_stream()
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
@@ -309,6 +310,126 @@ def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False):
 
 
 # ----------------------------------------------------------------------------------------------
+# two 3x3 convs of the same input as ONE conv with concatenated output channels (StyledDenorm's mlp_gamma | mlp_beta):
+# one pass over the input and twice the N-width per tile in forward, one K=2C dgrad whose accumulator sums the two
+# input gradients (no add pass), one wgrad.  The parameters stay the two reference tensors; their .grad are the two
+# halves of one buffer.
+# ----------------------------------------------------------------------------------------------
+def _cat_weights(wa, ba, wb, bb):
+    def _build():
+        Ca, Cin, ks, _ = wa.shape
+        Cb = wb.shape[0]
+        w = torch.empty((Ca + Cb, Cin, ks, ks), dtype=torch.float32, device=wa.device, memory_format=CL)
+        w[:Ca].copy_(wa.detach())
+        w[Ca:].copy_(wb.detach())
+        b = torch.cat([ba.detach().reshape(-1), bb.detach().reshape(-1)])
+        return w, b
+    return _cached(wa, "cat", _build, deps=(wb, ba, bb))
+
+
+def _grad_halves_adjacent(pa, pb, ga, gb_):
+    """True when pa.grad / pb.grad are the two halves of the buffer this module allocated."""
+    buf = pa.__dict__.get("_vqw_gcat")
+    return (buf is not None and ga is not None and gb_ is not None and ga.data_ptr() == buf.data_ptr()
+            and gb_.data_ptr() == buf.data_ptr() + ga.numel() * 4 and ga.numel() + gb_.numel() == buf.numel())
+
+
+def _deferred_wgrad_cat(wa, ba, wb, bb, x0, gy, ks, N, H, W):
+    global _join_queued
+    L = _L()
+    main = torch.cuda.current_stream()
+    side = wgrad_stream(gy.device)
+    ev = main.record_event()
+    Ca, Cin = wa.shape[0], wa.shape[1]
+    Ct = Ca + wb.shape[0]
+    x0.record_stream(side)
+    gy.record_stream(side)
+    with torch.cuda.stream(side):
+        side.wait_event(ev)
+        fresh = wa.grad is None and wb.grad is None and ba.grad is None and bb.grad is None
+        if fresh:
+            gw = torch.empty((Ct, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+            gb_ = torch.empty(Ct, dtype=torch.float32, device=gy.device)
+            wa.grad, wb.grad, ba.grad, bb.grad = gw[:Ca], gw[Ca:], gb_[:Ca], gb_[Ca:]
+            wa._vqw_gcat, ba._vqw_gcat = gw, gb_
+            _run_wgrad(L, x0, None, gy, gw, gb_, False, ks, 1, N, H, W, Ct, False, False)
+        elif _grad_halves_adjacent(wa, wb, wa.grad, wb.grad) and _grad_halves_adjacent(ba, bb, ba.grad, bb.grad):
+            _run_wgrad(L, x0, None, gy, wa._vqw_gcat, ba._vqw_gcat, False, ks, 1, N, H, W, Ct, True, False)
+        else:    # gradients someone else allocated: compute once, then accumulate the halves
+            gw = torch.empty((Ct, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+            gb_ = torch.empty(Ct, dtype=torch.float32, device=gy.device)
+            _run_wgrad(L, x0, None, gy, gw, gb_, False, ks, 1, N, H, W, Ct, False, False)
+            for p, g in ((wa, gw[:Ca]), (wb, gw[Ca:]), (ba, gb_[:Ca]), (bb, gb_[Ca:])):
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+        wa._vqw_pending = getattr(wa, "_vqw_pending", 1) - 1
+        if wa._vqw_pending <= 0:
+            wa._vqw_pending = 0
+            for fn in grad_ready_listeners:
+                for p in (wa, ba, wb, bb):
+                    fn(p)
+    if not _join_queued:
+        _join_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+
+
+class _ConvCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb):
+        _dev(x, wa, ba, wb, bb)
+        x = nhwc(x)
+        Ca, Cin, ks, _ = wa.shape
+        Cb = wb.shape[0]
+        N, _, H, W = x.shape
+        if x.shape[1] != Cin or tuple(wb.shape[1:]) != (Cin, ks, ks):
+            raise RuntimeError("conv2d_cat: shapes %s / %s / %s do not match" % (tuple(x.shape), tuple(wa.shape), tuple(wb.shape)))
+        w, b = _cat_weights(wa, ba, wb, bb)
+        y = _conv_fwd_raw(x, False, None, w, b, N, H, W, Ca + Cb, ks, 1, False)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (ks, N, H, W, Ca, Cb)
+        ctx.params = (wa, ba, wb, bb)
+        ctx.defer = (WGRAD_ASYNC and all(ctx.needs_input_grad[1:5]) and all(p.is_leaf for p in (wa, ba, wb, bb))
+                     and nhwc(wa) is wa and nhwc(wb) is wb and ba.is_contiguous() and bb.is_contiguous())
+        if ctx.defer:
+            wa._vqw_pending = getattr(wa, "_vqw_pending", 0) + 1
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        ks, N, H, W, Ca, Cb = ctx.cfg
+        wa, ba, wb, bb = ctx.params
+        Ct, Cin = Ca + Cb, x.shape[1]
+        L = _L()
+        gy = nhwc(gy)
+        gx = gwa = gba = gwb = gbb = None
+        if ctx.needs_input_grad[0]:
+            def _pack():
+                buf = torch.empty(Cin * ks * ks * Ct, dtype=torch.float32, device=gy.device)
+                _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Ct, Cin, ks, _st()), "vqw_pack_dgrad_weights")
+                return buf
+            wt = _cached(wa, "cat_dgrad", _pack, deps=(wb,))
+            gx = empty_nhwc(N, Cin, H, W, gy)
+            _lib.check(L.vqw_conv2d_fwd(_p(gy), Ct, 0, None, 0, _p(wt), None, _p(gx), N, H, W, Cin, ks, 1, 0, _st()),
+                       "vqw_conv2d_fwd(dgrad)")
+        if ctx.defer:
+            _deferred_wgrad_cat(wa, ba, wb, bb, x, gy, ks, N, H, W)
+        elif any(ctx.needs_input_grad[1:5]):
+            gw = torch.empty((Ct, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+            gb_ = torch.empty(Ct, dtype=torch.float32, device=gy.device)
+            _run_wgrad(L, x, None, gy, gw, gb_, False, ks, 1, N, H, W, Ct, False, False)
+            gwa, gwb, gba, gbb = gw[:Ca], gw[Ca:], gb_[:Ca], gb_[Ca:]
+        return gx, gwa, gba, gwb, gbb
+
+
+def conv2d_cat(x, weight_a, bias_a, weight_b, bias_b):
+    """[conv(x, weight_a, bias_a) | conv(x, weight_b, bias_b)] along channels (3x3 / 1x1, stride 1, 'same')."""
+    return _ConvCat.apply(x, weight_a, bias_a, weight_b, bias_b)
+
+
+# ----------------------------------------------------------------------------------------------
 # InstanceNorm (+ReLU)
 # ----------------------------------------------------------------------------------------------
 class _InstanceNorm(torch.autograd.Function):
@@ -404,8 +525,18 @@ class _Spade(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt):
         _dev(x, gamma, beta)
-        x, gamma, beta = nhwc(x), nhwc(gamma), nhwc(beta)
+        x, gamma = nhwc(x), nhwc(gamma)
         N, C, H, W = x.shape
+        # beta=None: `gamma` holds [gamma | beta] as 2C channels (conv2d_cat)
+        fused = beta is None
+        if fused:
+            if gamma.shape[1] != 2 * C:
+                raise RuntimeError("spade_norm: fused gamma|beta map needs %d channels, got %d" % (2 * C, gamma.shape[1]))
+        else:
+            beta = nhwc(beta)
+        gbs = 2 * C if fused else C
+        gptr = gamma.data_ptr()
+        bptr = gptr + 4 * C if fused else beta.data_ptr()
         L = _L()
         mr = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         count = float(N * H * W)
@@ -427,28 +558,34 @@ class _Spade(torch.autograd.Function):
         else:
             _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
         y = torch.empty_like(x, memory_format=CL)
-        _lib.check(L.vqw_spade_fwd(_p(x), _p(mr), _p(gamma), _p(beta), _p(y), N * H * W, C, int(relu), _st()), "vqw_spade_fwd")
+        _lib.check(L.vqw_spade_fwd(_p(x), _p(mr), gptr, bptr, gbs, _p(y), N * H * W, C, int(relu), _st()), "vqw_spade_fwd")
         ctx.save_for_backward(x, gamma, beta, mr)
-        ctx.cfg = (training, relu, count, sync)
+        ctx.cfg = (training, relu, count, sync, fused)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, gamma, beta, mr = ctx.saved_tensors
-        training, relu, count, sync = ctx.cfg
+        training, relu, count, sync, fused = ctx.cfg
         N, C, H, W = x.shape
         L = _L()
         gy = nhwc(gy)
-        dgamma = torch.empty_like(x, memory_format=CL)
-        dbeta = torch.empty_like(x, memory_format=CL)
+        if fused:
+            dgamma, dbeta, gbs = torch.empty_like(gamma, memory_format=CL), None, 2 * C
+            gptr, dgptr = gamma.data_ptr(), dgamma.data_ptr()
+            bptr, dbptr = gptr + 4 * C, dgptr + 4 * C
+        else:
+            dgamma = torch.empty_like(x, memory_format=CL)
+            dbeta = torch.empty_like(x, memory_format=CL)
+            gbs, gptr, bptr, dgptr, dbptr = C, gamma.data_ptr(), beta.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
         gx = torch.empty_like(x, memory_format=CL)
         sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
         ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
-        _lib.check(L.vqw_spade_bwd_reduce(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(dgamma), _p(dbeta), _p(sums), _p(ws),
+        _lib.check(L.vqw_spade_bwd_reduce(_p(x), _p(mr), gptr, bptr, _p(gy), dgptr, dbptr, gbs, _p(sums), _p(ws),
                                           ws.numel(), N, H * W, C, int(relu), _st()), "vqw_spade_bwd_reduce")
         if training and sync and _dist_on():
             dist.all_reduce(sums)
-        _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(sums), count, _p(gx), N * H * W, C,
+        _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), gptr, bptr, gbs, _p(gy), _p(sums), count, _p(gx), N * H * W, C,
                                          int(relu), int(training), _st()), "vqw_spade_bwd_apply")
         return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
 

@@ -7,6 +7,8 @@ hipops.ops (hand-written HIP through the C ABI) instead of ATen.  nn.Upsample an
 torch.cat are folded into the consuming convolution's loader; ReLU is fused into
 the InstanceNorm / SPADE / conv-epilogue kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -98,6 +100,9 @@ class DoubleConv(nn.Module):
         return x
 
 
+FUSE_GAMMA_BETA = os.environ.get("VQW_FUSE_GAMMA_BETA", "1") != "0"
+
+
 class StyledDenorm(nn.Module):
     """SPADE-style de-normalisation: BatchNorm2d(affine=False)(x) * (1 + gamma(style)) + beta(style)."""
 
@@ -115,8 +120,12 @@ class StyledDenorm(nn.Module):
     def forward(self, x, style, relu=False):
         bn = self.param_free_norm
         actv = self.mlp_shared[0](style, relu=True)
-        gamma = self.mlp_gamma(actv)
-        beta = self.mlp_beta(actv)
+        if FUSE_GAMMA_BETA:     # one conv with [gamma | beta] output channels (reference blocks.py:86-87 evaluated together)
+            gamma = ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias)
+            beta = None
+        else:
+            gamma = self.mlp_gamma(actv)
+            beta = self.mlp_beta(actv)
         return ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
                               momentum=bn.momentum, eps=bn.eps, relu=relu,
                               num_batches_tracked=bn.num_batches_tracked if self.training else None)

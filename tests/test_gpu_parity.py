@@ -52,6 +52,14 @@ CONV_CASES = [
     (2, 32, 32, 96, 0, False, 80, 3, 2, True, False),
     (2, 32, 32, 128, 0, True, 64, 3, 1, True, False),     # collapsed up-conv incl. its low-res wgrad (w_low = 16)
     (1, 64, 32, 32, 0, True, 48, 3, 1, False, True),
+    # LDS-resident halo-tile kernel (3x3, W % 32 == 0, narrow cout tile): every template configuration
+    (2, 32, 32, 32, 0, False, 64, 3, 1, True, True),       # one channel chunk, weights stay in LDS, 64-wide cout tile
+    (1, 20, 64, 64, 0, False, 32, 3, 1, True, False),      # channel chunks streamed, H not a multiple of the tile
+    (2, 16, 32, 64, 0, False, 64, 3, 1, True, False),
+    (1, 16, 32, 160, 0, False, 32, 3, 1, True, False),     # ASPP projection: 10 chunks; its dgrad has 3 cout tiles
+    (2, 16, 32, 16, 0, False, 32, 3, 1, False, False),
+    (3, 12, 32, 48, 0, False, 80, 3, 1, True, False),
+    (1, 16, 64, 16, 0, False, 48, 3, 1, True, True),
 ]
 
 
@@ -66,7 +74,7 @@ def _conv_ref(x0, x1, w, b, up, dil, relu):
     return torch.relu(y) if relu else y
 
 
-@pytest.mark.parametrize("backend", [0, 1])
+@pytest.mark.parametrize("backend", [0, 1, 2])     # auto, generic VALU kernels, implicit-GEMM MFMA without halo tiles
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d(case, backend):
     ops = _ops()
@@ -214,6 +222,39 @@ def test_blocks_golden(golden):
     _run_block(golden, "styled_denorm_eval", B.StyledDenorm(16, 16), 2, train=False)
     _run_block(golden, "styled_res_up", B.StyledResUpBlock(32, 16, 16, use_pixel_shuffle=False), 2)
     _run_block(golden, "aspp", ASPP(16, 16, [2, 6, 12, 18]), 1)
+
+
+def test_styled_denorm_gamma_beta_forms(golden, monkeypatch):
+    """mlp_gamma | mlp_beta as one concatenated conv (default) and as two convs both match the reference fixture;
+    the concatenated form accumulates over two backward passes and into gradients it did not allocate."""
+    from networks import blocks as B
+    monkeypatch.setattr(B, "FUSE_GAMMA_BETA", False)
+    _run_block(golden, "styled_denorm", B.StyledDenorm(16, 32), 2)
+    _run_block(golden, "styled_res_up", B.StyledResUpBlock(32, 16, 16, use_pixel_shuffle=False), 2)
+    monkeypatch.setattr(B, "FUSE_GAMMA_BETA", True)
+    g = golden("blocks.npz")
+    tag = "styled_denorm_eval"      # eval: no running-stat side effects, passes can be repeated
+    sd = {k[2:]: v for k, v in g.group(tag).items() if k.startswith("P.")}
+
+    def run(prealloc):
+        mod = B.StyledDenorm(16, 16)
+        mod.load_state_dict(sd, strict=True)
+        mod.to(DEV).eval()
+        if prealloc:
+            for p in mod.parameters():
+                p.grad = torch.zeros_like(p)
+        ins = [g.t("%s/in.%d" % (tag, i), DEV) for i in range(2)]
+        for _ in range(2):
+            (mod(*ins) * g.t(tag + "/R.0", DEV)).sum().backward()
+        torch.cuda.synchronize()
+        return mod
+    for prealloc in (False, True):
+        mod = run(prealloc)
+        for k, p in mod.named_parameters():
+            assert_close(p.grad, 2.0 * g["%s/gP.%s" % (tag, k)], 1e-3, "%s x2 gP.%s prealloc=%s" % (tag, k, prealloc), atol=4e-5)
+        if not prealloc:
+            ga, gb_ = mod.mlp_gamma.weight.grad, mod.mlp_beta.weight.grad
+            assert gb_.data_ptr() == ga.data_ptr() + 4 * ga.numel()      # halves of one buffer, second pass accumulated in place
 
 
 # --------------------------------------------------------------------------------------------------

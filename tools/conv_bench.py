@@ -49,7 +49,8 @@ def model_convs(size):
         h *= 2
         cin, c = df[i + 1], df[i]
         add(cin, 0, True, c, 3, 1, h, n=2)           # conv, conv1
-        add(c, 0, False, c, 3, 1, h, n=7)            # 2 x (shared, gamma, beta) + conv2
+        add(c, 0, False, c, 3, 1, h, n=3)            # 2 x mlp_shared + conv2
+        add(c, 0, False, 2 * c, 3, 1, h, n=2)        # 2 x [mlp_gamma | mlp_beta] as one conv
     c = df[0]
     add(c, 0, False, c, 1, 1, h)
     for r in (2, 6, 12, 18):
@@ -66,9 +67,11 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--filter", default="", help="substring filter on the shape label")
+    ap.add_argument("--backend", type=int, default=0, help="vqw_set_conv_backend mode (2 = no halo-tile kernel)")
     args = ap.parse_args()
     dev = "cuda"
     L = _lib.load()
+    L.vqw_set_conv_backend(args.backend)
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
     from collections import Counter
