@@ -6,9 +6,9 @@
 // (profiles/r01_sq_counters.txt).  Here a workgroup loads the (TH+2) x 34 pixel halo of a TH x 32 output tile ONCE per
 // channel chunk and all nine taps read it from LDS at shifted addresses, so the L2 -> CU traffic drops ~7x.
 //
-//   * persistent workgroups (one per CU, grid-stride over tiles): the halo of the next (tile, channel chunk) item is
-//     fetched into registers while the matrix cores work on the current one and written to the other LDS buffer
-//     afterwards; one barrier per item.  Every workgroup runs the same trip count formula, every wave reaches the end.
+//   * a workgroup walks several consecutive tiles: the halo of the next (tile, channel chunk) item is fetched into
+//     registers while the matrix cores work on the current one and written to the other LDS buffer afterwards; one
+//     barrier per item.  The trip count is uniform per workgroup, every wave reaches the end.
 //   * weights: [9 taps][BN couts][KC channels] in LDS; when the layer has a single channel chunk they are loaded once
 //     per workgroup and stay (WPERSIST), otherwise they are double-buffered along with the halo.
 //   * LDS rows (one pixel's / one cout's KC channels) are padded by 4 floats: the ds_read_b128 fragment reads of 32
@@ -19,6 +19,13 @@
 #include "common.h"
 #include "conv_common.h"
 #include "mfma_util.h"
+#include <cstdlib>
+
+static int halo_kt_env() {
+    const char* e = getenv("VQW_HALO_KT");
+    return e ? atoi(e) : 0;
+}
+static const int g_halo_kt = halo_kt_env();     // tuning aid: spatial tiles per workgroup (0 = default)
 
 namespace {
 
@@ -32,6 +39,7 @@ struct HaloArgs {
     int N, H, W, Cout;
     int tilesY, tilesX, nsp;   // spatial tiles per image column / row, total
     int ntn, nch;              // cout tiles, channel chunks
+    int kt;                    // consecutive spatial tiles per workgroup
     int relu;
     unsigned nb0, nb1, nbw;
 };
@@ -65,13 +73,17 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.in.src0, a.nb0), rs1 = make_rsrc(a.in.src1, a.nb1),
                                  rsw = make_rsrc(a.w, a.nbw);
 
-    // work split: this workgroup keeps one cout tile and strides over the spatial tiles
+    // work split: a workgroup keeps one cout tile and walks `kt` consecutive spatial tiles.  Tiles are ordered down
+    // a 32-pixel column strip first (consecutive items share 2 of their TH+2 halo rows in L1/L2), and the XCD remap
+    // keeps neighbouring strips and the cout tiles of one strip on one XCD's L2.
     const int ntn = a.ntn, nch = a.nch;
-    const int tile_n = blockIdx.x % ntn;
-    const int sp0 = blockIdx.x / ntn, sp_step = gridDim.x / ntn;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % ntn;
+    const int sp0 = (lb / ntn) * a.kt;
     const int co_base = tile_n * BN;
-    const int my_tiles = sp0 < a.nsp ? (a.nsp - sp0 + sp_step - 1) / sp_step : 0;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
     const int nitems = my_tiles * nch;
+    const int per_img = a.tilesY * a.tilesX;
 
     // loader slots (fixed for the whole kernel)
     int h_lds[LH];
@@ -103,10 +115,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     float4 rh[LH], rw[WPERSIST ? 1 : LW];
     auto issue = [&](int item) {       // global -> registers for item (tile, chunk)
         const int t = item / nch, ch = item - t * nch;
-        int sp = sp0 + t * sp_step;
-        const int tx = sp % a.tilesX; sp /= a.tilesX;
-        const int ty = sp % a.tilesY;
-        const int n = sp / a.tilesY;
+        const int sp = sp0 + t;
+        const int n = sp / per_img, rem = sp - n * per_img;
+        const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
         const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
         const int cc = ch * KC;
         if (cc < C0) {
@@ -144,7 +155,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         }
     };
 
-    if (nitems == 0) return;           // uniform per workgroup
+    if (nitems <= 0) return;           // uniform per workgroup
     if constexpr (WPERSIST) {
 #pragma unroll
         for (int j = 0; j < LW; ++j) {
@@ -200,10 +211,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         }
         if (ch == nch - 1) {
             // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel column)
-            int sp = sp0 + t * sp_step;
-            const int tx = sp % a.tilesX; sp /= a.tilesX;
-            const int ty = sp % a.tilesY;
-            const int n = sp / a.tilesY;
+            const int sp = sp0 + t;
+            const int n = sp / per_img, rem = sp - n * per_img;
+            const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int co = co_base + (wc * TN + j) * 32 + (lane & 31);
@@ -254,11 +264,14 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     a.nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4);
     a.nb1 = (unsigned)(P * in.C1 * 4);
     a.nbw = (unsigned)((long)Cout * 9 * (in.C0 + in.C1) * 4);
-    // one workgroup per CU (the LDS footprint allows no more); a multiple of the cout tiles so each keeps one
-    int per_n = 256 / a.ntn;
-    if (per_n > a.nsp) per_n = a.nsp;
-    if (per_n < 1) per_n = 1;
-    k_conv_halo<NW, TH, BN, KC, WPERSIST><<<per_n * a.ntn, 64 * NW, lds, st>>>(a);
+    // The LDS footprint allows one workgroup per CU: one workgroup per CU, each with an even share of the tiles, so the
+    // prologue (weights + first halo, not overlapped with MFMA work) is paid once.  Shorter runs per workgroup
+    // (VQW_HALO_KT) would let the dispatcher rebalance when other kernels hold CUs; measured 0.5-1 % slower in the step.
+    const int even = ceil_div((long)a.nsp * a.ntn, 256);
+    int kt = g_halo_kt > 0 ? g_halo_kt : even;
+    if (kt > even) kt = even;
+    a.kt = kt < 1 ? 1 : kt;
+    k_conv_halo<NW, TH, BN, KC, WPERSIST><<<ceil_div(a.nsp, a.kt) * a.ntn, 64 * NW, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_halo");
     return VQW_OK;
 }
