@@ -26,7 +26,11 @@ int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
                   int relu, hipStream_t st);
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
 // LDS-resident halo tiles for 3x3 layers with a narrow cout tile (conv_halo.hip)
-extern int g_halo_mode;
+extern int g_halo_mode, g_wgrad_tile_mode;
+bool conv_wgrad_tile_ok(int C0, int C1, int Cout, int ks, int W, int dil);
+int conv_wgrad_tile_blocks(int Cin, int Cout, int N, int H, int W, int max_blocks, int* kt_out);
+int conv_wgrad_tile(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
+                    hipStream_t st);
 bool conv_halo_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
 int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
                   hipStream_t st);

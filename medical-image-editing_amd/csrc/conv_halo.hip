@@ -188,26 +188,33 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         }
         const float* Hc = Hs + cur * HBUF + a_base;
         const float* Wc = Ws + (WPERSIST ? 0 : cur * WBUF) + b_base;
+        // fragment reads run one group (4 k-steps) ahead of the MFMAs that consume them, so a wave's LDS latency hides
+        // behind its own matrix work instead of relying on the partner wave
+        constexpr int KG = KC / 8, NG = 9 * KG;
+        float4 av[2][TM], bv[2][TN];
+        auto ldfrag = [&](int g, int s) {
+            const int tap = g / KG, kg = g % KG, ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
+            for (int i = 0; i < TM; ++i) av[s][i] = *(const float4*)&Hc[((i + ky) * HALO_W + kx) * KP + kg * 8];
 #pragma unroll
-            for (int kg = 0; kg < KC / 8; ++kg) {
-                float4 av[TM], bv[TN];
+            for (int j = 0; j < TN; ++j) bv[s][j] = *(const float4*)&Wc[(tap * BN + j * 32) * KP + kg * 8];
+        };
+        ldfrag(0, 0);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = *(const float4*)&Hc[((i + ky) * HALO_W + kx) * KP + kg * 8];
+        for (int g = 0; g < NG; ++g) {
+            const int s = g & 1;
+            if (g + 1 < NG) ldfrag(g + 1, s ^ 1);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = *(const float4*)&Wc[(tap * BN + j * 32) * KP + kg * 8];
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = MFMA32(av[i].x, bv[j].x, acc[i][j]);
-                        acc[i][j] = MFMA32(av[i].y, bv[j].y, acc[i][j]);
-                        acc[i][j] = MFMA32(av[i].z, bv[j].z, acc[i][j]);
-                        acc[i][j] = MFMA32(av[i].w, bv[j].w, acc[i][j]);
-                    }
-            }
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = MFMA32(av[s][i].x, bv[s][j].x, acc[i][j]);
+                    acc[i][j] = MFMA32(av[s][i].y, bv[s][j].y, acc[i][j]);
+                    acc[i][j] = MFMA32(av[s][i].z, bv[s][j].z, acc[i][j]);
+                    acc[i][j] = MFMA32(av[s][i].w, bv[s][j].w, acc[i][j]);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);          // next group's LDS reads first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... then this group's MFMAs
         }
         if (ch == nch - 1) {
             // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel column)
@@ -267,7 +274,9 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     // The LDS footprint allows one workgroup per CU: one workgroup per CU, each with an even share of the tiles, so the
     // prologue (weights + first halo, not overlapped with MFMA work) is paid once.  Shorter runs per workgroup
     // (VQW_HALO_KT) would let the dispatcher rebalance when other kernels hold CUs; measured 0.5-1 % slower in the step.
-    const int even = ceil_div((long)a.nsp * a.ntn, 256);
+    int groups = 256 / a.ntn;          // spatial groups: groups * ntn workgroups <= 256, never a second partial round
+    if (groups < 1) groups = 1;
+    const int even = ceil_div(a.nsp, groups);
     int kt = g_halo_kt > 0 ? g_halo_kt : even;
     if (kt > even) kt = even;
     a.kt = kt < 1 ? 1 : kt;
@@ -304,4 +313,232 @@ int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
     }
     if (wide) return launch_halo<8, 8, 64, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
     return launch_halo<8, 8, 32, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
+}
+
+// =============================================================================================
+// wgrad of a 3x3 stride-1 conv from block-shared tiles (k_conv_wgrad_tile)
+// =============================================================================================
+// dW[co][ky][kx][ci] = sum_p dY[p][co] * X[p + (ky-1, kx-1)][ci].  GEMM view per (32 co x 32 ci) tile: K = pixels.
+// The all-taps-per-wave kernel (k_conv_wgrad9, conv_mfma.hip) stages a private 3-row slab per wave: every x row is
+// fetched three times, the staging registers leave no room to read LDS fragments ahead of the MFMAs (256 VGPRs, 12
+// spilled) and its MFMA pipes stay ~65 % busy.  Here the 8 waves of a workgroup share ONE 8 x 32 pixel dY tile and its
+// 10 x 34 X halo in LDS (1.33x halo overhead instead of 3x, 10 instead of 17 staging float4 per lane); wave r takes
+// tile row r as its K slice and all nine taps (9 accumulators), with the fragment reads running one k-step ahead.
+// The next tile is fetched into registers during the MFMAs and written to the other LDS buffer afterwards; one barrier
+// per tile.  The 8 partial sums are folded through LDS and each workgroup writes one slab [Cout][9][Cin] (+ fused bias
+// partial), summed over workgroups in a fixed order by reduce_rows: deterministic, no float atomics.
+namespace {
+
+struct WgTileArgs {
+    ConvIn in;
+    const float* dy;
+    float* part;
+    float* bias_part;
+    int N, H, W, Cout;
+    int tilesY, tilesX, nsp;
+    int n_ci_t, ntiles, kt;
+    unsigned nb0, nb1, nbd;
+};
+
+constexpr int WT_TH = 8;
+constexpr int WT_D = WT_TH * 32 * 32;                 // floats per dY tile
+constexpr int WT_X = (WT_TH + 2) * HALO_W * 32;       // floats per X halo
+
+__global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
+    constexpr int NT = 512;
+    constexpr int LD = WT_TH * 32 * 8 / NT;                       // 4 dY float4 per thread
+    constexpr int XF = (WT_TH + 2) * HALO_W * 8;                  // 2720 X float4 per tile
+    constexpr int LX = (XF + NT - 1) / NT;                        // 6
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ds = smem;                 // [2][WT_D]
+    float* Xs = smem + 2 * WT_D;      // [2][WT_X]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = a.H, W = a.W, Cout = a.Cout;
+    const int C0 = a.in.C0, C1 = a.in.C1, Cin = C0 + C1;
+    const int Hs2 = H >> 1, Ws2 = W >> 1;
+    const int tile = blockIdx.x % a.ntiles, sblk = blockIdx.x / a.ntiles;
+    const int co_base = (tile / a.n_ci_t) * 32, ci_base = (tile % a.n_ci_t) * 32;
+    const int sp0 = sblk * a.kt;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int per_img = a.tilesY * a.tilesX;
+
+    const int c4 = tid & 7;
+    const int d_c = co_base + c4 * 4;
+    const bool d_ok = d_c < Cout;
+    const int x_c = ci_base + c4 * 4;
+    const bool x_cok = x_c < Cin;
+    const bool x_from0 = ci_base < C0;              // a 32-wide ci tile never straddles the sources
+    const unsigned xC = x_from0 ? (unsigned)C0 : (unsigned)C1;
+    const unsigned x_cb = (unsigned)(x_from0 ? x_c : x_c - C0) * 4u;
+    const unsigned nbx = x_from0 ? a.nb0 : a.nb1;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(x_from0 ? a.in.src0 : a.in.src1, nbx), rsd = make_rsrc(a.dy, a.nbd);
+    const bool x_up = x_from0 && a.in.up0;
+    const bool do_bias = a.bias_part != nullptr && ci_base == 0;
+    const int pslot = tid >> 3;                     // pixel slot of load slot 0 (slot j adds 64 pixels)
+
+    float4 rd[LD], rx[LX];
+    float4 bsum;
+    bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
+    auto issue = [&](int t) {
+        const int sp = sp0 + t;
+        const int n = sp / per_img, rem = sp - n * per_img;
+        const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
+        const int y0 = ty * WT_TH, x0 = tx * 32;
+        int ps = pslot;
+        asm volatile("" : "+v"(ps));               // keep the per-slot coordinates out of long-lived registers
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int pix = ps + 64 * j;            // 0..255
+            const int yy = y0 + (pix >> 5), xx = x0 + (pix & 31);
+            const bool ok = d_ok && yy < H;
+            const unsigned p = ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
+            rd[j] = buf_ld4(rsd, ok ? (p * (unsigned)Cout + d_c) * 4u : a.nbd);
+        }
+#pragma unroll
+        for (int j = 0; j < LX; ++j) {
+            const int hp = ps + 64 * j;             // 0..339 valid
+            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool ok = hp < (WT_TH + 2) * HALO_W && x_cok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned pix = x_up ? ((unsigned)n * Hs2 + (unsigned)(yy >> 1)) * Ws2 + (unsigned)(xx >> 1)
+                                      : ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
+            rx[j] = buf_ld4(rsx, ok ? pix * xC * 4u + x_cb : nbx);
+        }
+    };
+    auto commit = [&](int buf) {
+        float* D = Ds + buf * WT_D;
+        float* X = Xs + buf * WT_X;
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            *(float4*)&D[(tid + NT * j) * 4] = rd[j];
+            bsum.x += rd[j].x; bsum.y += rd[j].y; bsum.z += rd[j].z; bsum.w += rd[j].w;   // fused bias gradient
+        }
+#pragma unroll
+        for (int j = 0; j < LX; ++j) {
+            const int f = tid + NT * j;
+            if (XF % NT == 0 || f < XF) *(float4*)&X[f * 4] = rx[j];
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int lcol = lane & 31, lk = lane >> 5;
+    if (my_tiles > 0) {
+        issue(0);
+        commit(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < my_tiles; ++t) {
+        if (t + 1 < my_tiles) issue(t + 1);
+        const float* Dr = Ds + cur * WT_D + (wv * 32 + lk) * 32 + lcol;                 // a(k) = Dr[k * 32]
+        const float* Xr = Xs + cur * WT_X + (wv * HALO_W + lk) * 32 + lcol;             // b(ky,kx,k) = Xr[(ky*34 + k + kx) * 32]
+        float fa[2], fb[2][9];
+        auto ldfrag = [&](int k, int s) {
+            fa[s] = Dr[k * 32];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) fb[s][ky * 3 + kx] = Xr[(ky * HALO_W + k + kx) * 32];
+        };
+        ldfrag(0, 0);
+#pragma unroll
+        for (int k = 0; k < 32; k += 2) {
+            const int s = (k >> 1) & 1;
+            if (k + 2 < 32) ldfrag(k + 2, s ^ 1);
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) acc[tp] = MFMA32(fa[s], fb[s][tp], acc[tp]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+        }
+        if (t + 1 < my_tiles) commit(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // fold the 8 waves' partial sums through LDS (staging space is free now) and write ONE slab per workgroup
+    float* red = smem;                    // [8 waves][32 co][32 ci]
+    float* o = a.part + (size_t)sblk * Cout * 9 * Cin;
+    if (do_bias) {                        // threads with equal (tid & 7) hold the same 4 channels
+        *(float4*)&red[tid * 4] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            const int g = tid >> 2, comp = tid & 3;
+            float s = 0.f;
+            for (int i = 0; i < 64; ++i) s += red[(i * 8 + g) * 4 + comp];
+            if (co_base + tid < Cout) a.bias_part[(size_t)sblk * Cout + co_base + tid] = s;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            red[wv * 1024 + row * 32 + (lane & 31)] = acc[t][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            int idx = tid + e * 512;          // element of the 32x32 tile
+            int row = idx >> 5, col = idx & 31;
+            int co = co_base + row, ci = ci_base + col;
+            float v = ((red[idx] + red[1024 + idx]) + (red[2048 + idx] + red[3072 + idx])) +
+                      ((red[4096 + idx] + red[5120 + idx]) + (red[6144 + idx] + red[7168 + idx]));
+            if (co < Cout && ci < Cin) o[((size_t)co * 9 + t) * Cin + ci] = v;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int g_wgrad_tile_mode = 0;    // 0 auto, 1 off (A/B timing)
+
+bool conv_wgrad_tile_ok(int C0, int C1, int Cout, int ks, int W, int dil) {
+    return g_wgrad_tile_mode == 0 && ks == 3 && dil == 1 && (W % 32 == 0) && (C0 % 4 == 0) && (C1 % 4 == 0) && (Cout % 4 == 0) &&
+           (C1 == 0 || C0 % 32 == 0);
+}
+// number of slabs for a given upper bound (the workspace is sized by the wg9 split count, which is never smaller)
+int conv_wgrad_tile_blocks(int Cin, int Cout, int N, int H, int W, int max_blocks, int* kt_out) {
+    const int ntiles = ceil_div(Cout, 32) * ceil_div(Cin, 32);
+    const int nsp = N * ceil_div(H, WT_TH) * (W / 32);
+    int nsb = 256 / ntiles;                      // one workgroup per CU and never a second, nearly empty round
+    if (nsb > max_blocks) nsb = max_blocks;
+    if (nsb > nsp) nsb = nsp;
+    if (nsb < 1) nsb = 1;
+    const int kt = ceil_div(nsp, nsb);
+    if (kt_out) *kt_out = kt;
+    return ceil_div(nsp, kt);                     // every workgroup gets at least one tile
+}
+int conv_wgrad_tile(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
+                    hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (WT_D + WT_X) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "wgrad tiles do not fit the LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wgrad_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            vqw_set_error("conv_wgrad_tile: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const int Cin = in.C0 + in.C1;
+    const long P = (long)N * H * W;
+    WgTileArgs a;
+    a.in = in; a.dy = dy; a.part = ws; a.bias_part = bpart;
+    a.N = N; a.H = H; a.W = W; a.Cout = Cout;
+    a.tilesY = ceil_div(H, WT_TH); a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
+    a.n_ci_t = ceil_div(Cin, 32); a.ntiles = ceil_div(Cout, 32) * a.n_ci_t; a.kt = kt;
+    a.nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4);
+    a.nb1 = (unsigned)(P * in.C1 * 4);
+    a.nbd = (unsigned)(P * Cout * 4);
+    k_conv_wgrad_tile<<<a.ntiles * nsb, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wgrad_tile");
+    return VQW_OK;
 }

@@ -1000,6 +1000,18 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
         const long nout = (long)Cout * 9 * Cin;
         const unsigned nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
         const unsigned nbd = (unsigned)(P * Cout * 4);
+        if (conv_wgrad_tile_ok(in.C0, in.C1, Cout, ks, W, dil)) {           // block-shared tiles (conv_halo.hip)
+            int kt = 1;
+            const int nsbt = conv_wgrad_tile_blocks(Cin, Cout, N, H, W, nsb, &kt);
+            float* bp = dbias ? ws + (size_t)nsbt * nout : nullptr;
+            int rc = conv_wgrad_tile(in, dy, ws, bp, N, H, W, Cout, nsbt, kt, st);
+            if (rc) return rc;
+            if (dbias) {
+                rc = reduce_rows(bp, dbias, Cout, nsbt, st, acc);
+                if (rc) return rc;
+            }
+            return reduce_rows(ws, dw, nout, nsbt, st, acc);
+        }
         float* bpart = dbias ? ws + (size_t)nsb * nout : nullptr;          // [workgroups][Cout] after the weight slabs
 #define WG9_LAUNCH(NXL_, PF_)                                                                                         \
         do {                                                                                                          \
