@@ -117,15 +117,17 @@ class StyledDenorm(nn.Module):
         self.mlp_gamma = conv3x3(in_channels, in_channels)
         self.mlp_beta = conv3x3(in_channels, in_channels)
 
-    def forward(self, x, style, relu=False):
-        bn = self.param_free_norm
+    def style_maps(self, style):
+        """(gamma, beta) of reference blocks.py:85-87: a function of the style input only, so a caller may evaluate
+        it ahead of / beside the trunk and hand it to forward()."""
         actv = self.mlp_shared[0](style, relu=True)
-        if FUSE_GAMMA_BETA:     # one conv with [gamma | beta] output channels (reference blocks.py:86-87 evaluated together)
-            gamma = ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias)
-            beta = None
-        else:
-            gamma = self.mlp_gamma(actv)
-            beta = self.mlp_beta(actv)
+        if FUSE_GAMMA_BETA:     # one conv with [gamma | beta] output channels
+            return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias), None
+        return self.mlp_gamma(actv), self.mlp_beta(actv)
+
+    def forward(self, x, style, relu=False, maps=None):
+        bn = self.param_free_norm
+        gamma, beta = maps if maps is not None else self.style_maps(style)
         return ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
                               momentum=bn.momentum, eps=bn.eps, relu=relu,
                               num_batches_tracked=bn.num_batches_tracked if self.training else None)
@@ -171,14 +173,23 @@ class StyledResUpBlock(nn.Module):
             FusedReLU(),
         )
 
-    def forward(self, down_input, skip_input):
+    def style_maps(self, skip_input):
+        """Modulation maps of both StyledDenorms on the branch stream (they do not depend on down_input)."""
+        with ops.Branch(skip_input) as br:
+            m1 = self.norm1.style_maps(skip_input)
+            m2 = self.norm2.style_maps(skip_input)
+        return br, m1, m2
+
+    def forward(self, down_input, skip_input, maps=None):
+        br, m1, m2 = maps if maps is not None else self.style_maps(skip_input)
         if self.use_pixel_shuffle:
             x, up = self.up_sample(down_input), False
         else:
             x, up = down_input, True
         s = self.conv[1](self.conv[0](x, up2x=up))
         h = self.conv1(x, up2x=up)
-        h = self.norm1(h, skip_input, relu=True)
+        br.join(*m1, *m2)
+        h = self.norm1(h, skip_input, relu=True, maps=m1)
         h = self.conv2(h)
-        h = self.norm2(h, skip_input, relu=self.use_output_act)
+        h = self.norm2(h, skip_input, relu=self.use_output_act, maps=m2)
         return ops.add(s, h)

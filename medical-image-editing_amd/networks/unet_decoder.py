@@ -72,14 +72,18 @@ class UNetDecoder(nn.Module):
         for d in self.down_convs:
             x, d_skip = d(x)
             d_skips.append(d_skip)
-        x = self.double_conv2(x)
         d_skips.reverse()
-        for i, (u, d_skip) in enumerate(zip(self.up_convs, d_skips)):
+        for i in range(len(d_skips)):
             if i in self.dropped_skip_layers:
-                d_skip = torch.zeros_like(d_skip)
+                d_skips[i] = torch.zeros_like(d_skips[i])
             else:
-                d_skip = self.dropblock(d_skip)
-            x = u(x, d_skip)
+                d_skips[i] = self.dropblock(d_skips[i])
+        # the SPADE modulation maps need only the skips: queue them on the branch stream, deepest level first, so
+        # they run beside the bottleneck and the up-path trunk (same arithmetic as evaluating them inside each block)
+        maps = [u.style_maps(d_skip) for u, d_skip in zip(self.up_convs, d_skips)]
+        x = self.double_conv2(x)
+        for u, d_skip, m in zip(self.up_convs, d_skips, maps):
+            x = u(x, d_skip, maps=m)
         out = ops.add(x, self.conv_last(x))
         out = self.conv1x1(out)
         return ops.tanh(out)

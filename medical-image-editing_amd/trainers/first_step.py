@@ -158,6 +158,7 @@ class FirstStepTrainer:
         out["total"].backward()
         if self._s2 is not None:
             torch.cuda.current_stream().wait_stream(self._s2)
+        ops.join_streams()
         if self.reducer is not None:
             self.reducer.finish()
         self.enc_optim.step()
