@@ -21,11 +21,15 @@
 #include "mfma_util.h"
 #include <cstdlib>
 
-static int halo_kt_env() {
-    const char* e = getenv("VQW_HALO_KT");
-    return e ? atoi(e) : 0;
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
 }
-static const int g_halo_kt = halo_kt_env();     // tuning aid: spatial tiles per workgroup (0 = default)
+static const int g_halo_kt = env_int("VQW_HALO_KT", 0);     // tuning aid: spatial tiles per workgroup (0 = default)
+// Workgroups of the one-per-CU kernels in this file.  256 = every CU of an MI355X.  A smaller value leaves CUs whose
+// LDS is not taken for kernels of other streams that need LDS of their own (e.g. RCCL collectives in data-parallel
+// runs, which otherwise wait for one of these kernels to end).
+static const int g_max_blocks = []{ int v = env_int("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
 
 namespace {
 
@@ -274,7 +278,7 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     // The LDS footprint allows one workgroup per CU: one workgroup per CU, each with an even share of the tiles, so the
     // prologue (weights + first halo, not overlapped with MFMA work) is paid once.  Shorter runs per workgroup
     // (VQW_HALO_KT) would let the dispatcher rebalance when other kernels hold CUs; measured 0.5-1 % slower in the step.
-    int groups = 256 / a.ntn;          // spatial groups: groups * ntn workgroups <= 256, never a second partial round
+    int groups = g_max_blocks / a.ntn;  // spatial groups: groups * ntn workgroups <= one per CU, never a second partial round
     if (groups < 1) groups = 1;
     const int even = ceil_div(a.nsp, groups);
     int kt = g_halo_kt > 0 ? g_halo_kt : even;
@@ -508,7 +512,7 @@ bool conv_wgrad_tile_ok(int C0, int C1, int Cout, int ks, int W, int dil) {
 int conv_wgrad_tile_blocks(int Cin, int Cout, int N, int H, int W, int max_blocks, int* kt_out) {
     const int ntiles = ceil_div(Cout, 32) * ceil_div(Cin, 32);
     const int nsp = N * ceil_div(H, WT_TH) * (W / 32);
-    int nsb = 256 / ntiles;                      // one workgroup per CU and never a second, nearly empty round
+    int nsb = g_max_blocks / ntiles;             // one workgroup per CU and never a second, nearly empty round
     if (nsb > max_blocks) nsb = max_blocks;
     if (nsb > nsp) nsb = nsp;
     if (nsb < 1) nsb = 1;

@@ -5,19 +5,21 @@ FETCH_SIZE counts exactly half of the bytes of wide coalesced reads, so reads = 
 
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_hbm_traffic.json
 """
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, re, sys
 
-FAMILIES = {"conv_mfma_fwd_dgrad": ("k_conv_mfma_fwd",), "conv_mfma_wgrad": ("k_conv_wgrad9", "k_conv_wgrad_up", "k_conv_mfma_wgrad"),
+FAMILIES = {"conv_mfma_fwd_dgrad": ("k_conv_mfma_fwd", "k_conv_halo"),
+            "conv_mfma_wgrad": ("k_conv_wgrad9", "k_conv_wgrad_up", "k_conv_mfma_wgrad", "k_conv_wgrad_tile"),
             "conv_generic_fwd": ("k_conv_direct_fwd", "k_stem_fwd", "k_head_fwd"),
             "conv_generic_wgrad": ("k_conv_direct_wgrad", "k_stem_wgrad", "k_head_wgrad")}
 
 
 def load(d, name):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for f in glob.glob(d + "/*/*_counter_collection.csv"):
+    for f in glob.glob(d + "/*/*_counter_collection.csv") + glob.glob(d + "/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
-                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                m = re.search(r"(k_\w+(?:<[^>]*>)?)", r["Kernel_Name"])      # also inside "(anonymous namespace)::"
+                k = m.group(1) if m else r["Kernel_Name"].split("(")[0].replace("void ", "")
                 agg[k][0] += 1
                 agg[k][1] += float(r["Counter_Value"])
     return agg
