@@ -45,7 +45,7 @@ struct HaloArgs {
     int ntn, nch;              // cout tiles, channel chunks
     int kt;                    // consecutive spatial tiles per workgroup
     int relu;
-    unsigned nb0, nb1, nbw;
+    unsigned nb0, nb1, nbw, nby;
 };
 
 template <int NW, int TH, int BN, int KC, bool WPERSIST>
@@ -89,19 +89,25 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     const int nitems = my_tiles * nch;
     const int per_img = a.tilesY * a.tilesX;
 
-    // loader slots (fixed for the whole kernel)
+    // loader slots (fixed for the whole kernel).  The loader is branch-free on purpose: with loads spread over several
+    // basic blocks the compiler's waitcnt insertion falls back to vmcnt(0) in the middle of the MFMA loop.  Slots past
+    // the end of a tile are given the out-of-range offset (they load 0) and park their LDS write in the padding
+    // floats of row 0, which nothing reads.
+    constexpr int DUMMY = KC;          // floats KC..KC+3 of row 0: padding
     int h_lds[LH];
     short h_y[LH], h_x[LH];
-    unsigned h_c[LH];
+    bool h_ok[LH];
+    const unsigned h_c = (unsigned)(tid % C4) * 4u;      // NT % C4 == 0: every slot of a thread has the same channel group
+    static_assert(NT % C4 == 0, "channel group must be slot-invariant");
 #pragma unroll
     for (int j = 0; j < LH; ++j) {
         int f = tid + j * NT;
         bool ok = (HF % NT == 0) || f < HF;
-        int hp = ok ? f / C4 : 0, c4 = f % C4;
-        h_lds[j] = ok ? hp * KP + c4 * 4 : -1;
+        int hp = ok ? f / C4 : 0;
+        h_ok[j] = ok;
+        h_lds[j] = ok ? hp * KP + (int)h_c : DUMMY;
         h_y[j] = (short)(hp / HALO_W);
         h_x[j] = (short)(hp % HALO_W);
-        h_c[j] = (unsigned)c4 * 4u;
     }
     unsigned w_off[LW];
     int w_lds[LW];
@@ -112,7 +118,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         int row = ok ? f / C4 : 0, c4 = f % C4;      // row = tap * BN + n
         int tap = row / BN, n = row % BN;
         int co = co_base + n;
-        w_lds[j] = ok ? row * KP + c4 * 4 : -1;
+        w_lds[j] = ok ? row * KP + c4 * 4 : DUMMY;
         w_off[j] = (ok && co < Cout) ? (((unsigned)co * 9 + tap) * Cin + c4 * 4) * 4u : a.nbw;
     }
 
@@ -124,24 +130,20 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
         const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
         const int cc = ch * KC;
-        if (cc < C0) {
-            const unsigned img = up0 ? (unsigned)n * Hs2 * Ws2 : (unsigned)n * H * W;
+        // a chunk never straddles the two sources; everything below is wave-uniform selection, no branches
+        const bool from0 = cc < C0;
+        const bool up = from0 && up0;
+        const __amdgpu_buffer_rsrc_t rs = from0 ? rs0 : rs1;
+        const unsigned Csrc = from0 ? (unsigned)C0 : (unsigned)C1, nbs = from0 ? a.nb0 : a.nb1;
+        const unsigned cb = (unsigned)(from0 ? cc : cc - C0) + h_c;
+        const unsigned img = up ? (unsigned)n * Hs2 * Ws2 : (unsigned)n * H * W;
+        const int sh = up ? 1 : 0, Wsrc = up ? Ws2 : W;
 #pragma unroll
-            for (int j = 0; j < LH; ++j) {
-                int yy = y0 + h_y[j], xx = x0 + h_x[j];
-                bool ok = h_lds[j] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-                unsigned pix = up0 ? img + (unsigned)((yy >> 1) * Ws2 + (xx >> 1)) : img + (unsigned)(yy * W + xx);
-                rh[j] = buf_ld4(rs0, ok ? (pix * (unsigned)C0 + cc + h_c[j]) * 4u : a.nb0);
-            }
-        } else {
-            const unsigned img = (unsigned)n * H * W;
-#pragma unroll
-            for (int j = 0; j < LH; ++j) {
-                int yy = y0 + h_y[j], xx = x0 + h_x[j];
-                bool ok = h_lds[j] >= 0 && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-                unsigned pix = img + (unsigned)(yy * W + xx);
-                rh[j] = buf_ld4(rs1, ok ? (pix * (unsigned)C1 + (cc - C0) + h_c[j]) * 4u : a.nb1);
-            }
+        for (int j = 0; j < LH; ++j) {
+            const int yy = y0 + h_y[j], xx = x0 + h_x[j];
+            const bool ok = h_ok[j] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned pix = img + (unsigned)((yy >> sh) * Wsrc + (xx >> sh));
+            rh[j] = buf_ld4(rs, ok ? (pix * Csrc + cb) * 4u : nbs);
         }
         if constexpr (!WPERSIST) {
 #pragma unroll
@@ -150,12 +152,10 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     };
     auto commit = [&](int buf) {       // registers -> LDS buffer `buf`
 #pragma unroll
-        for (int j = 0; j < LH; ++j)
-            if (h_lds[j] >= 0) *(float4*)&Hs[buf * HBUF + h_lds[j]] = rh[j];
+        for (int j = 0; j < LH; ++j) *(float4*)&Hs[buf * HBUF + h_lds[j]] = rh[j];
         if constexpr (!WPERSIST) {
 #pragma unroll
-            for (int j = 0; j < LW; ++j)
-                if (w_lds[j] >= 0) *(float4*)&Ws[buf * WBUF + w_lds[j]] = rw[j];
+            for (int j = 0; j < LW; ++j) *(float4*)&Ws[buf * WBUF + w_lds[j]] = rw[j];
         }
     };
 
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
 #pragma unroll
         for (int j = 0; j < LW; ++j) {
             float4 v = buf_ld4(rsw, w_off[j]);
-            if (w_lds[j] >= 0) *(float4*)&Ws[w_lds[j]] = v;
+            *(float4*)&Ws[w_lds[j]] = v;
         }
     }
     issue(0);
@@ -177,10 +177,50 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     const int a_base = ((wr * TM) * HALO_W + lrow) * KP + lk;
     const int b_base = (wc * TN * 32 + lrow) * KP + lk;
 
-    f32x16 acc[TM][TN];
+    // Finished tiles are written one iteration late, BEFORE the next prefetch is issued, and through raw buffer stores
+    // (an invalid row / cout gets the out-of-range offset and is dropped by the hardware: no branches).  Reason: gfx9
+    // counts loads and stores in one vmcnt and the compiler treats the mix as unordered, so stores issued between a
+    // prefetch and its use turn every wait into vmcnt(0) (measured: waves parked 23 % of the time).  With the stores
+    // older than the loads, the single wait before the LDS commit finds both long finished.
+    const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.y, a.nby);
+    float bvv[TN];
+    unsigned co_off[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = co_base + (wc * TN + j) * 32 + (lane & 31);
+        bvv[j] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
+        co_off[j] = co < Cout ? (unsigned)co : 0xFFFFFFFFu;
+    }
+    const int col0 = 4 * (lane >> 5);
+    f32x16 acc[TM][TN], done[TM][TN];
+    int done_t = -1;
+    auto flush = [&]() {               // C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel column)
+        const bool valid = true;
+        const int sp = sp0 + done_t;
+        const int n = sp / per_img, rem = sp - n * per_img;
+        const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int yy = ty * TH + wr * TM + i;
+                const bool ok = valid && co_off[j] != 0xFFFFFFFFu && yy < H;
+                const unsigned base = (((unsigned)n * H + (unsigned)yy) * W + (unsigned)(tx * 32 + col0)) * (unsigned)Cout + co_off[j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = (r & 3) + 8 * (r >> 2);
+                    float v = done[i][j][r] + bvv[j];
+                    v = a.relu ? fmaxf(v, 0.f) : v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsy, ok ? (int)((base + (unsigned)col * Cout) * 4u) : (int)a.nby, 0, 0);
+                }
+            }
+        }
+        done_t = -1;
+    };
     int cur = 0;
     for (int item = 0; item < nitems; ++item) {
         const int t = item / nch, ch = item - t * nch;
+        if (done_t >= 0) flush();      // wave-uniform
         if (item + 1 < nitems) issue(item + 1);
         if (ch == 0) {
 #pragma unroll
@@ -221,33 +261,17 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... then this group's MFMAs
         }
         if (ch == nch - 1) {
-            // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel column)
-            const int sp = sp0 + t;
-            const int n = sp / per_img, rem = sp - n * per_img;
-            const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int co = co_base + (wc * TN + j) * 32 + (lane & 31);
-                const bool cok = co < Cout;
-                const float bvv = (a.bias && cok) ? a.bias[co] : 0.f;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int yy = ty * TH + wr * TM + i;
-                    if (!cok || yy >= H) continue;
-                    float* yrow = a.y + ((size_t)((size_t)n * H + yy) * W + tx * 32) * Cout + co;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int col = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        float v = acc[i][j][r] + bvv;
-                        yrow[(size_t)col * Cout] = a.relu ? fmaxf(v, 0.f) : v;
-                    }
-                }
-            }
+                for (int j = 0; j < TN; ++j) done[i][j] = acc[i][j];
+            done_t = t;
         }
         if (item + 1 < nitems) commit(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+    if (done_t >= 0) flush();
 }
 
 template <int NW, int TH, int BN, int KC, bool WPERSIST>
@@ -275,6 +299,7 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     a.nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4);
     a.nb1 = (unsigned)(P * in.C1 * 4);
     a.nbw = (unsigned)((long)Cout * 9 * (in.C0 + in.C1) * 4);
+    a.nby = (unsigned)(P * Cout * 4);
     // The LDS footprint allows one workgroup per CU: one workgroup per CU, each with an even share of the tiles, so the
     // prologue (weights + first halo, not overlapped with MFMA work) is paid once.  Shorter runs per workgroup
     // (VQW_HALO_KT) would let the dispatcher rebalance when other kernels hold CUs; measured 0.5-1 % slower in the step.

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvqwnet_hip.so")
+LIB_PATH = os.environ.get("VQW_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libvqwnet_hip.so")   # override: A/B of two builds
 
 c_p = ctypes.c_void_p
 c_i = ctypes.c_int
