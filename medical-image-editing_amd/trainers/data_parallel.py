@@ -90,12 +90,13 @@ class GradientAllReducer:
         for bi, work in self._work:
             work.wait()
             flat, views = self._flat[bi]
-            off = 0
+            flat.mul_(inv)
+            pieces, off = [], 0
             for v in views:
                 n = v.numel()
-                v.copy_(flat[off:off + n])
-                v.mul_(inv)
+                pieces.append(flat[off:off + n])
                 off += n
+            torch._foreach_copy_(views, pieces)        # one multi-tensor launch per bucket, not two per parameter
             self._flat[bi] = None
         self._armed = False
 
