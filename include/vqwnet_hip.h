@@ -194,6 +194,21 @@ int vqw_seg_losses_bwd(const float* logits_nchw, const float* target_nchw, const
                        const float* g_focal, float* glogits, int B, long HW, int C, int ignore_index, float smooth,
                        float gamma, float eps, void* stream);
 
+/* ---- two-view augmentation + id-map warps (networks/random_transform.py:10-112; used at
+ * single_window_trainer.py:75-76, 91-96).  The reference builds these from kornia 0.5.1, which is not available
+ * offline: the arithmetic is the one oracle/augment_ref.py states (parity unpinned).  Matrices are per-sample 3x3,
+ * row-major, mapping a DESTINATION pixel (x, y, 1) to the SOURCE pixel; pixel centres sit on integer coordinates.
+ * warp_image: bilinear, zero padding, (B, C, H, W) planes.  warp_labels: nearest (round half to even), 0 = out of frame.
+ * photometric params per sample {brightness add, contrast multiplier, posterize bits (8 = off), noise std}: clamp(x+b),
+ * clamp(x*c), posterize, + std * noise (noise may be NULL).  gauss_blur: separable, reflect border, apply[b] on/off. */
+int vqw_warp_image(const float* src, const float* minv /*[B][9]*/, float* dst, int B, int C, int H, int W, void* stream);
+int vqw_warp_labels(const void* ids, int ids_are_int64, const float* minv /*[B][9]*/, int32_t* out, int B, int H, int W,
+                    void* stream);
+int vqw_photometric(const float* x, const float* params /*[B][4]*/, const float* noise, float* y, int B, long per_sample,
+                    void* stream);
+int vqw_gauss_blur(const float* x, const float* taps /*[K]*/, const unsigned char* apply /*[B] or NULL*/, float* tmp, float* y,
+                   int B, int C, int H, int W, int K, void* stream);
+
 /* ---- optimiser: torch.optim.Adam as built in trainers/base.py:165-175 */
 int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,

@@ -72,6 +72,10 @@ SIGNATURES = {
     "vqw_codebook_losses": (c_i, [c_p, c_f, c_p, c_p, c_i, c_i, c_p]),
     "vqw_onehot": (c_i, [c_p, c_p, c_i, c_l, c_i, c_p]),
     "vqw_flip_labels": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_warp_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_warp_labels": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "vqw_photometric": (c_i, [c_p, c_p, c_p, c_p, c_i, c_l, c_p]),
+    "vqw_gauss_blur": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_pixel_shuffle2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_dropblock_mask": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_dropblock_apply": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_p]),

@@ -971,6 +971,66 @@ def flip_labels(ids, border=0):
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# two-view augmentation + id-map warps (data path: no autograd)
+# ----------------------------------------------------------------------------------------------
+def warp_image(x, minv):
+    """x (B, C, H, W) fp32, minv (B, 3, 3) fp32 destination->source pixel matrices: bilinear resample, zero padding."""
+    _dev(x, minv)
+    x, minv = _flat(x), _flat(minv)
+    B, C, H, W = x.shape
+    if tuple(minv.shape) != (B, 3, 3):
+        raise RuntimeError("warp_image: expected %s matrices, got %s" % ((B, 3, 3), tuple(minv.shape)))
+    y = torch.empty_like(x)
+    _lib.check(_L().vqw_warp_image(_p(x), _p(minv), _p(y), B, C, H, W, _st()), "vqw_warp_image")
+    return y
+
+
+def warp_labels(ids, minv):
+    """ids (B, H, W) int64 or int32 -> int32 map sampled with nearest neighbour through minv; 0 = out of frame."""
+    _dev(ids, minv)
+    if ids.dtype not in (torch.int64, torch.int32):
+        raise RuntimeError("warp_labels: ids must be int64 or int32 (got %s)" % ids.dtype)
+    ids = ids.contiguous()
+    minv = _flat(minv)
+    B, H, W = ids.shape
+    if tuple(minv.shape) != (B, 3, 3):
+        raise RuntimeError("warp_labels: expected %s matrices, got %s" % ((B, 3, 3), tuple(minv.shape)))
+    out = torch.empty((B, H, W), dtype=torch.int32, device=ids.device)
+    _lib.check(_L().vqw_warp_labels(_p(ids), int(ids.dtype == torch.int64), _p(minv), _p(out), B, H, W, _st()), "vqw_warp_labels")
+    return out
+
+
+def photometric(x, params, noise=None):
+    """Per-sample brightness add, contrast multiply (clamped to [0,1]), posterize, + std * noise; params (B, 4)."""
+    _dev(x, params, noise)
+    x, params = _flat(x), _flat(params)
+    B = x.shape[0]
+    if tuple(params.shape) != (B, 4):
+        raise RuntimeError("photometric: params must be (%d, 4)" % B)
+    if noise is not None:
+        noise = _flat(noise)
+        if noise.shape != x.shape:
+            raise RuntimeError("photometric: noise shape %s != %s" % (tuple(noise.shape), tuple(x.shape)))
+    y = torch.empty_like(x)
+    _lib.check(_L().vqw_photometric(_p(x), _p(params), _p(noise), _p(y), B, x.numel() // B, _st()), "vqw_photometric")
+    return y
+
+
+def gauss_blur(x, taps, apply=None):
+    """Separable Gaussian blur of (B, C, H, W) with 1-D `taps`, reflect border; apply (B,) uint8 selects samples."""
+    _dev(x, taps, apply)
+    x, taps = _flat(x), _flat(taps)
+    B, C, H, W = x.shape
+    if apply is not None:
+        apply = apply.to(torch.uint8).contiguous()
+        if apply.numel() != B:
+            raise RuntimeError("gauss_blur: apply must have one entry per sample")
+    tmp, y = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_L().vqw_gauss_blur(_p(x), _p(taps), _p(apply), _p(tmp), _p(y), B, C, H, W, taps.numel(), _st()), "vqw_gauss_blur")
+    return y
+
+
 def set_conv_backend(mode):
     """0 = auto (MFMA kernels where shapes allow), 1 = generic VALU kernels only (testing)."""
     return _L().vqw_set_conv_backend(int(mode))

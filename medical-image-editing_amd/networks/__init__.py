@@ -6,3 +6,4 @@ from .blocks import UpBlock, ResBlock, DoubleConv, StyledDenorm, StyledResUpBloc
 from .aspp import ASPP  # noqa: F401
 from .vq import VQ  # noqa: F401
 from .vqwnet import VQWNet  # noqa: F401
+from .random_transform import RandomTransform  # noqa: F401

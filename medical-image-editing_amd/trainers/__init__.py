@@ -1,2 +1,2 @@
-from .first_step import FirstStepTrainer, FlipViews, LossWeights  # noqa: F401
+from .first_step import FirstStepTrainer, FlipViews, RandomTransformViews, LossWeights  # noqa: F401
 from .data_parallel import GradientAllReducer  # noqa: F401

@@ -32,8 +32,27 @@ class FlipViews:
         noised2 = flipped if noise is None else ops.add(flipped, noise)
         return (image, image), (noised2, flipped)
 
-    def cross_ids(self, ids):
+    def cross_ids(self, ids, which=1):
         return ops.flip_labels(ids, self.border)
+
+
+class RandomTransformViews:
+    """The reference's pair of RandomTransform modules (trainers/base.py:280-282) behind the `views` protocol:
+    images arrive in [-1, 1], are augmented in [0, 1] and handed back in [-1, 1] (single_window_trainer.py:73-83);
+    cross_ids(ids, which) = other.forward_transform(own.reverse_transform(ids)) (:91-96)."""
+
+    def __init__(self, transform_1, transform_2):
+        self.t = (transform_1, transform_2)
+
+    def __call__(self, image, noise=None):
+        x = denorm(image.clone(), vmin=0, vmax=1)           # norm / denorm work in place: keep the batch intact
+        n1, c1 = self.t[0](x.clone())
+        n2, c2 = self.t[1](x)
+        return (norm(n1), norm(c1)), (norm(n2), norm(c2))
+
+    def cross_ids(self, ids, which=1):
+        own, other = (self.t[0], self.t[1]) if which == 1 else (self.t[1], self.t[0])
+        return other.forward_transform(own.reverse_transform(ids))
 
 
 class FirstStepTrainer:
@@ -90,11 +109,11 @@ class FirstStepTrainer:
         with torch.cuda.stream(s2):
             feat_2 = self.encoder.feature_extraction(noised_2)
         embed_1, l_commit_1, ids_1 = self.encoder(noised_1)
-        r_ids_1 = self.views.cross_ids(ids_1)
+        r_ids_1 = self.views.cross_ids(ids_1, 1)
         with torch.cuda.stream(s2):
             embed_2, l_commit_2, ids_2 = self.encoder.vq(feat_2, id_base=1)       # ordered after view 1's update
             ids_2 = torch.transpose(ids_2, 1, 2)
-            r_ids_2 = self.views.cross_ids(ids_2)
+            r_ids_2 = self.views.cross_ids(ids_2, 2)
             ev2 = s2.record_event()
         s1.wait_event(ev2)
         for t in (embed_2, r_ids_2, ids_2):
@@ -126,8 +145,8 @@ class FirstStepTrainer:
         (noised_1, clear_1), (noised_2, clear_2) = self.views(image, noise)
         embed_1, l_commit_1, ids_1 = self.encoder(noised_1)
         embed_2, l_commit_2, ids_2 = self.encoder(noised_2)
-        r_ids_1 = self.views.cross_ids(ids_1)
-        r_ids_2 = self.views.cross_ids(ids_2)
+        r_ids_1 = self.views.cross_ids(ids_1, 1)
+        r_ids_2 = self.views.cross_ids(ids_2, 2)
         codebook = self.encoder.vq.get_codebook()
         if self.use_onehot:      # the reference's literal route: (B,K+1,H,W) one-hot, class 0 dropped
             oh1 = self.one_hot_encoder(r_ids_1)[:, 1:, ...]

@@ -630,3 +630,118 @@ def test_rejects_bad_arguments():
                    skip=torch.randn(1, 16, 7, 7, device=DEV))
     with pytest.raises(RuntimeError, match="vqw_maxpool2_fwd"):      # rejected by the C ABI's own argument check
         ops.maxpool2(torch.randn(1, 16, 1, 8, device=DEV))
+
+
+# --------------------------------------------------------------------------------------------------
+# two-view augmentation + id-map warps (oracle/augment_ref.py defines the arithmetic, kornia absent)
+# --------------------------------------------------------------------------------------------------
+def _rand_mats(B, H, W, seed):
+    from oracle import augment_ref as A
+    rng = np.random.default_rng(seed)
+    mats = []
+    for b in range(B):
+        kind = b % 4
+        if kind == 0:
+            mats.append(A.identity_matrix())
+        elif kind == 1:
+            mats.append(A.hflip_matrix(W))
+        elif kind == 2:
+            mats.append(A.affine_matrix(0.0, float(rng.integers(-5, 6)), float(rng.integers(-5, 6)), 0.0, 0.0, H, W))
+        else:
+            mats.append(A.affine_matrix(rng.uniform(-30, 30), rng.uniform(-6, 6), rng.uniform(-6, 6), rng.uniform(-10, 10), 0.0, H, W))
+    return np.stack(mats)
+
+
+@pytest.mark.parametrize("shape", [(8, 32, 32), (5, 40, 24), (4, 256, 256)])
+def test_augment_warps_match_oracle(shape):
+    from oracle import augment_ref as A
+    ops = _ops()
+    B, H, W = shape
+    rng = np.random.default_rng(7)
+    fwd = _rand_mats(B, H, W, 11)
+    minv = np.stack([A.dst_to_src(m) for m in fwd])
+    img = rng.random((B, 1, H, W), dtype=np.float32)
+    ids = rng.integers(1, 11, size=(B, H, W)).astype(np.int64)
+    y = ops.warp_image(torch.from_numpy(img).to(DEV), torch.from_numpy(minv).to(DEV))
+    assert_close(y, A.warp_image(img, minv), 2e-6, "warp_image", atol=2e-6)
+    for dt in (torch.int64, torch.int32):
+        w = ops.warp_labels(torch.from_numpy(ids).to(DEV).to(dt), torch.from_numpy(minv).to(DEV))
+        assert w.dtype == torch.int32
+        assert np.array_equal(w.cpu().numpy(), A.warp_labels(ids, minv)), "warp_labels %s" % dt
+    # degenerate matrix (w = 0 row): everything out of frame
+    bad = np.zeros((B, 3, 3), dtype=np.float32)
+    assert int(ops.warp_labels(torch.from_numpy(ids).to(DEV), torch.from_numpy(bad).to(DEV)).abs().sum()) == 0
+
+
+def test_augment_photometric_and_blur_match_oracle():
+    from oracle import augment_ref as A
+    ops = _ops()
+    rng = np.random.default_rng(3)
+    B, H, W = 6, 48, 40
+    x = rng.random((B, 1, H, W), dtype=np.float32)
+    noise = rng.standard_normal((B, 1, H, W)).astype(np.float32)
+    params = np.array([[0.0, 1.0, 8, 0.0], [0.2, 1.0, 8, 0.0], [-0.3, 1.4, 8, 0.0], [0.0, 0.6, 3, 0.0], [0.1, 1.1, 5, 0.05],
+                       [0.0, 1.0, 1, 0.2]], dtype=np.float32)
+    y = ops.photometric(torch.from_numpy(x).to(DEV), torch.from_numpy(params).to(DEV), torch.from_numpy(noise).to(DEV))
+    assert_close(y, A.photometric(x, params, noise), 1e-6, "photometric", atol=1e-6)
+    y0 = ops.photometric(torch.from_numpy(x).to(DEV), torch.from_numpy(params[:, :]).to(DEV), None)
+    assert_close(y0, A.photometric(x, params, None), 1e-6, "photometric (no noise)", atol=1e-6)
+    for k, sigma in ((3, 1.0), (5, 1.5), (9, 2.0)):
+        taps = A.gaussian_taps(k, sigma)
+        apply = np.array([1, 0, 1, 1, 0, 1], dtype=np.uint8)
+        yb = ops.gauss_blur(torch.from_numpy(x).to(DEV), torch.from_numpy(taps).to(DEV), torch.from_numpy(apply).to(DEV))
+        assert_close(yb, A.gauss_blur(x, taps, apply), 2e-6, "gauss_blur k=%d" % k, atol=2e-6)
+    with pytest.raises(RuntimeError, match="vqw_gauss_blur"):
+        ops.gauss_blur(torch.from_numpy(x).to(DEV), torch.ones(4, device=DEV) / 4)          # even kernel size
+
+
+def test_random_transform_module_properties():
+    """RandomTransform: reverse then forward of the SAME transform is the identity away from the border, flips and
+    whole-pixel shifts are exact, the module equals the oracle driven with the matrices it sampled, and the
+    trainer runs a step with the reference's two-transform view pair."""
+    from oracle import augment_ref as A
+    from networks import RandomTransform
+    from trainers import FirstStepTrainer, RandomTransformViews
+    cfg = dict(modules=["RandomHorizontalFlip", "RandomAffine", "ColorJitter", "RandomGaussianBlur", "RandomPosterize",
+                        "RandomGaussianNoise"],
+               RandomHorizontalFlip=dict(p=0.5), RandomAffine=dict(degrees=20.0, translate=(0.1, 0.1), shear=8.0, p=0.8),
+               ColorJitter=dict(brightness=0.2, contrast=0.2, saturation=0.0, hue=0.0, p=0.8),
+               RandomGaussianBlur=dict(kernel=5, sigma=1.2, p=0.5), RandomPosterize=dict(bits=4, p=0.3),
+               RandomGaussianNoise=dict(std=0.05, p=0.5))
+    B, H, W = 8, 64, 64
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 1, H, W, generator=g).to(DEV)
+    t = RandomTransform(cfg, seed=123)
+    aug, clear = t(x)
+    assert aug.shape == x.shape and clear.shape == x.shape and len(t._transforms) == 2
+    mats = [m.numpy() for m in t._transforms]
+    # geometric part against the oracle with the sampled matrices
+    ref = x.cpu().numpy()
+    for m in mats:
+        ref = A.warp_image(ref, np.stack([A.dst_to_src(m[b]) for b in range(B)]))
+    assert_close(clear, ref, 5e-6, "clear view", atol=5e-6)
+    # id maps: forward / reverse against the oracle, and reverse∘forward = identity on the interior
+    ids = torch.randint(1, 11, (B, H, W), generator=g).to(DEV)
+    f = t.forward_transform(ids)
+    assert np.array_equal(f.cpu().numpy(), A.forward_transform(ids.cpu().numpy(), mats))
+    r = t.reverse_transform(f)
+    assert np.array_equal(r.cpu().numpy(), A.reverse_transform(f.cpu().numpy(), mats))
+    smooth = (torch.arange(H).view(1, H, 1) // 8 * 8 + torch.arange(W).view(1, 1, W) // 8 + 1).expand(B, H, W).contiguous().to(DEV)
+    back = t.reverse_transform(t.forward_transform(smooth))
+    inside = back != 0
+    assert float(inside.float().mean()) > 0.5
+    assert float((back[inside] == smooth[inside].int()).float().mean()) > 0.9       # piecewise-constant map survives two nearest warps
+    # exact transforms: flip only
+    tf = RandomTransform(dict(modules=["RandomHorizontalFlip"], RandomHorizontalFlip=dict(p=1.0)), seed=1)
+    a2, c2 = tf(x)
+    assert torch.equal(a2, torch.flip(x, dims=[3])) and torch.equal(c2, a2)
+    assert torch.equal(tf.forward_transform(ids), torch.flip(ids, dims=[2]).int())
+    assert torch.equal(tf.reverse_transform(tf.forward_transform(ids)), ids.int())
+    # one training step with the reference's view pair
+    tr = FirstStepTrainer(enc_filters=(4, 8, 8, 8, 8), dec_filters=(4, 8, 8, 8, 8), device=DEV,
+                          views=RandomTransformViews(RandomTransform(cfg, seed=1), RandomTransform(cfg, seed=2)))
+    img = torch.rand(2, 1, 32, 32, generator=g).to(DEV) * 2 - 1
+    keep = img.clone()
+    out = tr.training_step({"image": img})
+    assert torch.equal(img, keep)                                    # the batch is not modified in place
+    assert np.isfinite(float(out["total"].detach()))
