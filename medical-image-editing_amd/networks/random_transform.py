@@ -8,8 +8,6 @@ runs in the HIP kernels of csrc/augment.hip.  The arithmetic is the one oracle/a
 kornia unpinned: it is not installed offline).  A grey image expanded to RGB and converted back (reference :77, :91-92)
 is the identity up to one rounding, so the image stays single-channel here.
 """
-import math
-
 import torch
 import torch.nn as nn
 
@@ -39,7 +37,7 @@ class RandomTransform(nn.Module):
         self.geometrics = [m for m in modules if m in self.GEOMETRIC]
         self.photometrics = [m for m in modules if m in self.PHOTOMETRIC]
         self.generator = torch.Generator().manual_seed(int(seed))
-        self._transforms = []
+        self._transforms, self._on_device = [], []
 
     # -- host-side parameter sampling (float64, one row per sample)
     def _uniform(self, n, lo, hi):
@@ -65,17 +63,16 @@ class RandomTransform(nn.Module):
         tx = self._uniform(B, -tr[0] * W, tr[0] * W)
         ty = self._uniform(B, -tr[1] * H, tr[1] * H)
         sx = self._uniform(B, sh[0], sh[1])
+        # back @ rot @ shear @ to_centre, written out (vectorised over the batch)
         cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
-        f64 = dict(dtype=torch.float64)
-        for b in range(B):
-            if not bool(on[b]):
-                continue
-            a = math.radians(float(ang[b]))
-            rot = torch.tensor([[math.cos(a), math.sin(a), 0.0], [-math.sin(a), math.cos(a), 0.0], [0.0, 0.0, 1.0]], **f64)
-            shm = torch.tensor([[1.0, -math.tan(math.radians(float(sx[b]))), 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]], **f64)
-            to_c = torch.tensor([[1.0, 0.0, -cx], [0.0, 1.0, -cy], [0.0, 0.0, 1.0]], **f64)
-            back = torch.tensor([[1.0, 0.0, cx + float(tx[b])], [0.0, 1.0, cy + float(ty[b])], [0.0, 0.0, 1.0]], **f64)
-            m[b] = back @ rot @ shm @ to_c
+        a = torch.deg2rad(ang)
+        c, s_, t = torch.cos(a), torch.sin(a), -torch.tan(torch.deg2rad(sx))
+        r00, r01 = c, c * t + s_           # rot @ shear, first row
+        r10, r11 = -s_, -s_ * t + c        # second row
+        aff = torch.eye(3, dtype=torch.float64).repeat(B, 1, 1)
+        aff[:, 0, 0], aff[:, 0, 1], aff[:, 0, 2] = r00, r01, cx + tx - (r00 * cx + r01 * cy)
+        aff[:, 1, 0], aff[:, 1, 1], aff[:, 1, 2] = r10, r11, cy + ty - (r10 * cx + r11 * cy)
+        m[on] = aff[on]
         return m
 
     def _photometric_op(self, name, B):
@@ -110,11 +107,14 @@ class RandomTransform(nn.Module):
     def forward(self, x):
         """x: (B, 1, H, W) in [0, 1].  Returns (augmented, clear) like random_transform.py:76-94."""
         B, _, H, W = x.shape
-        self._transforms = []
+        self._transforms, self._on_device = [], []
         for name in self.geometrics:
             m = self._geometric_matrix(name, B, H, W)
             self._transforms.append(m)
-            x = ops.warp_image(x, torch.linalg.inv(m).float().to(x.device))
+            # both directions go to the device once: (destination->source of the forward warp, of the inverse warp)
+            pair = torch.stack([torch.linalg.inv(m), m]).float().to(x.device, non_blocking=True)
+            self._on_device.append((pair[0], pair[1]))
+            x = ops.warp_image(x, pair[0])
         clear_x = x.detach().clone()
         for name in self.photometrics:
             op = self._photometric_op(name, B)
@@ -127,12 +127,12 @@ class RandomTransform(nn.Module):
 
     def forward_transform(self, x):
         """Warp an id map (B, H, W) into this view's frame (nearest, 0 = out of frame); int32 result."""
-        for m in self._transforms:
-            x = ops.warp_labels(x, torch.linalg.inv(m).float().to(x.device))
+        for minv, _ in self._on_device:
+            x = ops.warp_labels(x, minv)
         return x
 
     def reverse_transform(self, x):
         """Warp an id map of this view back to the un-augmented frame (inverse matrices, reverse order)."""
-        for m in reversed(self._transforms):
-            x = ops.warp_labels(x, m.float().to(x.device))      # destination->source of the inverse warp = forward matrix
+        for _, mfwd in reversed(self._on_device):
+            x = ops.warp_labels(x, mfwd)      # destination->source of the inverse warp = the forward matrix
         return x
