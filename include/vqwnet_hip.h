@@ -209,6 +209,32 @@ int vqw_photometric(const float* x, const float* params /*[B][4]*/, const float*
 int vqw_gauss_blur(const float* x, const float* taps /*[K]*/, const unsigned char* apply /*[B] or NULL*/, float* tmp, float* y,
                    int B, int C, int H, int W, int K, void* stream);
 
+/* ---- second training step: PatchGAN discriminator + GAN losses (networks/discriminator.py:18-87,
+ * functions/gan_loss.py:6-10, trainers/single_window_trainer.py:434-488).  NHWC activations, OHWI weights
+ * [Cout][k][k][Cin]; output size floor((H + 2 pad - k) / stride) + 1; stride 1 or 2; H, W are INPUT dims.
+ * sconv_fwd applies LeakyReLU(slope) in the epilogue (slope = 1: none). */
+int vqw_sconv_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+                  int ks, int stride, int pad, float slope, void* stream);
+int vqw_sconv_dgrad(const float* gy, const float* w_ohwi, float* gx, int N, int H, int W, int Cin, int Cout, int ks,
+                    int stride, int pad, void* stream);
+size_t vqw_sconv_wgrad_ws_bytes(int Cin, int Cout, int ks, int N, int H, int W, int stride, int pad);
+int vqw_sconv_wgrad(const float* x, const float* gy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes, int N, int H,
+                    int W, int Cin, int Cout, int ks, int stride, int pad, int accumulate, void* stream);
+int vqw_leaky_relu_bwd(const float* y, const float* gy, float* gx, float slope, long n, void* stream);
+/* BatchNorm2d(affine) + LeakyReLU: y = lrelu(((x - mean) * rstd) * gamma + beta); statistics through
+ * vqw_bn_partial_stats / vqw_bn_finalize.  bwd_reduce: sums[C][2] = {sum g', sum g' * xhat} (dbeta, dgamma);
+ * bwd_apply: dx, and dgamma / dbeta (may be NULL) written or accumulated. */
+int vqw_bn_affine_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, float* y, long P, int C,
+                      float slope, void* stream);
+int vqw_bn_affine_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* gy,
+                             double* sums, void* ws, size_t ws_bytes, int N, int HW, int C, float slope, void* stream);
+int vqw_bn_affine_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta, const float* gy,
+                            const double* sums, double count, float* gx, float* dgamma, float* dbeta, long P, int C,
+                            float slope, int training, int accumulate, void* stream);
+/* mode 0: mean(relu(1 - x)), 1: mean(relu(1 + x)) (hinge_d_loss halves), 2: -mean(x) (generator loss) */
+int vqw_hinge_fwd(const float* x, long n, int mode, float* loss, void* stream);
+int vqw_hinge_bwd(const float* x, long n, int mode, const float* gloss, float* gx, void* stream);
+
 /* ---- optimiser: torch.optim.Adam as built in trainers/base.py:165-175 */
 int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,

@@ -1,0 +1,235 @@
+// PatchGAN discriminator path of the second training step (reference: networks/discriminator.py:18-87,
+// functions/gan_loss.py:6-10, trainers/single_window_trainer.py:434-488): 4x4 convolutions with stride 1 or 2 and
+// padding 1, BatchNorm2d (affine) + LeakyReLU(0.2), hinge / generator losses.  NHWC activations, OHWI weights.
+//
+// The strided convolutions here are direct VALU kernels (any kernel size / stride / padding): the discriminator is
+// ~6 GFLOP per image and call against ~245 for one W-Net view; routing its three wide layers onto the MFMA kernels
+// (the stride-2 gather is the geometry conv_mfma.hip already runs for the collapsed dgrad) is the listed next step.
+#include "common.h"
+#include "conv_common.h"
+#include "../../include/vqwnet_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// one thread per output element (pixel, co); adjacent threads = adjacent co
+__global__ void __launch_bounds__(256) k_sconv_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int N, int H, int W,
+                                                   int Ho, int Wo, int Cin, int Cout, int ks, int stride, int pad, float slope) {
+    const int taps = ks * ks;
+    long total = (long)N * Ho * Wo * Cout;
+    long gstride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        int co = (int)(i % Cout);
+        long p = i / Cout;
+        int xo = (int)(p % Wo);
+        long q = p / Wo;
+        int yo = (int)(q % Ho);
+        int n = (int)(q / Ho);
+        float acc = bias ? bias[co] : 0.f;
+        for (int t = 0; t < taps; ++t) {
+            int hy = yo * stride - pad + t / ks, wx = xo * stride - pad + t % ks;
+            if ((unsigned)hy >= (unsigned)H || (unsigned)wx >= (unsigned)W) continue;
+            const float* wr = w + ((long)co * taps + t) * Cin;
+            const float* s = x + (((long)n * H + hy) * W + wx) * Cin;
+            if ((Cin & 3) == 0) {
+                for (int c = 0; c < Cin; c += 4) {
+                    float4 a = *(const float4*)(s + c), b = *(const float4*)(wr + c);
+                    acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                }
+            } else {
+                for (int c = 0; c < Cin; ++c) acc = fmaf(s[c], wr[c], acc);
+            }
+        }
+        y[i] = lrelu(acc, slope);
+    }
+}
+
+// input gradient: one thread per (input pixel, ci); gx = sum over the output pixels / taps that touched it
+__global__ void __launch_bounds__(256) k_sconv_dgrad(const float* __restrict__ gy, const float* __restrict__ w,
+                                                     float* __restrict__ gx, int N, int H, int W, int Ho, int Wo, int Cin,
+                                                     int Cout, int ks, int stride, int pad) {
+    const int taps = ks * ks;
+    long total = (long)N * H * W * Cin;
+    long gstride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        int ci = (int)(i % Cin);
+        long p = i / Cin;
+        int xx = (int)(p % W);
+        long q = p / W;
+        int yy = (int)(q % H);
+        int n = (int)(q / H);
+        float acc = 0.f;
+        for (int t = 0; t < taps; ++t) {
+            int ny = yy + pad - t / ks, nx = xx + pad - t % ks;
+            if (ny < 0 || nx < 0 || ny % stride || nx % stride) continue;
+            int yo = ny / stride, xo = nx / stride;
+            if (yo >= Ho || xo >= Wo) continue;
+            const float* g = gy + (((long)n * Ho + yo) * Wo + xo) * Cout;
+            const float* wr = w + (long)t * Cin + ci;                 // w[co][t][ci], co stride taps*Cin
+            for (int co = 0; co < Cout; ++co) acc = fmaf(g[co], wr[(long)co * taps * Cin], acc);
+        }
+        gx[i] = acc;
+    }
+}
+
+// weight gradient: workgroup = (co, tap, pixel split); threads stride over (pixel, ci); partial[split][co][tap][ci]
+__global__ void __launch_bounds__(256) k_sconv_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
+                                                     float* __restrict__ part, int N, int H, int W, int Ho, int Wo, int Cin,
+                                                     int Cout, int ks, int stride, int pad, int nsplit) {
+    extern __shared__ float red[];                 // [256 / cl][cl] partial sums, cl = lanes over ci
+    const int taps = ks * ks;
+    int b = blockIdx.x;
+    const int split = b % nsplit; b /= nsplit;
+    const int t = b % taps;
+    const int co = b / taps;
+    const int cl = Cin >= 256 ? 256 : (Cin >= 64 ? 64 : (Cin >= 16 ? 16 : (Cin >= 4 ? 4 : 1)));
+    const int lanes_p = 256 / cl;
+    const int lc = threadIdx.x % cl, lp = threadIdx.x / cl;
+    const long Po = (long)N * Ho * Wo;
+    const long per = (Po + nsplit - 1) / nsplit;
+    const long p0 = split * per, p1 = p0 + per < Po ? p0 + per : Po;
+    const int ky = t / ks, kx = t % ks;
+    for (int c0 = 0; c0 < Cin; c0 += cl) {
+        const int ci = c0 + lc;
+        float acc = 0.f;
+        if (ci < Cin) {
+            for (long p = p0 + lp; p < p1; p += lanes_p) {
+                int xo = (int)(p % Wo);
+                long q = p / Wo;
+                int yo = (int)(q % Ho);
+                int n = (int)(q / Ho);
+                int hy = yo * stride - pad + ky, wx = xo * stride - pad + kx;
+                if ((unsigned)hy >= (unsigned)H || (unsigned)wx >= (unsigned)W) continue;
+                acc = fmaf(gy[p * Cout + co], x[(((long)n * H + hy) * W + wx) * Cin + ci], acc);
+            }
+        }
+        red[lp * cl + lc] = acc;
+        __syncthreads();
+        if (lp == 0 && ci < Cin) {
+            float s = 0.f;
+            for (int k = 0; k < lanes_p; ++k) s += red[k * cl + lc];
+            part[(((long)split * Cout + co) * taps + t) * Cin + ci] = s;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_leaky_bwd(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, float slope, long n) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gx[i] = y[i] > 0.f ? gy[i] : gy[i] * slope;
+}
+
+// mode 0: mean(relu(1 - x)); 1: mean(relu(1 + x)); 2: -mean(x).  One workgroup, fixed order, double accumulation.
+__global__ void __launch_bounds__(1024) k_hinge_fwd(const float* __restrict__ x, long n, int mode, float* __restrict__ loss) {
+    __shared__ double sm[1024];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) {
+        float v = x[i];
+        a += mode == 0 ? (double)fmaxf(1.f - v, 0.f) : (mode == 1 ? (double)fmaxf(1.f + v, 0.f) : -(double)v);
+    }
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)(sm[0] / (double)n);
+}
+__global__ void k_hinge_bwd(const float* __restrict__ x, long n, int mode, const float* __restrict__ gloss, float* __restrict__ gx) {
+    long stride = (long)gridDim.x * blockDim.x;
+    const float g = gloss[0] / (float)n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float v = x[i];
+        gx[i] = mode == 0 ? (1.f - v > 0.f ? -g : 0.f) : (mode == 1 ? (1.f + v > 0.f ? g : 0.f) : -g);
+    }
+}
+
+int out_dim(int n, int ks, int stride, int pad) { return (n + 2 * pad - ks) / stride + 1; }
+int wgrad_splits(long Po) {
+    long s = Po / 4096;
+    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
+}  // namespace
+
+static int check_sconv(const char* who, int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad) {
+    VQW_CHECK(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && ks >= 1 && ks <= 7 && (stride == 1 || stride == 2) && pad >= 0 &&
+                  pad < ks && H + 2 * pad >= ks && W + 2 * pad >= ks,
+              "%s: bad geometry N=%d H=%d W=%d Cin=%d Cout=%d k=%d stride=%d pad=%d", who, N, H, W, Cin, Cout, ks, stride, pad);
+    return VQW_OK;
+}
+
+extern "C" int vqw_sconv_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N, int H, int W, int Cin,
+                             int Cout, int ks, int stride, int pad, float slope, void* stream) {
+    int rc = check_sconv("vqw_sconv_fwd", N, H, W, Cin, Cout, ks, stride, pad);
+    if (rc) return rc;
+    VQW_CHECK(x && w_ohwi && y, "vqw_sconv_fwd: null pointer");
+    const int Ho = out_dim(H, ks, stride, pad), Wo = out_dim(W, ks, stride, pad);
+    long total = (long)N * Ho * Wo * Cout;
+    k_sconv_fwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, w_ohwi, bias, y, N, H, W, Ho, Wo, Cin, Cout, ks, stride,
+                                                                          pad, slope);
+    VQW_LAUNCH_CHECK("vqw_sconv_fwd");
+    return VQW_OK;
+}
+
+extern "C" int vqw_sconv_dgrad(const float* gy, const float* w_ohwi, float* gx, int N, int H, int W, int Cin, int Cout, int ks,
+                               int stride, int pad, void* stream) {
+    int rc = check_sconv("vqw_sconv_dgrad", N, H, W, Cin, Cout, ks, stride, pad);
+    if (rc) return rc;
+    VQW_CHECK(gy && w_ohwi && gx, "vqw_sconv_dgrad: null pointer");
+    const int Ho = out_dim(H, ks, stride, pad), Wo = out_dim(W, ks, stride, pad);
+    long total = (long)N * H * W * Cin;
+    k_sconv_dgrad<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gy, w_ohwi, gx, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad);
+    VQW_LAUNCH_CHECK("vqw_sconv_dgrad");
+    return VQW_OK;
+}
+
+extern "C" size_t vqw_sconv_wgrad_ws_bytes(int Cin, int Cout, int ks, int N, int H, int W, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || ks <= 0 || stride <= 0) return 0;
+    const long Po = (long)N * out_dim(H, ks, stride, pad) * out_dim(W, ks, stride, pad);
+    return ((size_t)wgrad_splits(Po) * Cout * ks * ks * Cin + bias_grad_ws_floats(Cout)) * sizeof(float);
+}
+
+extern "C" int vqw_sconv_wgrad(const float* x, const float* gy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes, int N,
+                               int H, int W, int Cin, int Cout, int ks, int stride, int pad, int accumulate, void* stream) {
+    int rc = check_sconv("vqw_sconv_wgrad", N, H, W, Cin, Cout, ks, stride, pad);
+    if (rc) return rc;
+    VQW_CHECK(x && gy && dw_ohwi && ws, "vqw_sconv_wgrad: null pointer");
+    VQW_CHECK(ws_bytes >= vqw_sconv_wgrad_ws_bytes(Cin, Cout, ks, N, H, W, stride, pad), "vqw_sconv_wgrad: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int Ho = out_dim(H, ks, stride, pad), Wo = out_dim(W, ks, stride, pad);
+    const long Po = (long)N * Ho * Wo;
+    const int nsplit = wgrad_splits(Po);
+    float* wsf = (float*)ws;
+    if (dbias) {
+        rc = bias_grad(gy, dbias, wsf, Po, Cout, st, accumulate);
+        if (rc) return rc;
+    }
+    float* part = wsf + bias_grad_ws_floats(Cout);
+    k_sconv_wgrad<<<Cout * ks * ks * nsplit, 256, 256 * sizeof(float), st>>>(x, gy, part, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad,
+                                                                               nsplit);
+    VQW_LAUNCH_CHECK("vqw_sconv_wgrad");
+    return reduce_rows(part, dw_ohwi, (long)Cout * ks * ks * Cin, nsplit, st, accumulate);
+}
+
+extern "C" int vqw_leaky_relu_bwd(const float* y, const float* gy, float* gx, float slope, long n, void* stream) {
+    VQW_CHECK(y && gy && gx && n > 0, "vqw_leaky_relu_bwd: bad arguments");
+    k_leaky_bwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(y, gy, gx, slope, n);
+    VQW_LAUNCH_CHECK("vqw_leaky_relu_bwd");
+    return VQW_OK;
+}
+
+extern "C" int vqw_hinge_fwd(const float* x, long n, int mode, float* loss, void* stream) {
+    VQW_CHECK(x && loss && n > 0 && mode >= 0 && mode <= 2, "vqw_hinge_fwd: bad arguments");
+    k_hinge_fwd<<<1, 1024, 0, (hipStream_t)stream>>>(x, n, mode, loss);
+    VQW_LAUNCH_CHECK("vqw_hinge_fwd");
+    return VQW_OK;
+}
+extern "C" int vqw_hinge_bwd(const float* x, long n, int mode, const float* gloss, float* gx, void* stream) {
+    VQW_CHECK(x && gloss && gx && n > 0 && mode >= 0 && mode <= 2, "vqw_hinge_bwd: bad arguments");
+    k_hinge_bwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(x, n, mode, gloss, gx);
+    VQW_LAUNCH_CHECK("vqw_hinge_bwd");
+    return VQW_OK;
+}

@@ -643,3 +643,94 @@ extern "C" int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const
     VQW_LAUNCH_CHECK("vqw_spade_bwd_apply");
     return VQW_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d with per-channel affine + LeakyReLU (PatchGAN discriminator, networks/discriminator.py:66-78):
+//   y = lrelu(((x - mean) * rstd) * gamma + beta, slope)
+// Statistics come from vqw_bn_partial_stats / vqw_bn_finalize (running stats, SyncBN-able sums) like StyledDenorm.
+__global__ void k_bn_affine_fwd(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, long total, int C, float slope) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        float v = ((x[i] - mr[2 * c]) * mr[2 * c + 1]) * gamma[c] + beta[c];
+        y[i] = v > 0.f ? v : v * slope;
+    }
+}
+extern "C" int vqw_bn_affine_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, float* y, long P,
+                                 int C, float slope, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && y && P > 0 && C > 0, "vqw_bn_affine_fwd: bad arguments");
+    long total = P * C;
+    k_bn_affine_fwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, mean_rstd, gamma, beta, y, total, C, slope);
+    VQW_LAUNCH_CHECK("vqw_bn_affine_fwd");
+    return VQW_OK;
+}
+
+// backward phase 1: g' = gy * lrelu'(z); per-channel sums [sum g', sum g' * xhat]  (= dbeta, dgamma)
+struct FBnAffineBwd {
+    const float* x;
+    const float* mr;
+    const float* gamma;
+    const float* beta;
+    const float* gy;
+    float slope;
+    __device__ void operator()(long i, int, int c, float& a, float& b) const {
+        float xh = (x[i] - mr[2 * c]) * mr[2 * c + 1];
+        float z = xh * gamma[c] + beta[c];
+        float g = z > 0.f ? gy[i] : gy[i] * slope;
+        a = g;
+        b = g * xh;
+    }
+};
+extern "C" int vqw_bn_affine_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                                        const float* gy, double* sums, void* ws, size_t ws_bytes, int N, int HW, int C,
+                                        float slope, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && gy && sums && ws && N > 0 && HW > 0 && C > 0, "vqw_bn_affine_bwd_reduce: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_bn_affine_bwd_reduce: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = plane_splits(N, HW);
+    FBnAffineBwd f{x, mean_rstd, gamma, beta, gy, slope};
+    k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    VQW_LAUNCH_CHECK("vqw_bn_affine_bwd_reduce");
+    return VQW_OK;
+}
+
+// phase 2: dx = gamma * rstd * (g' - sum_g'/count - xhat * sum_g'xhat/count)  (training) or gamma * rstd * g' (eval);
+// dgamma / dbeta (accumulated into when acc != 0) are written by the first C threads
+__global__ void k_bn_affine_bwd_apply(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ gy,
+                                      const double* __restrict__ sums, double inv_count, float* __restrict__ gx,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta, long total, int C, float slope,
+                                      int training, int acc) {
+    long stride = (long)gridDim.x * blockDim.x;
+    long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 < C && dgamma) {
+        float dg = (float)sums[2 * i0 + 1], db = (float)sums[2 * i0];
+        dgamma[i0] = acc ? dgamma[i0] + dg : dg;
+        dbeta[i0] = acc ? dbeta[i0] + db : db;
+    }
+    for (long i = i0; i < total; i += stride) {
+        int c = (int)(i % C);
+        float r = mr[2 * c + 1];
+        float xh = (x[i] - mr[2 * c]) * r;
+        float z = xh * gamma[c] + beta[c];
+        float g = z > 0.f ? gy[i] : gy[i] * slope;
+        float v = g;
+        if (training) v = g - (float)(sums[2 * c] * inv_count) - xh * (float)(sums[2 * c + 1] * inv_count);
+        gx[i] = gamma[c] * r * v;
+    }
+}
+extern "C" int vqw_bn_affine_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
+                                       const float* gy, const double* sums, double count, float* gx, float* dgamma,
+                                       float* dbeta, long P, int C, float slope, int training, int accumulate, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && gy && sums && gx && P > 0 && C > 0 && count > 0, "vqw_bn_affine_bwd_apply: bad arguments");
+    VQW_CHECK((dgamma == nullptr) == (dbeta == nullptr), "vqw_bn_affine_bwd_apply: dgamma and dbeta go together");
+    long total = P * C;
+    int grid = stream_grid(total, 256);
+    if ((long)grid * 256 < C) grid = ceil_div(C, 256);
+    k_bn_affine_bwd_apply<<<grid, 256, 0, (hipStream_t)stream>>>(x, mean_rstd, gamma, beta, gy, sums, 1.0 / count, gx, dgamma, dbeta,
+                                                                 total, C, slope, training, accumulate);
+    VQW_LAUNCH_CHECK("vqw_bn_affine_bwd_apply");
+    return VQW_OK;
+}

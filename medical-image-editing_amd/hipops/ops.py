@@ -1031,6 +1031,159 @@ def gauss_blur(x, taps, apply=None):
     return y
 
 
+# ----------------------------------------------------------------------------------------------
+# second training step: PatchGAN discriminator pieces (strided conv, BatchNorm(affine)+LeakyReLU, hinge losses)
+# ----------------------------------------------------------------------------------------------
+class _SConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, slope):
+        _dev(x, weight, bias)
+        x, w = nhwc(x), nhwc(weight)
+        Cout, Cin, ks, _ = weight.shape
+        N, _, H, W = x.shape
+        if x.shape[1] != Cin:
+            raise RuntimeError("sconv2d: input has %d channels, weight expects %d" % (x.shape[1], Cin))
+        Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
+        if bias is not None:
+            bias = _flat(bias)
+        y = empty_nhwc(N, Cout, Ho, Wo, x)
+        _lib.check(_L().vqw_sconv_fwd(_p(x), _p(w), _p(bias), _p(y), N, H, W, Cin, Cout, ks, stride, pad, float(slope), _st()),
+                   "vqw_sconv_fwd")
+        ctx.save_for_backward(x, w, y if slope != 1.0 else None)
+        ctx.cfg = (stride, pad, float(slope), bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, slope, has_bias = ctx.cfg
+        L = _L()
+        gy = nhwc(gy)
+        Cout, Cin, ks, _ = w.shape
+        N, _, H, W = x.shape
+        if y is not None:
+            gm = torch.empty_like(y, memory_format=CL)
+            _lib.check(L.vqw_leaky_relu_bwd(_p(y), _p(gy), _p(gm), slope, gy.numel(), _st()), "vqw_leaky_relu_bwd")
+            gy = gm
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x, memory_format=CL)
+            _lib.check(L.vqw_sconv_dgrad(_p(gy), _p(w), _p(gx), N, H, W, Cin, Cout, ks, stride, pad, _st()), "vqw_sconv_dgrad")
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+            gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
+            ws = _ws(L.vqw_sconv_wgrad_ws_bytes(Cin, Cout, ks, N, H, W, stride, pad), gy)
+            _lib.check(L.vqw_sconv_wgrad(_p(x), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), N, H, W, Cin, Cout, ks, stride, pad, 0,
+                                         _st()), "vqw_sconv_wgrad")
+        return gx, gw, gb, None, None, None
+
+
+def sconv2d(x, weight, bias=None, stride=1, padding=0, slope=1.0):
+    """nn.Conv2d(k, stride in {1,2}, padding) with an optional LeakyReLU(slope) epilogue."""
+    return _SConv.apply(x, weight, bias, int(stride), int(padding), float(slope))
+
+
+class _BnLrelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, slope, sync):
+        _dev(x, gamma, beta)
+        x = nhwc(x)
+        gamma, beta = _flat(gamma), _flat(beta)
+        N, C, H, W = x.shape
+        L = _L()
+        mr = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+        count = float(N * H * W)
+        if training:
+            sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+            _lib.check(L.vqw_bn_partial_stats(_p(x), _p(sums), _p(ws), ws.numel(), N, H * W, C, _st()), "vqw_bn_partial_stats")
+            if sync and _dist_on():
+                dist.all_reduce(sums)
+                count *= dist.get_world_size()
+            cur = _order_begin(running_mean)
+            _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
+                       "vqw_bn_finalize")
+            if nbt is not None:
+                nbt.add_(1)
+            _order_end(running_mean, cur)
+        else:
+            _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
+        y = torch.empty_like(x, memory_format=CL)
+        _lib.check(L.vqw_bn_affine_fwd(_p(x), _p(mr), _p(gamma), _p(beta), _p(y), N * H * W, C, float(slope), _st()), "vqw_bn_affine_fwd")
+        ctx.save_for_backward(x, gamma, beta, mr)
+        ctx.cfg = (training, float(slope), count, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mr = ctx.saved_tensors
+        training, slope, count, sync = ctx.cfg
+        N, C, H, W = x.shape
+        L = _L()
+        gy = nhwc(gy)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
+        ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+        _lib.check(L.vqw_bn_affine_bwd_reduce(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(sums), _p(ws), ws.numel(), N, H * W, C,
+                                              slope, _st()), "vqw_bn_affine_bwd_reduce")
+        # dgamma / dbeta are this rank's sums (DDP averages parameter gradients); dx needs the global-batch sums
+        dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x, memory_format=CL)
+        if training and sync and _dist_on():
+            local = sums.clone()
+            dist.all_reduce(sums)
+            _lib.check(L.vqw_bn_affine_bwd_apply(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(sums), count, _p(gx), None, None,
+                                                 N * H * W, C, slope, 1, 0, _st()), "vqw_bn_affine_bwd_apply")
+            dbeta.copy_(local[0::2])
+            dgamma.copy_(local[1::2])
+        else:
+            _lib.check(L.vqw_bn_affine_bwd_apply(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(sums), count, _p(gx), _p(dgamma),
+                                                 _p(dbeta), N * H * W, C, slope, int(training), 0, _st()), "vqw_bn_affine_bwd_apply")
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def batch_norm_lrelu(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, slope=0.2, sync=True,
+                     num_batches_tracked=None):
+    """nn.BatchNorm2d (affine) followed by nn.LeakyReLU(slope) (slope = 1: plain BatchNorm)."""
+    return _BnLrelu.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), float(momentum),
+                          float(eps), float(slope), bool(sync))
+
+
+class _Hinge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        _dev(x)
+        x = x.contiguous() if not (x.is_contiguous() or x.is_contiguous(memory_format=CL)) else x
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        _lib.check(_L().vqw_hinge_fwd(_p(x), x.numel(), mode, _p(loss), _st()), "vqw_hinge_fwd")
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        g = g.contiguous().float()
+        _lib.check(_L().vqw_hinge_bwd(_p(x), x.numel(), ctx.mode, _p(g), _p(gx), _st()), "vqw_hinge_bwd")
+        return gx, None
+
+
+def hinge_real(logits):
+    """mean(relu(1 - logits)) (gan_loss.py:7)"""
+    return _Hinge.apply(logits, 0)
+
+
+def hinge_fake(logits):
+    """mean(relu(1 + logits)) (gan_loss.py:8)"""
+    return _Hinge.apply(logits, 1)
+
+
+def neg_mean(logits):
+    """-mean(logits): the generator loss (single_window_trainer.py:463)"""
+    return _Hinge.apply(logits, 2)
+
+
 def set_conv_backend(mode):
     """0 = auto (MFMA kernels where shapes allow), 1 = generic VALU kernels only (testing)."""
     return _L().vqw_set_conv_backend(int(mode))

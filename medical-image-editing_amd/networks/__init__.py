@@ -7,3 +7,4 @@ from .aspp import ASPP  # noqa: F401
 from .vq import VQ  # noqa: F401
 from .vqwnet import VQWNet  # noqa: F401
 from .random_transform import RandomTransform  # noqa: F401
+from .discriminator import NLayerDiscriminator  # noqa: F401

@@ -70,7 +70,12 @@ def load_reference():
     fn.embed_loss = _load("functions.embed_loss", "functions/embed_loss.py")
     fn.onehot = _load("functions.onehot", "functions/onehot.py")
     fn.seg_loss = _load("functions.seg_loss", "functions/seg_loss.py")
+    # second training step: PatchGAN discriminator + hinge loss
+    _load("networks.actnorm", "networks/actnorm.py")
+    nets.discriminator = _load("networks.discriminator", "networks/discriminator.py")
+    fn.gan_loss = _load("functions.gan_loss", "functions/gan_loss.py")
     return types.SimpleNamespace(
+        NLayerDiscriminator=nets.discriminator.NLayerDiscriminator, hinge_d_loss=fn.gan_loss.hinge_d_loss,
         blocks=nets.blocks, aspp=nets.aspp, vq_module=vqm,
         dropblock=sys.modules["networks.dropblock"],
         UNetEncoder=nets.unet_encoder.UNetEncoder,

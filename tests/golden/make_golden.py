@@ -340,7 +340,57 @@ def gen_extras():
     save("extras.npz", d)
 
 
+def gen_gan():
+    """Second training step pieces: the reference's NLayerDiscriminator (discriminator.py:18-87)
+    forward / backward in train and eval mode, hinge_d_loss (gan_loss.py:6-10), and the discriminator half of
+    _train_second_step_nl_dis (single_window_trainer.py:474-487) for two Adam steps."""
+    d = {}
+    torch.manual_seed(41)
+    dis = R.NLayerDiscriminator(in_channels=1, out_channels=1, n_filters=16, n_layers=3)
+    module_case("dis_f16", dis, [torch.randn(3, 1, 64, 64)], d)
+    torch.manual_seed(42)
+    dis2 = R.NLayerDiscriminator(in_channels=1, out_channels=1, n_filters=8, n_layers=2)
+    with torch.no_grad():                      # non-trivial running statistics for the eval case
+        for m in dis2.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    module_case("dis_f8_eval", dis2, [torch.randn(2, 1, 40, 48)], d, train=False)
+    # hinge loss values and gradients
+    torch.manual_seed(43)
+    lr_, lf_ = torch.randn(4, 1, 6, 6, requires_grad=True), torch.randn(4, 1, 6, 6, requires_grad=True)
+    l = R.hinge_d_loss(lr_, lf_)
+    (3.0 * l).backward()
+    d["hinge/real"], d["hinge/fake"], d["hinge/loss"] = npy(lr_), npy(lf_), npy(l)
+    d["hinge/g_real"], d["hinge/g_fake"] = npy(lr_.grad), npy(lf_.grad)
+    g = torch.randn(4, 1, 6, 6, requires_grad=True)
+    lg = -torch.mean(g)
+    (2.0 * lg).backward()
+    d["gen/x"], d["gen/loss"], d["gen/gx"] = npy(g), npy(lg), npy(g.grad)
+    # discriminator update loop: two steps of (real, fake) -> hinge -> Adam(lr 1e-3, betas (0.5, 0.999))
+    torch.manual_seed(44)
+    dis3 = R.NLayerDiscriminator(in_channels=1, out_channels=1, n_filters=8, n_layers=3)
+    dis3.train()
+    for k, v in dis3.state_dict().items():
+        d["dstep/P." + k] = npy(v).copy()
+    opt = torch.optim.Adam(dis3.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    for s in range(2):
+        real, fake = torch.randn(2, 1, 32, 32).clamp_(-1, 1), torch.randn(2, 1, 32, 32).clamp_(-1, 1)
+        l_dis = R.hinge_d_loss(dis3(real), dis3(fake))
+        opt.zero_grad()
+        (0.8 * l_dis).backward()
+        opt.step()
+        d["dstep/real%d" % s], d["dstep/fake%d" % s], d["dstep/loss%d" % s] = npy(real), npy(fake), npy(l_dis)
+    for k, v in dis3.state_dict().items():
+        d["dstep/after." + k] = npy(v).copy()
+    save("gan.npz", d)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gan":
+        gen_gan()
+        sys.exit(0)
+    gen_gan()
     gen_extras()
     gen_blocks()
     gen_vq()

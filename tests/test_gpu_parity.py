@@ -182,8 +182,8 @@ def test_maxpool_ties_route_to_first():
 # --------------------------------------------------------------------------------------------------
 # blocks against the reference's golden vectors
 # --------------------------------------------------------------------------------------------------
-def _run_block(golden, tag, mod, n_in, train=True, fwd_tol=1e-4, bwd_tol=1e-3):
-    g = golden("blocks.npz")
+def _run_block(golden, tag, mod, n_in, train=True, fwd_tol=1e-4, bwd_tol=1e-3, file="blocks.npz"):
+    g = golden(file)
     sd = {k[2:]: v for k, v in g.group(tag).items() if k.startswith("P.")}
     mod.load_state_dict(sd, strict=True)
     mod.to(DEV).train(train)
@@ -745,3 +745,101 @@ def test_random_transform_module_properties():
     out = tr.training_step({"image": img})
     assert torch.equal(img, keep)                                    # the batch is not modified in place
     assert np.isfinite(float(out["total"].detach()))
+
+
+# --------------------------------------------------------------------------------------------------
+# second training step: PatchGAN discriminator, hinge / generator losses, trainer
+# --------------------------------------------------------------------------------------------------
+def test_discriminator_golden(golden):
+    """networks.NLayerDiscriminator against the reference module's outputs, input / parameter gradients and updated
+    BatchNorm buffers (train mode) and against its eval-mode pass."""
+    from networks import NLayerDiscriminator
+    _run_block(golden, "dis_f16", NLayerDiscriminator(1, 1, n_filters=16, n_layers=3), 1, file="gan.npz")
+    _run_block(golden, "dis_f8_eval", NLayerDiscriminator(1, 1, n_filters=8, n_layers=2), 1, train=False, file="gan.npz")
+    with pytest.raises(NotImplementedError):
+        NLayerDiscriminator(normalization='instancenorm')
+
+
+def test_gan_losses_golden(golden):
+    from functions import hinge_d_loss, generator_loss
+    g = golden("gan.npz")
+    real = g.t("hinge/real", DEV).requires_grad_(True)
+    fake = g.t("hinge/fake", DEV).requires_grad_(True)
+    l = hinge_d_loss(real, fake)
+    (3.0 * l).backward()
+    assert_close(l, g["hinge/loss"], 1e-6, "hinge loss")
+    assert_close(real.grad, g["hinge/g_real"], 1e-6, "hinge g_real", atol=1e-9)
+    assert_close(fake.grad, g["hinge/g_fake"], 1e-6, "hinge g_fake", atol=1e-9)
+    x = g.t("gen/x", DEV).requires_grad_(True)
+    lg = generator_loss(x)
+    (2.0 * lg).backward()
+    assert_close(lg, g["gen/loss"], 1e-6, "generator loss", atol=1e-8)
+    assert_close(x.grad, g["gen/gx"], 1e-6, "generator gx")
+
+
+def test_discriminator_update_golden(golden):
+    """Two discriminator updates of _train_second_step_nl_dis (hinge on real / fake, Adam) against the reference run."""
+    from networks import NLayerDiscriminator
+    from functions import hinge_d_loss
+    from hipops import Adam, ops
+    g = golden("gan.npz")
+    dis = NLayerDiscriminator(1, 1, n_filters=8, n_layers=3)
+    dis.load_state_dict({k[2:]: v for k, v in g.group("dstep").items() if k.startswith("P.")}, strict=True)
+    dis.to(DEV).train()
+    opt = Adam(dis.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    for s in range(2):
+        l_dis = hinge_d_loss(dis(g.t("dstep/real%d" % s, DEV)), dis(g.t("dstep/fake%d" % s, DEV)))
+        assert_close(l_dis, g["dstep/loss%d" % s], 2e-4 if s else 1e-5, "l_dis step %d" % s)
+        opt.zero_grad()
+        ops.weighted_sum([l_dis], [0.8]).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    for k, v in dis.state_dict().items():
+        ref = g["dstep/after." + k]
+        if "num_batches" in k:
+            assert int(v) == int(ref)
+        else:
+            assert_close(v.float(), ref.astype(np.float32), 2e-3, "after." + k, atol=2e-4)
+
+
+def test_second_step_trainer_vs_oracle():
+    """SecondStepTrainer (frozen encoder -> decoder -> D; generator update, then discriminator update) against the
+    oracle's restatement of single_window_trainer.py:434-488 from the same initial state."""
+    from oracle import vqwnet_ref as O
+    from oracle import gan_ref as G
+    from networks import UNetEncoder, UNetDecoder, NLayerDiscriminator
+    from trainers import SecondStepTrainer, GanLossWeights
+    torch.manual_seed(3)
+    ef, df, K = [8, 8, 16, 16, 16], [8, 16, 16, 16, 32], 6
+    enc = UNetEncoder(1, ef, K, 0.99, 'torch', False, 1, True)
+    dec = UNetDecoder(ef[0], 1, df, use_dropblock=False, dropped_skip_layers=[], use_styled_up_block=True, use_pixel_shuffle=False)
+    dis = NLayerDiscriminator(1, 1, n_filters=8, n_layers=3)
+    PE = {k: v.clone().contiguous() for k, v in enc.state_dict().items()}
+    PD = {k: v.clone().contiguous() for k, v in dec.state_dict().items()}
+    PS = {k: v.clone().contiguous() for k, v in dis.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    image = (torch.rand(2, 1, 32, 32, generator=g) * 2 - 1)
+    w = GanLossWeights(recon=1.0, gen=0.1, dis=0.8)
+    tr = SecondStepTrainer(enc, dec, dis, loss_weight=w, n_inner_loops=1, lr=1e-3, device=DEV)
+    out = tr.training_step(image.to(DEV))
+    # oracle
+    for k in O.trainable_keys(PD):
+        PD[k].requires_grad_(True)
+    for k in [k for k, v in PS.items() if v.is_floating_point() and "running" not in k]:
+        PS[k].requires_grad_(True)
+    with torch.no_grad():
+        e, _, ids, _ = O.encoder_forward(PE, image, False, 0.99)
+    rec = O.decoder_forward(PD, e.detach(), True, 4)
+    l_rec = F.mse_loss(rec, image)
+    l_gen = G.generator_loss(G.discriminator_forward(PS, rec, True))
+    assert torch.equal(out["ids"].cpu(), ids)
+    assert_close(out["recon"], l_rec, 2e-5, "l_recon")
+    assert_close(out["gen"], l_gen, 2e-4, "l_gen", atol=1e-6)
+    assert_close(out["recon_image"], rec, 2e-4, "recon", atol=1e-5)
+    gen_total = w.recon * l_rec + w.gen * l_gen
+    grads = torch.autograd.grad(gen_total, [PD[k] for k in O.trainable_keys(PD)])
+    # discriminator loss of the inner loop: D saw recon once already (running stats updated), decoder weights moved
+    # after the generator update only affect the NEXT step, recon is the pre-update tensor (recon.detach())
+    l_dis = G.hinge_d_loss(G.discriminator_forward(PS, image, True), G.discriminator_forward(PS, rec.detach(), True))
+    assert_close(out["dis_total"], w.dis * l_dis, 2e-4, "l_dis_total")
+    assert len(grads) > 0 and np.isfinite(float(out["gen_total"].detach()))

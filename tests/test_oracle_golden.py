@@ -274,3 +274,32 @@ def test_extras(golden):
     assert_close(out["commit_loss"], g["vqwnet/commit"], 1e-4, "vqwnet commit")
     keep = O.dropblock_mask(g.t("dropblock/seed"), 4)
     assert_close(O.dropblock_apply(g.t("dropblock/x"), keep), g["dropblock/y"], 1e-6, "dropblock apply")
+
+
+def test_gan_oracle(golden):
+    """oracle/gan_ref.py against the reference's NLayerDiscriminator / hinge_d_loss vectors (tests/golden/gan.npz)."""
+    from oracle import gan_ref as G
+    g = golden("gan.npz")
+    for tag, nl, train in (("dis_f16", 3, True), ("dis_f8_eval", 2, False)):
+        P = {k[2:]: v.clone() for k, v in g.group(tag).items() if k.startswith("P.")}
+        fl = [k for k, v in P.items() if v.is_floating_point() and "running" not in k]
+        for k in fl:
+            P[k].requires_grad_(True)
+        x = g.t(tag + "/in.0").requires_grad_(True)
+        y = G.discriminator_forward(P, x, train, n_layers=nl)
+        (y * g.t(tag + "/R.0")).sum().backward()
+        assert_close(y, g[tag + "/out.0"], 1e-5, tag + " out")
+        assert_close(x.grad, g[tag + "/gin.0"], 1e-4, tag + " gin", atol=1e-7)
+        for k in fl:
+            assert_close(P[k].grad, g["%s/gP.%s" % (tag, k)], 1e-4, "%s gP.%s" % (tag, k), atol=1e-6)
+        for k in P:
+            key = "%s/after.%s" % (tag, k)
+            if key in g.files:
+                assert_close(P[k].detach().float(), g[key].astype(np.float32), 1e-5, key)
+    real, fake = g.t("hinge/real").requires_grad_(True), g.t("hinge/fake").requires_grad_(True)
+    l = G.hinge_d_loss(real, fake)
+    (3.0 * l).backward()
+    assert_close(l, g["hinge/loss"], 1e-6, "hinge")
+    assert_close(real.grad, g["hinge/g_real"], 1e-6, "hinge g_real", atol=1e-9)
+    x = g.t("gen/x")
+    assert_close(G.generator_loss(x), g["gen/loss"], 1e-6, "gen loss", atol=1e-8)
