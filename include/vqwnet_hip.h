@@ -213,10 +213,12 @@ int vqw_gauss_blur(const float* x, const float* taps /*[K]*/, const unsigned cha
  * functions/gan_loss.py:6-10, trainers/single_window_trainer.py:434-488).  NHWC activations, OHWI weights
  * [Cout][k][k][Cin]; output size floor((H + 2 pad - k) / stride) + 1; stride 1 or 2; H, W are INPUT dims.
  * sconv_fwd applies LeakyReLU(slope) in the epilogue (slope = 1: none). */
-int vqw_sconv_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
-                  int ks, int stride, int pad, float slope, void* stream);
-int vqw_sconv_dgrad(const float* gy, const float* w_ohwi, float* gx, int N, int H, int W, int Cin, int Cout, int ks,
-                    int stride, int pad, void* stream);
+size_t vqw_sconv_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad);
+int vqw_sconv_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, void* ws, size_t ws_bytes, int N, int H,
+                  int W, int Cin, int Cout, int ks, int stride, int pad, float slope, void* stream);
+size_t vqw_sconv_dgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad);
+int vqw_sconv_dgrad(const float* gy, const float* w_ohwi, float* gx, void* ws, size_t ws_bytes, int N, int H, int W, int Cin,
+                    int Cout, int ks, int stride, int pad, void* stream);
 size_t vqw_sconv_wgrad_ws_bytes(int Cin, int Cout, int ks, int N, int H, int W, int stride, int pad);
 int vqw_sconv_wgrad(const float* x, const float* gy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes, int N, int H,
                     int W, int Cin, int Cout, int ks, int stride, int pad, int accumulate, void* stream);

@@ -49,6 +49,23 @@ size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc);
 
+// 4x4 padding-1 convolutions of the PatchGAN discriminator on the MFMA kernels (conv_mfma.hip; callers in gan.hip)
+bool conv_k4_mfma_ok(int Cin, int Cout, long P);
+int conv_k4s2_fwd(const float* x_high, const float* w, const float* bias, float* y_low, int N, int h, int w_, int Cin, int Cout,
+                  hipStream_t st);
+size_t conv_k4s2_dgrad_ws_floats(int Cin, int Cout);
+int conv_k4s2_dgrad(const float* gy_low, const float* w, float* ws, float* gx_high, int N, int h, int w_, int Cin, int Cout,
+                    hipStream_t st);
+bool conv_k4s2_wgrad_ok(int Cin, int Cout, int N, int h, int w);
+size_t conv_k4s2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w);
+int conv_k4s2_wgrad(const float* x_high, const float* gy_low, float* dw, float* ws, int N, int h, int w, int Cin, int Cout, int acc,
+                    hipStream_t st);
+int conv_k4s1_grid(const float* src, const float* w16, const float* bias, float* dst, int N, int H, int W, int Csrc, int Cdst,
+                   int tap0, hipStream_t st);
+size_t conv_k4s1_wgrad_ws_floats(int Cin, int Cout, long P);
+int conv_k4s1_wgrad_grid(const float* x, const float* dy_grid, float* dw, float* ws, int N, int H, int W, int Cin, int Cout, int acc,
+                         hipStream_t st);
+
 // thin-channel streams (conv_thin.hip): 1-channel stem, 1-channel 1x1 head
 bool conv_stem_ok(const ConvIn& in, int Cout, int ks);
 int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,

@@ -61,7 +61,7 @@ __global__ void k_pack_dgrad(const float* __restrict__ w, float* __restrict__ wt
     }
 }
 extern "C" int vqw_pack_dgrad_weights(const float* w_ohwi, float* wt, int Cout, int Cin, int ksize, void* stream) {
-    VQW_CHECK(w_ohwi && wt && Cout > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "vqw_pack_dgrad_weights: bad arguments");
+    VQW_CHECK(w_ohwi && wt && Cout > 0 && Cin > 0 && ksize >= 1 && ksize <= 7, "vqw_pack_dgrad_weights: bad arguments");
     long total = (long)Cout * ksize * ksize * Cin;
     k_pack_dgrad<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(w_ohwi, wt, Cout, Cin, ksize * ksize);
     VQW_LAUNCH_CHECK("vqw_pack_dgrad_weights");

@@ -277,12 +277,13 @@ static inline bool fits_u32(long P, int Cin, int Cout) {
     return P * c * 4 <= 0xFFFFFFE0L;
 }
 
-static ConvGeom plain_geom(int ks, int dil) {
+static ConvGeom plain_geom(int ks, int dil, int tap0 = -1) {
+    if (tap0 < 0) tap0 = ks / 2;
     ConvGeom g{};
     g.ntaps = ks * ks;
     for (int t = 0; t < ks * ks; ++t) {
-        g.dy[t] = (signed char)((t / ks - ks / 2) * dil);
-        g.dx[t] = (signed char)((t % ks - ks / 2) * dil);
+        g.dy[t] = (signed char)((t / ks - tap0) * dil);
+        g.dx[t] = (signed char)((t % ks - tap0) * dil);
     }
     return g;
 }
@@ -402,6 +403,61 @@ int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h
     return dispatch_fwd(in, ws + 16L * Cout * Cin, nullptr, dx_low, N, h, w, Cin, g, 0, st);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 4x4, padding 1 convolutions of the PatchGAN discriminator (gan.hip) on the kernels above.
+//   stride 2, forward:  M grid = the (h, w) output, source = the (2h, 2w) input, 16 taps at (2y + ky - 1, 2x + kx - 1):
+//                       the geometry of the collapsed dgrad (src_mode 2); weights are the OHWI 4x4 kernel as it is.
+//   stride 2, dgrad:    a transposed 4x4 stride-2 conv = four 2x2 convs by output parity = the collapsed forward
+//                       (out_mode 1) with weights re-ordered by k_pack_k4s2_dgrad.
+//   stride 1 (on a common H x W grid; the caller pads / crops the (H-1) x (W-1) side):  16-tap table with origin 1
+//                       (forward) or 2 with flipped taps (dgrad).
+__global__ void k_pack_k4s2_dgrad(const float* __restrict__ w, float* __restrict__ wc, int Cout, int Cin) {
+    // wc[py*2+px][ci][a*2+b][co] = w[co][ky(py,a)][kx(px,b)][ci],  ky(0,0)=3 ky(0,1)=1 ky(1,0)=2 ky(1,1)=0
+    long total = 16L * Cin * Cout;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int co = (int)(i % Cout);
+        long r = i / Cout;
+        int ab = (int)(r % 4); r /= 4;
+        int ci = (int)(r % Cin);
+        int par = (int)(r / Cin);
+        int py = par >> 1, px = par & 1, a = ab >> 1, b = ab & 1;
+        int ky = 3 - py - 2 * a, kx = 3 - px - 2 * b;
+        wc[i] = w[(((long)co * 4 + ky) * 4 + kx) * Cin + ci];
+    }
+}
+bool conv_k4_mfma_ok(int Cin, int Cout, long P) { return (Cin % 4 == 0) && (Cout % 4 == 0) && Cin >= 8 && Cout >= 8 && fits_u32(4 * P, Cin, Cout); }
+int conv_k4s2_fwd(const float* x_high, const float* w, const float* bias, float* y_low, int N, int h, int w_, int Cin, int Cout,
+                  hipStream_t st) {
+    ConvIn in{x_high, nullptr, Cin, 0, 0};
+    ConvGeom g{};
+    g.ntaps = 16;
+    g.src_mode = 2;
+    for (int rs = 0; rs < 16; ++rs) {
+        g.dy[rs] = (signed char)((rs >> 2) - 1);
+        g.dx[rs] = (signed char)((rs & 3) - 1);
+    }
+    return dispatch_fwd(in, w, bias, y_low, N, h, w_, Cout, g, 0, st);
+}
+size_t conv_k4s2_dgrad_ws_floats(int Cin, int Cout) { return (size_t)16 * Cin * Cout; }
+int conv_k4s2_dgrad(const float* gy_low, const float* w, float* ws, float* gx_high, int N, int h, int w_, int Cin, int Cout,
+                    hipStream_t st) {
+    long n = 16L * Cin * Cout;
+    k_pack_k4s2_dgrad<<<stream_grid(n, 256), 256, 0, st>>>(w, ws, Cout, Cin);
+    VQW_LAUNCH_CHECK("pack_k4s2_dgrad");
+    ConvIn in{gy_low, nullptr, Cout, 0, 0};
+    ConvGeom g{};
+    g.ntaps = 4;
+    g.out_mode = 1;
+    return dispatch_fwd(in, ws, nullptr, gx_high, N, h, w_, Cin, g, 0, st);
+}
+// stride 1 on a common grid: x, y (or gy, gx) are both N x H x W maps; tap0 = 1 forward, 2 for the flipped dgrad weights
+int conv_k4s1_grid(const float* src, const float* w16, const float* bias, float* dst, int N, int H, int W, int Csrc, int Cdst,
+                   int tap0, hipStream_t st) {
+    ConvIn in{src, nullptr, Csrc, 0, 0};
+    return dispatch_fwd(in, w16, bias, dst, N, H, W, Cdst, plain_geom(4, 1, tap0), 0, st);
+}
+
 // 0 = auto, 1 = per-tap kernel only, (testing / A-B timing)
 int g_wgrad_variant = 0;
 
@@ -411,7 +467,7 @@ int g_wgrad_variant = 0;
 template <int BM, int BN, int WM, int WN, int KP>
 __global__ void __launch_bounds__(64 * (BM / WM) * (BN / WN))
 k_conv_mfma_wgrad(ConvIn in, const float* __restrict__ dy, float* __restrict__ part, int N, int H, int W, int Cout, int ks,
-                  int dil, int ntm, int ntn, long per_split) {
+                  int dil, int ntm, int ntn, long per_split, int tap0) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int NT = 64 * NW;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -425,7 +481,7 @@ k_conv_mfma_wgrad(ConvIn in, const float* __restrict__ dy, float* __restrict__ p
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int Cin = in.C0 + in.C1;
-    const int taps = ks * ks, half = ks >> 1;
+    const int taps = ks * ks, half = tap0;          // tap (ky, kx) reads pixel offset (ky - tap0, kx - tap0) * dil
     const long P = (long)N * H * W;
     const int Hs = H >> 1, Ws = W >> 1;
 
@@ -939,6 +995,45 @@ int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, 
     return VQW_OK;
 }
 
+// 4x4 stride-2 pad-1 weight gradient (PatchGAN): dW[co][ky][kx][ci] = sum dYlow[y, x][co] * Xhigh[2y + ky - 1, 2x + kx - 1][ci]
+// is the G matrix set of the kernel above with the roles swapped (Xhigh in the "dY" slot, dYlow in the "Xlow" slot):
+// slab[split][py][ci][px*4 + a*2 + b][co] with ky = 3 - py - 2a, kx = 3 - px - 2b.
+__global__ void __launch_bounds__(256) k_reduce_wg_k4s2(const float* __restrict__ part, float* __restrict__ dw, int Cout, int Cin,
+                                                         int nsplits, int acc) {
+    const long n = (long)Cout * 16 * Cin;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int ci = (int)(i % Cin);
+        const long r = i / Cin;
+        const int t = (int)(r % 16), co = (int)(r / 16);
+        const int ky = t >> 2, kx = t & 3;
+        const int py = (ky & 1) ? 0 : 1, a = ky >= 2 ? 0 : 1;
+        const int px = (kx & 1) ? 0 : 1, b = kx >= 2 ? 0 : 1;
+        float v = 0.f;
+        for (int s = 0; s < nsplits; ++s) v += part[((((long)s * 2 + py) * Cin + ci) * 8 + px * 4 + a * 2 + b) * Cout + co];
+        dw[i] = acc ? dw[i] + v : v;
+    }
+}
+bool conv_k4s2_wgrad_ok(int Cin, int Cout, int N, int h, int w) { return conv_up2_wgrad_ok(Cout, Cin, N, h, w); }
+size_t conv_k4s2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) { return conv_up2_wgrad_ws_floats(Cout, Cin, N, h, w); }
+int conv_k4s2_wgrad(const float* x_high, const float* gy_low, float* dw, float* ws, int N, int h, int w, int Cin, int Cout, int acc,
+                    hipStream_t st) {
+    const long Plow = (long)N * h * w;
+    const int cin_r = Cout, cout_r = Cin;                 // roles inside k_conv_wgrad_up
+    const int n_ci_t = ceil_div(cin_r, 32), ntiles = ceil_div(cout_r, 32) * n_ci_t;
+    const int nsb = wgup_split_blocks(cin_r, cout_r, Plow);
+    const unsigned nbx = (unsigned)(Plow * cin_r * 4), nbd = (unsigned)(4 * Plow * cout_r * 4);
+    k_conv_wgrad_up<<<ntiles * 2 * nsb, 256, 0, st>>>(gy_low, x_high, ws, nullptr, N, h, w, cin_r, cout_r, n_ci_t, ntiles, nsb, nbx, nbd);
+    VQW_LAUNCH_CHECK("conv_wgrad_up(k4s2)");
+    const long n = (long)Cout * 16 * Cin;
+    k_reduce_wg_k4s2<<<stream_grid(n, 256), 256, 0, st>>>(ws, dw, Cout, Cin, nsb * 4, acc);
+    VQW_LAUNCH_CHECK("reduce_wg_k4s2");
+    return VQW_OK;
+}
+// 4x4 stride-1 weight gradient on a common N x H x W grid (dy zero-padded to the grid by the caller)
+int conv_k4s1_wgrad_grid(const float* x, const float* dy_grid, float* dw, float* ws, int N, int H, int W, int Cin, int Cout, int acc,
+                         hipStream_t st);
+
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks) {
     (void)ks;
     int Cin = in.C0 + in.C1;
@@ -965,7 +1060,8 @@ size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P) {
 
 template <int BM, int BN, int KP>
 static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, int ks, int dil,
-                        hipStream_t st, int acc) {
+                        hipStream_t st, int acc, int tap0 = -1) {
+    if (tap0 < 0) tap0 = ks >> 1;
     constexpr int WM = BM > 64 ? 64 : BM, WN = BN > 64 ? 64 : BN;
     constexpr int NT = 64 * (BM / WM) * (BN / WN);
     const int Cin = in.C0 + in.C1;
@@ -977,7 +1073,7 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
     const long nout = (long)Cout * ks * ks * Cin;
     float* part = (splits > 1 || acc) ? ws : dw;
     k_conv_mfma_wgrad<BM, BN, WM, WN, KP><<<ntm * ntn * ks * ks * splits, NT, 0, st>>>(in, dy, part, N, H, W, Cout, ks, dil,
-                                                                                         ntm, ntn, per);
+                                                                                         ntm, ntn, per, tap0);
     VQW_LAUNCH_CHECK("conv_mfma_wgrad");
     if (splits > 1 || acc) return reduce_rows(ws, dw, nout, splits, st, acc);
     return VQW_OK;
@@ -1055,5 +1151,26 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
     WG_CASE(128, 128, 32);
 #undef WG_CASE
     vqw_set_error("conv_mfma_wgrad: no tile configuration");
+    return VQW_ERR_ARG;
+}
+
+size_t conv_k4s1_wgrad_ws_floats(int Cin, int Cout, long P) { return (size_t)wgrad_splits(Cin, Cout, 4, P) * Cout * 16 * Cin; }
+int conv_k4s1_wgrad_grid(const float* x, const float* dy_grid, float* dw, float* ws, int N, int H, int W, int Cin, int Cout, int acc,
+                         hipStream_t st) {
+    ConvIn in{x, nullptr, Cin, 0, 0};
+    const int bm = wg_tile(Cout), bn = wg_tile(Cin);
+#define WG_CASE(M_, N_, K_) \
+    if (bm == M_ && bn == N_) return launch_wgrad<M_, N_, K_>(in, dy_grid, dw, ws, N, H, W, Cout, 4, 1, st, acc, 1)
+    WG_CASE(32, 32, 32);
+    WG_CASE(32, 64, 32);
+    WG_CASE(64, 32, 32);
+    WG_CASE(64, 64, 32);
+    WG_CASE(32, 128, 32);
+    WG_CASE(128, 32, 32);
+    WG_CASE(64, 128, 32);
+    WG_CASE(128, 64, 32);
+    WG_CASE(128, 128, 32);
+#undef WG_CASE
+    vqw_set_error("conv_k4s1_wgrad_grid: no tile configuration");
     return VQW_ERR_ARG;
 }

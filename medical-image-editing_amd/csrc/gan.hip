@@ -2,9 +2,11 @@
 // functions/gan_loss.py:6-10, trainers/single_window_trainer.py:434-488): 4x4 convolutions with stride 1 or 2 and
 // padding 1, BatchNorm2d (affine) + LeakyReLU(0.2), hinge / generator losses.  NHWC activations, OHWI weights.
 //
-// The strided convolutions here are direct VALU kernels (any kernel size / stride / padding): the discriminator is
-// ~6 GFLOP per image and call against ~245 for one W-Net view; routing its three wide layers onto the MFMA kernels
-// (the stride-2 gather is the geometry conv_mfma.hip already runs for the collapsed dgrad) is the listed next step.
+// The wide layers (64->128, 128->256 stride 2; 256->512 stride 1) run on the exact-fp32 MFMA kernels of conv_mfma.hip:
+// the stride-2 gather is the geometry of the collapsed dgrad, its transpose the collapsed forward, its weight gradient
+// the parity/tap matrices of the collapsed wgrad with the roles swapped; the stride-1 layers run on a common H x W grid
+// with a 16-tap table (this file pads / crops the (H-1) x (W-1) side).  The 1-channel ends (1->64, 512->1) and any
+// other shape use the direct VALU kernels below (any kernel size / stride / padding).
 #include "common.h"
 #include "conv_common.h"
 #include "../../include/vqwnet_hip.h"
@@ -146,7 +148,32 @@ __global__ void k_hinge_bwd(const float* __restrict__ x, long n, int mode, const
     }
 }
 
+// dst[n, y, x, :] = src[n, y, x, :] inside the source frame, 0 outside: crops (Hd < Hs) or zero-pads (Hd > Hs)
+__global__ void k_crop_pad(const float* __restrict__ src, float* __restrict__ dst, long total, int Hs, int Ws, int Hd, int Wd, int C) {
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int c = (int)(i % C);
+        long p = i / C;
+        int x = (int)(p % Wd);
+        long q = p / Wd;
+        int y = (int)(q % Hd);
+        long n = q / Hd;
+        dst[i] = (y < Hs && x < Ws) ? src[((n * Hs + y) * Ws + x) * C + c] : 0.f;
+    }
+}
+int crop_pad(const float* src, float* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, hipStream_t st) {
+    long total = (long)N * Hd * Wd * C;
+    k_crop_pad<<<stream_grid(total, 256), 256, 0, st>>>(src, dst, total, Hs, Ws, Hd, Wd, C);
+    VQW_LAUNCH_CHECK("crop_pad");
+    return VQW_OK;
+}
+
 int out_dim(int n, int ks, int stride, int pad) { return (n + 2 * pad - ks) / stride + 1; }
+// which 4x4 layers go to the MFMA kernels
+bool k4_mfma(int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad) {
+    if (ks != 4 || pad != 1 || !conv_k4_mfma_ok(Cin, Cout, (long)N * H * W)) return false;
+    return stride == 1 ? (H >= 4 && W >= 4) : (H % 2 == 0 && W % 2 == 0);
+}
 int wgrad_splits(long Po) {
     long s = Po / 4096;
     return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
@@ -161,35 +188,75 @@ static int check_sconv(const char* who, int N, int H, int W, int Cin, int Cout, 
     return VQW_OK;
 }
 
-extern "C" int vqw_sconv_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, int N, int H, int W, int Cin,
-                             int Cout, int ks, int stride, int pad, float slope, void* stream) {
+extern "C" size_t vqw_sconv_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return (k4_mfma(N, H, W, Cin, Cout, ks, stride, pad) && stride == 1) ? (size_t)N * H * W * Cout * sizeof(float) : 0;
+}
+extern "C" int vqw_sconv_fwd(const float* x, const float* w_ohwi, const float* bias, float* y, void* ws, size_t ws_bytes, int N,
+                             int H, int W, int Cin, int Cout, int ks, int stride, int pad, float slope, void* stream) {
     int rc = check_sconv("vqw_sconv_fwd", N, H, W, Cin, Cout, ks, stride, pad);
     if (rc) return rc;
     VQW_CHECK(x && w_ohwi && y, "vqw_sconv_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
     const int Ho = out_dim(H, ks, stride, pad), Wo = out_dim(W, ks, stride, pad);
+    if (slope == 1.f && k4_mfma(N, H, W, Cin, Cout, ks, stride, pad)) {
+        if (stride == 2) return conv_k4s2_fwd(x, w_ohwi, bias, y, N, Ho, Wo, Cin, Cout, st);
+        VQW_CHECK(ws && ws_bytes >= vqw_sconv_fwd_ws_bytes(N, H, W, Cin, Cout, ks, stride, pad), "vqw_sconv_fwd: workspace too small");
+        rc = conv_k4s1_grid(x, w_ohwi, bias, (float*)ws, N, H, W, Cin, Cout, 1, st);       // on the H x W grid ...
+        if (rc) return rc;
+        return crop_pad((const float*)ws, y, N, H, W, Ho, Wo, Cout, st);                  // ... cropped to (H-1) x (W-1)
+    }
     long total = (long)N * Ho * Wo * Cout;
-    k_sconv_fwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, w_ohwi, bias, y, N, H, W, Ho, Wo, Cin, Cout, ks, stride,
-                                                                          pad, slope);
+    k_sconv_fwd<<<stream_grid(total, 256), 256, 0, st>>>(x, w_ohwi, bias, y, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad, slope);
     VQW_LAUNCH_CHECK("vqw_sconv_fwd");
     return VQW_OK;
 }
 
-extern "C" int vqw_sconv_dgrad(const float* gy, const float* w_ohwi, float* gx, int N, int H, int W, int Cin, int Cout, int ks,
-                               int stride, int pad, void* stream) {
+extern "C" size_t vqw_sconv_dgrad_ws_bytes(int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad) {
+    if (N <= 0 || H <= 0 || W <= 0 || !k4_mfma(N, H, W, Cin, Cout, ks, stride, pad)) return 0;
+    size_t fl = (size_t)16 * Cin * Cout;                             // re-ordered weights
+    if (stride == 1) fl += (size_t)N * H * W * Cout;                 // gy zero-padded to the H x W grid
+    return fl * sizeof(float);
+}
+extern "C" int vqw_sconv_dgrad(const float* gy, const float* w_ohwi, float* gx, void* ws, size_t ws_bytes, int N, int H, int W,
+                               int Cin, int Cout, int ks, int stride, int pad, void* stream) {
     int rc = check_sconv("vqw_sconv_dgrad", N, H, W, Cin, Cout, ks, stride, pad);
     if (rc) return rc;
     VQW_CHECK(gy && w_ohwi && gx, "vqw_sconv_dgrad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
     const int Ho = out_dim(H, ks, stride, pad), Wo = out_dim(W, ks, stride, pad);
+    if (k4_mfma(N, H, W, Cin, Cout, ks, stride, pad)) {
+        VQW_CHECK(ws && ws_bytes >= vqw_sconv_dgrad_ws_bytes(N, H, W, Cin, Cout, ks, stride, pad), "vqw_sconv_dgrad: workspace too small");
+        float* wsf = (float*)ws;
+        if (stride == 2) return conv_k4s2_dgrad(gy, w_ohwi, wsf, gx, N, Ho, Wo, Cin, Cout, st);
+        float* gpad = wsf + (size_t)16 * Cin * Cout;
+        rc = vqw_pack_dgrad_weights(w_ohwi, wsf, Cout, Cin, 4, stream);                   // wt[ci][15 - t][co]
+        if (rc) return rc;
+        rc = crop_pad(gy, gpad, N, Ho, Wo, H, W, Cout, st);
+        if (rc) return rc;
+        return conv_k4s1_grid(gpad, wsf, nullptr, gx, N, H, W, Cout, Cin, 2, st);
+    }
     long total = (long)N * H * W * Cin;
-    k_sconv_dgrad<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(gy, w_ohwi, gx, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad);
+    k_sconv_dgrad<<<stream_grid(total, 256), 256, 0, st>>>(gy, w_ohwi, gx, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad);
     VQW_LAUNCH_CHECK("vqw_sconv_dgrad");
     return VQW_OK;
 }
 
+static bool k4_mfma_wgrad(int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad) {
+    if (!k4_mfma(N, H, W, Cin, Cout, ks, stride, pad)) return false;
+    return stride == 1 || conv_k4s2_wgrad_ok(Cin, Cout, N, H / 2, W / 2);
+}
 extern "C" size_t vqw_sconv_wgrad_ws_bytes(int Cin, int Cout, int ks, int N, int H, int W, int stride, int pad) {
     if (N <= 0 || H <= 0 || W <= 0 || ks <= 0 || stride <= 0) return 0;
     const long Po = (long)N * out_dim(H, ks, stride, pad) * out_dim(W, ks, stride, pad);
-    return ((size_t)wgrad_splits(Po) * Cout * ks * ks * Cin + bias_grad_ws_floats(Cout)) * sizeof(float);
+    size_t fl = bias_grad_ws_floats(Cout);
+    if (k4_mfma_wgrad(N, H, W, Cin, Cout, ks, stride, pad)) {
+        if (stride == 2) fl += conv_k4s2_wgrad_ws_floats(Cin, Cout, N, H / 2, W / 2);
+        else fl += (size_t)N * H * W * Cout + conv_k4s1_wgrad_ws_floats(Cin, Cout, (long)N * H * W);
+    } else {
+        fl += (size_t)wgrad_splits(Po) * Cout * ks * ks * Cin;
+    }
+    return fl * sizeof(float);
 }
 
 extern "C" int vqw_sconv_wgrad(const float* x, const float* gy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes, int N,
@@ -201,13 +268,20 @@ extern "C" int vqw_sconv_wgrad(const float* x, const float* gy, float* dw_ohwi, 
     hipStream_t st = (hipStream_t)stream;
     const int Ho = out_dim(H, ks, stride, pad), Wo = out_dim(W, ks, stride, pad);
     const long Po = (long)N * Ho * Wo;
-    const int nsplit = wgrad_splits(Po);
     float* wsf = (float*)ws;
     if (dbias) {
         rc = bias_grad(gy, dbias, wsf, Po, Cout, st, accumulate);
         if (rc) return rc;
     }
     float* part = wsf + bias_grad_ws_floats(Cout);
+    if (k4_mfma_wgrad(N, H, W, Cin, Cout, ks, stride, pad)) {
+        if (stride == 2) return conv_k4s2_wgrad(x, gy, dw_ohwi, part, N, Ho, Wo, Cin, Cout, accumulate, st);
+        float* gpad = part;
+        rc = crop_pad(gy, gpad, N, Ho, Wo, H, W, Cout, st);
+        if (rc) return rc;
+        return conv_k4s1_wgrad_grid(x, gpad, dw_ohwi, part + (size_t)N * H * W * Cout, N, H, W, Cin, Cout, accumulate, st);
+    }
+    const int nsplit = wgrad_splits(Po);
     k_sconv_wgrad<<<Cout * ks * ks * nsplit, 256, 256 * sizeof(float), st>>>(x, gy, part, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad,
                                                                                nsplit);
     VQW_LAUNCH_CHECK("vqw_sconv_wgrad");

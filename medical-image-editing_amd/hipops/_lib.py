@@ -76,8 +76,10 @@ SIGNATURES = {
     "vqw_warp_labels": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p]),
     "vqw_photometric": (c_i, [c_p, c_p, c_p, c_p, c_i, c_l, c_p]),
     "vqw_gauss_blur": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "vqw_sconv_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
-    "vqw_sconv_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_sconv_fwd_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "vqw_sconv_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "vqw_sconv_dgrad_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "vqw_sconv_dgrad": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_sconv_wgrad_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "vqw_sconv_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_leaky_relu_bwd": (c_i, [c_p, c_p, c_p, c_f, c_l, c_p]),

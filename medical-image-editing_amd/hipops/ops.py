@@ -1047,8 +1047,10 @@ class _SConv(torch.autograd.Function):
         if bias is not None:
             bias = _flat(bias)
         y = empty_nhwc(N, Cout, Ho, Wo, x)
-        _lib.check(_L().vqw_sconv_fwd(_p(x), _p(w), _p(bias), _p(y), N, H, W, Cin, Cout, ks, stride, pad, float(slope), _st()),
-                   "vqw_sconv_fwd")
+        L = _L()
+        ws = _ws(L.vqw_sconv_fwd_ws_bytes(N, H, W, Cin, Cout, ks, stride, pad), x)
+        _lib.check(L.vqw_sconv_fwd(_p(x), _p(w), _p(bias), _p(y), _p(ws), ws.numel(), N, H, W, Cin, Cout, ks, stride, pad,
+                                   float(slope), _st()), "vqw_sconv_fwd")
         ctx.save_for_backward(x, w, y if slope != 1.0 else None)
         ctx.cfg = (stride, pad, float(slope), bias is not None)
         return y
@@ -1068,7 +1070,9 @@ class _SConv(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x, memory_format=CL)
-            _lib.check(L.vqw_sconv_dgrad(_p(gy), _p(w), _p(gx), N, H, W, Cin, Cout, ks, stride, pad, _st()), "vqw_sconv_dgrad")
+            ws = _ws(L.vqw_sconv_dgrad_ws_bytes(N, H, W, Cin, Cout, ks, stride, pad), gy)
+            _lib.check(L.vqw_sconv_dgrad(_p(gy), _p(w), _p(gx), _p(ws), ws.numel(), N, H, W, Cin, Cout, ks, stride, pad, _st()),
+                       "vqw_sconv_dgrad")
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
             gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None

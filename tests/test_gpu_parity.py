@@ -843,3 +843,45 @@ def test_second_step_trainer_vs_oracle():
     l_dis = G.hinge_d_loss(G.discriminator_forward(PS, image, True), G.discriminator_forward(PS, rec.detach(), True))
     assert_close(out["dis_total"], w.dis * l_dis, 2e-4, "l_dis_total")
     assert len(grads) > 0 and np.isfinite(float(out["gen_total"].detach()))
+
+
+SCONV_CASES = [
+    # N, H, W, Cin, Cout, ks, stride, pad, bias, slope
+    (2, 32, 32, 16, 32, 4, 2, 1, True, 1.0),      # MFMA: stride-2 gather / transposed conv / swapped-role parity wgrad
+    (2, 64, 32, 64, 128, 4, 2, 1, False, 1.0),
+    (3, 16, 16, 32, 16, 4, 1, 1, False, 1.0),     # MFMA: stride 1 on the common grid (pad / crop)
+    (2, 9, 12, 16, 48, 4, 1, 1, True, 1.0),
+    (2, 32, 32, 1, 8, 4, 2, 1, True, 0.2),        # direct kernels: 1-channel ends, LeakyReLU epilogue
+    (2, 17, 16, 16, 1, 4, 1, 1, True, 1.0),
+    (1, 30, 30, 16, 32, 4, 2, 1, False, 0.2),     # slope in the epilogue keeps the direct kernel
+    (2, 11, 13, 3, 5, 3, 2, 1, True, 1.0),        # another kernel size, odd sizes
+    (1, 16, 16, 8, 12, 4, 2, 1, True, 1.0),       # low-res width 8: stride-2 wgrad falls back to the direct kernel
+]
+
+
+@pytest.mark.parametrize("case", SCONV_CASES)
+def test_sconv2d(case):
+    ops = _ops()
+    N, H, W, Cin, Cout, ks, stride, pad, bias, slope = case
+    g = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(N, Cin, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g, dtype=torch.float64) * 0.2
+    b = torch.randn(Cout, generator=g, dtype=torch.float64) if bias else None
+    rx, rw = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    rb = b.clone().requires_grad_(True) if bias else None
+    yref = F.leaky_relu(F.conv2d(rx, rw, rb, stride=stride, padding=pad), slope) if slope != 1.0 else F.conv2d(rx, rw, rb, stride=stride, padding=pad)
+    r = torch.randn(yref.shape, generator=g, dtype=torch.float64)
+    (yref * r).sum().backward()
+    dx = x.float().to(DEV).requires_grad_(True)
+    dw = w.float().to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    db = b.float().to(DEV).requires_grad_(True) if bias else None
+    y = ops.sconv2d(dx, dw, db, stride=stride, padding=pad, slope=slope)
+    assert tuple(y.shape) == tuple(yref.shape)
+    (y * r.float().to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    tol = 2e-5
+    assert_close(y, yref, tol, "y")
+    assert_close(dx.grad, rx.grad, tol, "dx")
+    assert_close(dw.grad, rw.grad, tol, "dw")
+    if bias:
+        assert_close(db.grad, rb.grad, tol, "db")
