@@ -118,6 +118,47 @@ __global__ void __launch_bounds__(256) k_sconv_wgrad(const float* __restrict__ x
     }
 }
 
+// weight gradient of a 1-input-channel layer (the discriminator's first conv): lanes over (co, 4 pixel lanes); per pixel
+// the Cout gradients are one coalesced row and the k*k input taps are wave-uniform scalars.  partial[split][co][tap]
+template <int TAPS>
+__global__ void __launch_bounds__(256) k_sconv_wgrad_c1(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        float* __restrict__ part, int N, int H, int W, int Ho, int Wo, int Cout,
+                                                        int ks, int stride, int pad, int nsplit) {
+    __shared__ float red[256 * TAPS];
+    const int cl = Cout < 256 ? Cout : 256;            // lanes over co (Cout <= 256 and a divisor of 256)
+    const int lanes_p = 256 / cl;
+    const int co = threadIdx.x % cl, lp = threadIdx.x / cl;
+    const long Po = (long)N * Ho * Wo;
+    const long per = (Po + nsplit - 1) / nsplit;
+    const long p0 = blockIdx.x * per, p1 = p0 + per < Po ? p0 + per : Po;
+    float acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
+    for (long p = p0 + lp; p < p1; p += lanes_p) {
+        int xo = (int)(p % Wo);
+        long q = p / Wo;
+        int yo = (int)(q % Ho);
+        int n = (int)(q / Ho);
+        const float g = gy[p * Cout + co];
+        const float* img = x + (long)n * H * W;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            int hy = yo * stride - pad + t / ks, wx = xo * stride - pad + t % ks;
+            float v = ((unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W) ? img[(long)hy * W + wx] : 0.f;
+            acc[t] = fmaf(g, v, acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) red[(lp * TAPS + t) * cl + co] = acc[t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < cl * TAPS; i += 256) {
+        int c = i % cl, t = i / cl;
+        float s = 0.f;
+        for (int k = 0; k < lanes_p; ++k) s += red[(k * TAPS + t) * cl + c];
+        part[((long)blockIdx.x * Cout + c) * TAPS + t] = s;
+    }
+}
+
 __global__ void k_leaky_bwd(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, float slope, long n) {
     long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) gx[i] = y[i] > 0.f ? gy[i] : gy[i] * slope;
@@ -175,8 +216,13 @@ bool k4_mfma(int N, int H, int W, int Cin, int Cout, int ks, int stride, int pad
     return stride == 1 ? (H >= 4 && W >= 4) : (H % 2 == 0 && W % 2 == 0);
 }
 int wgrad_splits(long Po) {
-    long s = Po / 4096;
-    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+    long s = Po / 512;
+    return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+bool wgrad_c1_ok(int Cin, int Cout, int ks) { return Cin == 1 && ks == 4 && Cout <= 256 && 256 % Cout == 0; }
+int wgrad_c1_splits(long Po) {
+    long s = Po / 1024;
+    return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
 }
 
 }  // namespace
@@ -253,6 +299,8 @@ extern "C" size_t vqw_sconv_wgrad_ws_bytes(int Cin, int Cout, int ks, int N, int
     if (k4_mfma_wgrad(N, H, W, Cin, Cout, ks, stride, pad)) {
         if (stride == 2) fl += conv_k4s2_wgrad_ws_floats(Cin, Cout, N, H / 2, W / 2);
         else fl += (size_t)N * H * W * Cout + conv_k4s1_wgrad_ws_floats(Cin, Cout, (long)N * H * W);
+    } else if (wgrad_c1_ok(Cin, Cout, ks)) {
+        fl += (size_t)wgrad_c1_splits(Po) * Cout * ks * ks;
     } else {
         fl += (size_t)wgrad_splits(Po) * Cout * ks * ks * Cin;
     }
@@ -280,6 +328,12 @@ extern "C" int vqw_sconv_wgrad(const float* x, const float* gy, float* dw_ohwi, 
         rc = crop_pad(gy, gpad, N, Ho, Wo, H, W, Cout, st);
         if (rc) return rc;
         return conv_k4s1_wgrad_grid(x, gpad, dw_ohwi, part + (size_t)N * H * W * Cout, N, H, W, Cin, Cout, accumulate, st);
+    }
+    if (wgrad_c1_ok(Cin, Cout, ks)) {
+        const int ns = wgrad_c1_splits(Po);
+        k_sconv_wgrad_c1<16><<<ns, 256, 0, st>>>(x, gy, part, N, H, W, Ho, Wo, Cout, ks, stride, pad, ns);
+        VQW_LAUNCH_CHECK("vqw_sconv_wgrad(c1)");
+        return reduce_rows(part, dw_ohwi, (long)Cout * 16, ns, st, accumulate);
     }
     const int nsplit = wgrad_splits(Po);
     k_sconv_wgrad<<<Cout * ks * ks * nsplit, 256, 256 * sizeof(float), st>>>(x, gy, part, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad,

@@ -38,10 +38,19 @@ class SecondStepTrainer:
             embed, _, ids = self.encoder(image)
         recon = self.decoder(embed.detach())
         l_recon = ops.mse_loss(recon, image)
-        l_gen = generator_loss(self.dis(recon))
-        l_gen_total = ops.weighted_sum([l_recon, l_gen], [w.recon, w.gen])
-        self.dec_optim.zero_grad()
-        l_gen_total.backward()
+        # The reference lets autograd fill the discriminator's parameter gradients in this pass and discards them
+        # (dis_optim.zero_grad() below); they are not computed here.  Same decoder gradients, same update.
+        dis_params = [p for p in self.dis.parameters() if p.requires_grad]
+        for p in dis_params:
+            p.requires_grad_(False)
+        try:
+            l_gen = generator_loss(self.dis(recon))
+            l_gen_total = ops.weighted_sum([l_recon, l_gen], [w.recon, w.gen])
+            self.dec_optim.zero_grad()
+            l_gen_total.backward()
+        finally:
+            for p in dis_params:
+                p.requires_grad_(True)
         ops.join_streams()
         self.dec_optim.step()
         l_dis_total = None
