@@ -885,3 +885,33 @@ def test_sconv2d(case):
     assert_close(dw.grad, rw.grad, tol, "dw")
     if bias:
         assert_close(db.grad, rb.grad, tol, "db")
+
+
+def test_recon_from_checkpoint_and_nifti(tmp_path):
+    """SURVEY §8f rank 3: Lightning-style checkpoint -> load_model -> edited NIfTI label map -> reconstruction file;
+    equals the in-memory reconstruct() of the same models."""
+    from collections import namedtuple
+    import run_recon as RR
+    from networks import UNetEncoder, UNetDecoder
+    from utils.checkpoint import save_lightning_style_ckpt
+    torch.manual_seed(5)
+    ef, df, K = [8, 8, 16, 16, 16], [8, 16, 16, 16, 32], 6
+    enc = UNetEncoder(1, ef, K, 0.99, 'torch', False, 1, False)
+    dec = UNetDecoder(ef[0], 1, df, use_dropblock=False, dropped_skip_layers=[], use_styled_up_block=True, use_pixel_shuffle=False)
+    ckpt = str(tmp_path / "first_stage.ckpt")
+    save_lightning_style_ckpt(ckpt, enc, dec)
+    Cfg = namedtuple("Cfg", "in_channels enc_filters dec_filters dict_size momentum knn_backend use_dropblock block_size "
+                            "start_value stop_value nr_steps dropped_skip_layers use_pixel_shuffle resume_checkpoint")
+    cfg = Cfg(1, ef, df, K, 0.99, 'torch', False, 30, 0.1, 0.5, 20, [], False, ckpt)
+    e2, d2 = RR.load_model(cfg, device=DEV)
+    g = torch.Generator().manual_seed(2)
+    label = torch.randint(0, K + 1, (32, 32), generator=g)
+    edited = str(tmp_path / "edited.nii")
+    RR.save_as_nifti(label.float(), edited)
+    out = str(tmp_path / "recon.nii")
+    rec = RR.reconstruct_file(e2, d2, edited, out_nifti=out, device=DEV)
+    ref = RR.reconstruct(enc.to(DEV), dec.to(DEV), label.unsqueeze(0).to(DEV))[0, 0].cpu().numpy()
+    assert rec.shape == (32, 32) and np.array_equal(rec, ref)
+    assert np.allclose(RR.load_from_nifti(out), ref)
+    win = RR.reconstruct_file(e2, d2, edited, window=(2000, 0, 2.0), device=DEV)
+    assert np.allclose(win, RR.normalize(RR.denormalize(ref, 2000, 0, 2.0), **RR.LUNG_WINDOW))

@@ -165,3 +165,92 @@ def test_data_parallel_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_nifti_roundtrip_and_header(tmp_path):
+    """utils/nifti.py (stands in for nibabel in the reference's run_recon I/O): header fields per the NIfTI-1 layout,
+    Fortran-order payload, round trips for the dtypes the path uses, gzip, scaling."""
+    import struct
+    from utils import nifti
+    a = (np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4) - 5.5)
+    p = str(tmp_path / "a.nii")
+    nifti.save(a, p)
+    raw = open(p, "rb").read()
+    assert len(raw) == 352 + a.size * 4
+    assert struct.unpack_from("<i", raw, 0)[0] == 348 and raw[344:348] == b"n+1\x00"
+    assert struct.unpack_from("<8h", raw, 40) == (3, 2, 3, 4, 1, 1, 1, 1)
+    assert struct.unpack_from("<h", raw, 70)[0] == 16 and struct.unpack_from("<h", raw, 72)[0] == 32       # float32
+    assert struct.unpack_from("<f", raw, 108)[0] == 352.0
+    assert np.array_equal(np.frombuffer(raw, "<f4", offset=352)[:3], a.ravel(order="F")[:3])             # x fastest
+    back, aff = nifti.load(p)
+    assert back.dtype == np.float64 and np.array_equal(back, a.astype(np.float64)) and np.array_equal(aff, np.eye(4))
+    for dt in (np.int16, np.int32, np.uint8, np.float64):
+        b = (np.arange(12).reshape(3, 4) % 7).astype(dt)
+        q = str(tmp_path / ("b_%s.nii.gz" % np.dtype(dt).name))
+        nifti.save(b, q, affine=np.diag([2.0, 3.0, 1.0, 1.0]))
+        back, aff = nifti.load(q)
+        assert np.array_equal(back, b.astype(np.float64)) and np.allclose(np.diag(aff), [2, 3, 1, 1])
+    # scl_slope / scl_inter are honoured like nibabel's get_fdata
+    buf = bytearray(open(p, "rb").read())
+    struct.pack_into("<2f", buf, 112, 2.0, 1.0)
+    open(p, "wb").write(bytes(buf))
+    assert np.allclose(nifti.load(p)[0], a * 2.0 + 1.0)
+    with pytest.raises(ValueError):
+        open(p, "wb").write(b"\x00" * 400)
+        nifti.load(p)
+
+
+def test_checkpoint_wire_format(tmp_path):
+    """Lightning-style checkpoints (trainers/base.py:85-113, run_recon.py:98-112): prefixes encoder. / decoder. / dis.,
+    plain contiguous tensors; encoder strict, decoder strict=False; init_from_ckpt's key filter."""
+    from networks import UNetEncoder, UNetDecoder, NLayerDiscriminator
+    from utils.checkpoint import (load_first_stage_from_ckpt, load_discriminator_from_ckpt, init_from_ckpt,
+                                  save_lightning_style_ckpt)
+    torch.manual_seed(1)
+    mk_e = lambda: UNetEncoder(1, [4, 8, 8, 8, 8], 6, 0.99, 'torch', False, 1, True)  # noqa: E731
+    mk_d = lambda: UNetDecoder(4, 1, [4, 8, 8, 8, 8], use_dropblock=False, dropped_skip_layers=[], use_styled_up_block=True,  # noqa: E731
+                               use_pixel_shuffle=False)
+    e0, d0, s0 = mk_e(), mk_d(), NLayerDiscriminator(1, 1, n_filters=8, n_layers=2)
+    with torch.no_grad():
+        e0.vq.cluster_size.uniform_(1, 5)
+        for m in list(d0.modules()) + list(s0.modules()):
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.5, 2)
+    path = str(tmp_path / "epoch=3.ckpt")
+    save_lightning_style_ckpt(path, e0, d0, s0, extra={"epoch": 3, "global_step": 1234})
+    sd = torch.load(path, map_location="cpu")["state_dict"]
+    assert all(k.split(".")[0] in ("encoder", "decoder", "dis") for k in sd) and all(v.is_contiguous() for v in sd.values())
+    e1, d1, s1 = mk_e(), mk_d(), NLayerDiscriminator(1, 1, n_filters=8, n_layers=2)
+    load_first_stage_from_ckpt(path, e1, d1)
+    load_discriminator_from_ckpt(path, s1)
+    for a, b in ((e0, e1), (d0, d1), (s0, s1)):
+        for (k, v), (k2, v2) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert k == k2 and torch.equal(v, v2), k
+    assert d1.up_conv2_4.conv1.weight.is_contiguous(memory_format=torch.channels_last)      # layout kept on load
+    e2, d2 = mk_e(), mk_d()
+    init_from_ckpt(path, e2, 'encoder', 'encoder.')
+    init_from_ckpt(path, d2, 'decoder', 'decoder.')
+    assert torch.equal(e2.vq.cluster_size, e0.vq.cluster_size)
+    assert torch.equal(d2.conv1x1.weight, d0.conv1x1.weight)
+    e3 = mk_e()
+    load_first_stage_from_ckpt(path, e3, None, load_only_enc=True)
+    assert torch.equal(e3.vq.embed, e0.vq.embed)
+    with pytest.raises(RuntimeError):                     # encoder is loaded strictly
+        load_first_stage_from_ckpt(path, UNetEncoder(1, [4, 8, 8, 8, 16], 6, 0.99, 'torch', False, 1, True))
+
+
+def test_recon_file_helpers(tmp_path):
+    """save_as_nifti / load_from_nifti keep the reference's orientation convention (run_recon.py:83-95) and invert
+    each other; window helpers match utils/__init__.py:17-51."""
+    import run_recon as RR
+    a = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    p = str(tmp_path / "m.nii")
+    RR.save_as_nifti(a, p)
+    from utils import nifti
+    stored, _ = nifti.load(p)
+    assert np.array_equal(stored, a.numpy().T[::-1, ::-1])
+    assert np.array_equal(RR.load_from_nifti(p), a.numpy())
+    x = np.array([-1.0, 0.0, 1.0])
+    hu = RR.denormalize(x, 1500, -550, 2.0)
+    assert np.allclose(hu, [-1300.0, -550.0, 200.0]) and np.allclose(RR.normalize(hu, **RR.LUNG_WINDOW), x)
