@@ -3,64 +3,38 @@ import torch
 import torch.nn as nn
 
 from hipops import ops
-from .blocks import ResBlock, DoubleConv, StyledResUpBlock, Conv2d
+from .blocks import DoubleConv, StyledResUpBlock, Conv2d
+from ._unet import add_half, level_modules
 from .dropblock import LinearScheduler, DropBlock2D
 from .initialize import init_weights
 from .aspp import ASPP
 
 
 class UNetDecoder(nn.Module):
+    """Constructor arguments as unet_decoder.py:21-34: in_channels, out_channels, filters, use_dropblock, block_size,
+    start_value, stop_value, nr_steps, dropped_skip_layers, use_styled_up_block, use_pixel_shuffle,
+    use_last_pixel_shuffle."""
 
-    def __init__(self,
-                 in_channels: int,
-                 out_channels: int,
-                 filters: list = [64, 128, 256, 512, 1024],
-                 use_dropblock: bool = False,
-                 block_size: int = 30,
-                 start_value: float = 0.3,
-                 stop_value: float = 0.9,
-                 nr_steps: int = 100,
-                 dropped_skip_layers: list = [5, 6],
-                 use_styled_up_block: bool = True,
-                 use_pixel_shuffle: bool = True,
-                 use_last_pixel_shuffle: bool = False,
-                 ):
+    def __init__(self, in_channels, out_channels, filters=[64, 128, 256, 512, 1024], use_dropblock=False, block_size=30,
+                 start_value=0.3, stop_value=0.9, nr_steps=100, dropped_skip_layers=[5, 6], use_styled_up_block=True,
+                 use_pixel_shuffle=True, use_last_pixel_shuffle=False):
         super().__init__()
         assert use_styled_up_block
         if use_last_pixel_shuffle:
             raise NotImplementedError("use_last_pixel_shuffle heads are not built (off by default upstream)")
         self.use_last_pixel_shuffle = use_last_pixel_shuffle
         self.dropped_skip_layers = dropped_skip_layers
+        self.dropblock = (LinearScheduler(DropBlock2D(block_size=block_size, drop_prob=start_value), start_value=start_value,
+                                          stop_value=stop_value, nr_steps=nr_steps) if use_dropblock else (lambda t: t))
+        f = list(filters)
 
-        if use_dropblock:
-            self.dropblock = LinearScheduler(
-                DropBlock2D(block_size=block_size, drop_prob=start_value),
-                start_value=start_value, stop_value=stop_value, nr_steps=nr_steps)
-        else:
-            self.dropblock = lambda x: x
-
-        n = len(filters) - 1
-        self.down_convs = []
-        for i in range(n):
-            block = ResBlock(in_channels if i == 0 else filters[i - 1], filters[i])
-            self.add_module('down_conv2_{}'.format(i + 1), block)
-            self.down_convs.append(block)
-
-        self.double_conv2 = DoubleConv(filters[n - 1], filters[n])
-
-        self.up_convs = []
-        for i in reversed(range(n)):
-            block = StyledResUpBlock(filters[i + 1], filters[i], filters[i], use_pixel_shuffle=use_pixel_shuffle)
-            self.add_module('up_conv2_{}'.format(i + 1), block)
-            self.up_convs.append(block)
-
-        init_weights(self, 'kaiming')
-
-        self.conv_last = nn.Sequential(
-            ASPP(filters[0], filters[0], [2, 6, 12, 18]),
-            DoubleConv(5 * filters[0], filters[0]),
-        )
-        self.conv1x1 = Conv2d(filters[0], out_channels, kernel_size=1)
+        def up_block(k):        # level k: f[k] channels coming up, f[k-1] skip channels as the SPADE style input
+            return StyledResUpBlock(f[k], f[k - 1], f[k - 1], use_pixel_shuffle=use_pixel_shuffle)
+        n = add_half(self, 2, in_channels, f, up_block)
+        self.down_convs, _, self.up_convs = level_modules(self, 2, n)      # plain lists, as upstream keeps them
+        init_weights(self, 'kaiming')      # upstream initialises here: the head below keeps the default initialisation
+        self.conv_last = nn.Sequential(ASPP(f[0], f[0], [2, 6, 12, 18]), DoubleConv(5 * f[0], f[0]))
+        self.conv1x1 = Conv2d(f[0], out_channels, kernel_size=1)
         self.final_act = nn.Tanh()
 
     @property

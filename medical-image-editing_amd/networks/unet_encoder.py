@@ -4,49 +4,29 @@ import torch.nn as nn
 
 from hipops import ops
 from .vq import VQ
-from .blocks import ResBlock, UpBlock, DoubleConv, StyledResUpBlock
+from .blocks import UpBlock, StyledResUpBlock
+from ._unet import add_half, run_half
 from .initialize import init_weights
 
 
 class UNetEncoder(nn.Module):
+    """in_channels, filters, dict_size, momentum, knn_backend, use_styled_up_block, num_gpus, init_embed: the reference's
+    constructor (unet_encoder.py:18-27), positionally compatible."""
 
-    def __init__(self,
-                 in_channels: int,
-                 filters: list = [64, 128, 256, 512, 1024],
-                 dict_size: int = 512,
-                 momentum: float = 0.99,
-                 knn_backend: str = 'torch',
-                 use_styled_up_block: bool = False,
-                 num_gpus: int = 4,
-                 init_embed: bool = False,
-                 ):
+    def __init__(self, in_channels, filters=[64, 128, 256, 512, 1024], dict_size=512, momentum=0.99, knn_backend='torch',
+                 use_styled_up_block=False, num_gpus=4, init_embed=False):
         super().__init__()
-        self.dict_size = dict_size
-        self.init_embed = init_embed
+        self.dict_size, self.init_embed, self.num_gpus = dict_size, init_embed, num_gpus
         self.dims = filters[0]
-        self.num_gpus = num_gpus
+        f = list(filters)
 
-        self.down_conv1_1 = ResBlock(in_channels, filters[0])
-        self.down_conv1_2 = ResBlock(filters[0], filters[1])
-        self.down_conv1_3 = ResBlock(filters[1], filters[2])
-        self.down_conv1_4 = ResBlock(filters[2], filters[3])
-
-        self.double_conv1 = DoubleConv(filters[3], filters[4])
-
-        if use_styled_up_block:
-            self.up_conv1_4 = StyledResUpBlock(filters[4], filters[3], filters[3])
-            self.up_conv1_3 = StyledResUpBlock(filters[3], filters[2], filters[2])
-            self.up_conv1_2 = StyledResUpBlock(filters[2], filters[1], filters[1])
-            self.up_conv1_1 = StyledResUpBlock(filters[0], filters[0], filters[0])
-        else:
-            self.up_conv1_4 = UpBlock(filters[3] + filters[4], filters[3])
-            self.up_conv1_3 = UpBlock(filters[2] + filters[3], filters[2])
-            self.up_conv1_2 = UpBlock(filters[1] + filters[2], filters[1])
-            self.up_conv1_1 = UpBlock(filters[1] + filters[0], filters[0])
-
-        self.vq = VQ(emb_dim=filters[0], dict_size=self.dict_size, momentum=momentum, eps=1e-5,
-                     knn_backend=knn_backend)
-
+        def up_block(k):
+            if not use_styled_up_block:
+                return UpBlock(f[k - 1] + f[k], f[k - 1])          # concat [up(x) | skip]
+            # the reference feeds level 1 with filters[0] channels (unet_encoder.py:45)
+            return StyledResUpBlock(f[k] if k > 1 else f[0], f[k - 1], f[k - 1])
+        self._levels = add_half(self, 1, in_channels, f, up_block)
+        self.vq = VQ(emb_dim=f[0], dict_size=dict_size, momentum=momentum, eps=1e-5, knn_backend=knn_backend)
         init_weights(self, 'kaiming')
 
     @property
@@ -61,16 +41,7 @@ class UNetEncoder(nn.Module):
                            "encoder.vq.embed and pass init_embed=True (config use_init_embed falsy)")
 
     def feature_extraction(self, x):
-        x, skip1 = self.down_conv1_1(x)
-        x, skip2 = self.down_conv1_2(x)
-        x, skip3 = self.down_conv1_3(x)
-        x, skip4 = self.down_conv1_4(x)
-        x = self.double_conv1(x)
-        x = self.up_conv1_4(x, skip4)
-        x = self.up_conv1_3(x, skip3)
-        x = self.up_conv1_2(x, skip2)
-        x = self.up_conv1_1(x, skip1)
-        return x
+        return run_half(self, 1, self._levels, x)
 
     def forward(self, x, skip_vq=False, rank=False):
         x = self.feature_extraction(x)
