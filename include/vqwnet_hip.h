@@ -237,6 +237,13 @@ int vqw_bn_affine_bwd_apply(const float* x, const float* mean_rstd, const float*
 int vqw_hinge_fwd(const float* x, long n, int mode, float* loss, void* stream);
 int vqw_hinge_bwd(const float* x, long n, int mode, const float* gloss, float* gx, void* stream);
 
+/* ---- multi-window reconstruction loss (trainers/multi_window_trainer.py:93-109, base.py:290-314):
+ * mean((w(a) - w(b))^2) with w(x) = clamp(alpha * x + beta, lo, hi); gradient w.r.t. a (zero where clamped). */
+int vqw_window_mse_fwd(const float* a, const float* b, float* loss, void* ws, size_t ws_bytes, long n, float alpha,
+                       float beta, float lo, float hi, void* stream);
+int vqw_window_mse_bwd(const float* a, const float* b, const float* gloss, float* ga, long n, float alpha, float beta,
+                       float lo, float hi, void* stream);
+
 /* ---- optimiser: torch.optim.Adam as built in trainers/base.py:165-175 */
 int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,

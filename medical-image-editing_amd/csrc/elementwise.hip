@@ -210,6 +210,57 @@ extern "C" int vqw_mse_bwd(const float* a, const float* b, const float* gloss, f
     return VQW_OK;
 }
 
+// Windowed MSE (trainers/multi_window_trainer.py:93-109 with base.py:290-314): both tensors are re-windowed before the
+// squared error, w(x) = clamp(alpha * x + beta, lo, hi) — the reference's denormalize (dataset window) followed by
+// normalize (lung / mediastinal window) folded into one affine map and one clamp.  Gradient is zero where clamped.
+__device__ __forceinline__ float win_map(float x, float alpha, float beta, float lo, float hi) {
+    return fminf(fmaxf(alpha * x + beta, lo), hi);
+}
+__global__ void k_window_mse_partial(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ part, long n,
+                                     float alpha, float beta, float lo, float hi) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float d = win_map(a[i], alpha, beta, lo, hi) - win_map(b[i], alpha, beta, lo, hi);
+        acc += (double)(d * d);
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+extern "C" int vqw_window_mse_fwd(const float* a, const float* b, float* loss, void* ws, size_t ws_bytes, long n, float alpha,
+                                  float beta, float lo, float hi, void* stream) {
+    VQW_CHECK(a && b && loss && ws && n > 0 && lo <= hi, "vqw_window_mse_fwd: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_reduce_ws_bytes(n), "vqw_window_mse_fwd: workspace too small");
+    int g = imin(RED_BLOCKS, stream_grid(n, 256));
+    k_window_mse_partial<<<g, 256, 0, (hipStream_t)stream>>>(a, b, (double*)ws, n, alpha, beta, lo, hi);
+    k_sum_finalize<<<1, 256, 0, (hipStream_t)stream>>>((const double*)ws, g, 1.0 / (double)n, loss);
+    VQW_LAUNCH_CHECK("vqw_window_mse_fwd");
+    return VQW_OK;
+}
+__global__ void k_window_mse_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gl,
+                                 float* __restrict__ ga, long n, float inv_n2, float alpha, float beta, float lo, float hi) {
+    float s = gl[0] * inv_n2 * alpha;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float z = alpha * a[i] + beta;
+        float d = fminf(fmaxf(z, lo), hi) - win_map(b[i], alpha, beta, lo, hi);
+        ga[i] = (z > lo && z < hi) ? d * s : 0.f;
+    }
+}
+extern "C" int vqw_window_mse_bwd(const float* a, const float* b, const float* gloss, float* ga, long n, float alpha, float beta,
+                                  float lo, float hi, void* stream) {
+    VQW_CHECK(a && b && gloss && ga && n > 0, "vqw_window_mse_bwd: bad arguments");
+    k_window_mse_bwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, gloss, ga, n, 2.0f / (float)n, alpha, beta, lo, hi);
+    VQW_LAUNCH_CHECK("vqw_window_mse_bwd");
+    return VQW_OK;
+}
+
 __global__ void k_weighted_sum(const float* const* __restrict__ terms, const float* __restrict__ w, int n, float* __restrict__ out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float s = 0.f;

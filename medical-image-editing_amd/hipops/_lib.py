@@ -88,6 +88,8 @@ SIGNATURES = {
     "vqw_bn_affine_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_d, c_p, c_p, c_p, c_l, c_i, c_f, c_i, c_i, c_p]),
     "vqw_hinge_fwd": (c_i, [c_p, c_l, c_i, c_p, c_p]),
     "vqw_hinge_bwd": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
+    "vqw_window_mse_fwd": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_l, c_f, c_f, c_f, c_f, c_p]),
+    "vqw_window_mse_bwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p]),
     "vqw_pixel_shuffle2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_dropblock_mask": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_dropblock_apply": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_p]),

@@ -773,6 +773,49 @@ def mse_loss(a, b):
     return _Mse.apply(a, b.detach())
 
 
+class _WindowMse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta, lo, hi):
+        _dev(a, b)
+        a, b = nhwc(a), nhwc(b)
+        if a.shape != b.shape:
+            raise RuntimeError("window_mse_loss: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        L = _L()
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = _ws(L.vqw_reduce_ws_bytes(a.numel()), a)
+        _lib.check(L.vqw_window_mse_fwd(_p(a), _p(b), _p(out), _p(ws), ws.numel(), a.numel(), alpha, beta, lo, hi, _st()),
+                   "vqw_window_mse_fwd")
+        ctx.save_for_backward(a, b)
+        ctx.win = (alpha, beta, lo, hi)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a, memory_format=CL)
+        _lib.check(_L().vqw_window_mse_bwd(_p(a), _p(b), _p(g.contiguous()), _p(ga), a.numel(), *ctx.win, _st()), "vqw_window_mse_bwd")
+        return ga, None, None, None, None, None
+
+
+def window_map(dataset_window, target_window):
+    """(alpha, beta, lo, hi) of w(x) = normalize(denormalize(x, dataset window), target window) for x in the dataset's
+    normalised units (utils/__init__.py:17-51 as used by trainers/base.py:290-314); windows are (width, center, scale)."""
+    w0, c0, s0 = dataset_window
+    w1, c1, s1 = target_window
+    vmax0, vmin0 = c0 + w0 // 2, c0 - w0 // 2
+    vmax1, vmin1 = c1 + w1 // 2, c1 - w1 // 2
+    # hu = (x / s0 + 0.5) * (vmax0 - vmin0) + vmin0 ;  y = ((clip(hu) - vmin1) / (vmax1 - vmin1) - 0.5) * s1
+    a_hu, b_hu = (vmax0 - vmin0) / s0, 0.5 * (vmax0 - vmin0) + vmin0
+    k = s1 / (vmax1 - vmin1)
+    alpha, beta = a_hu * k, (b_hu - vmin1) * k - 0.5 * s1
+    return float(alpha), float(beta), float(-0.5 * s1), float(0.5 * s1)
+
+
+def window_mse_loss(a, b, dataset_window, target_window):
+    """F.mse_loss(to_window(a), to_window(b)): the lung / mediastinal terms of the multi-window reconstruction loss."""
+    return _WindowMse.apply(a, b.detach(), *window_map(dataset_window, target_window))
+
+
 class _WeightedSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *terms):

@@ -55,11 +55,16 @@ class RandomTransformViews:
         return other.forward_transform(own.reverse_transform(ids))
 
 
+LUNG_WINDOW = (1500, -550, 2.0)             # trainers/base.py:33-43
+MEDIASTINAL_WINDOW = (400, 20, 2.0)
+
+
 class FirstStepTrainer:
     def __init__(self, in_channels=1, enc_filters=(16, 32, 64, 128, 256), dec_filters=(32, 64, 128, 256, 512),
                  dict_size=10, momentum=0.999, margin=0.5, loss_weight=None, lr=1e-4, betas=(0.5, 0.999),
                  weight_decay=0.0, use_pixel_shuffle=False, dropped_skip_layers=(), views=None, device="cuda",
-                 encoder=None, decoder=None, data_parallel=False, use_onehot=False, concurrent_views=None):
+                 encoder=None, decoder=None, data_parallel=False, use_onehot=False, concurrent_views=None,
+                 multi_window=None):
         self.device = torch.device(device)
         self.encoder = encoder if encoder is not None else UNetEncoder(
             in_channels, list(enc_filters), dict_size, momentum, 'torch', False, 1, True)
@@ -74,6 +79,9 @@ class FirstStepTrainer:
         self.use_onehot = use_onehot
         self.w = loss_weight if loss_weight is not None else LossWeights()
         self.views = views if views is not None else FlipViews()
+        # multi_window = dict(dataset_window=(width, center, scale), recon_weights=(w_full, w_lung, w_mediastinal)): the
+        # reconstruction term of trainers/multi_window_trainer.py:93-118 (same step otherwise)
+        self.multi_window = multi_window
         # base.py:165-175: one Adam per sub-network over its trainable parameters
         self.enc_optim = Adam([p for p in self.encoder.parameters() if p.requires_grad], lr=lr, betas=betas,
                               weight_decay=weight_decay)
@@ -122,20 +130,31 @@ class FirstStepTrainer:
         codebook = self.encoder.vq.get_codebook()
         l_cross, l_dist, l_reg = self.embed_loss.forward_labels(embed_1, r_ids_1, embed_2, r_ids_2, codebook)
         recon_1 = self.decoder(embed_1)
-        l_rec_1 = ops.mse_loss(recon_1, clear_1)
+        rec_1 = self._recon_terms(recon_1, clear_1)
         with torch.cuda.stream(s2):
             recon_2 = self.decoder(embed_2)
-            l_rec_2 = ops.mse_loss(recon_2, clear_2)
+            rec_2 = self._recon_terms(recon_2, clear_2)
             ev2 = s2.record_event()
         s1.wait_event(ev2)
-        for t in (l_rec_2, l_commit_2, recon_2):
+        for t in [l_commit_2, recon_2] + [t for t, _ in rec_2]:
             t.record_stream(s1)
+        l_rec_1, l_rec_2 = rec_1[0][0], rec_2[0][0]
         l_total = ops.weighted_sum(
-            [l_commit_1, l_commit_2, l_cross, l_dist, l_reg, l_rec_1, l_rec_2],
-            [w.commit, w.commit, w.cross, w.dist, w.reg, w.recon, w.recon])
+            [l_commit_1, l_commit_2, l_cross, l_dist, l_reg] + [t for t, _ in rec_1 + rec_2],
+            [w.commit, w.commit, w.cross, w.dist, w.reg] + [c for _, c in rec_1 + rec_2])
         return dict(total=l_total, commit_1=l_commit_1, commit_2=l_commit_2, cross=l_cross, dist=l_dist, reg=l_reg,
                     recon_l1=l_rec_1, recon_l2=l_rec_2, ids_1=ids_1, ids_2=ids_2, recon_1=recon_1, recon_2=recon_2,
                     embed_1=embed_1, embed_2=embed_2)
+
+    def _recon_terms(self, recon, clear):
+        """[(loss term, weight)] of one view's reconstruction loss: plain MSE, or the multi-window mean of
+        recon_weights[i] * MSE on the full / lung / mediastinal windows (multi_window_trainer.py:93-118)."""
+        if self.multi_window is None:
+            return [(ops.mse_loss(recon, clear), self.w.recon)]
+        dw, rw = self.multi_window["dataset_window"], self.multi_window["recon_weights"]
+        terms = [ops.mse_loss(recon, clear), ops.window_mse_loss(recon, clear, dw, LUNG_WINDOW),
+                 ops.window_mse_loss(recon, clear, dw, MEDIASTINAL_WINDOW)]
+        return [(t, self.w.recon * float(r) / 3.0) for t, r in zip(terms, rw)]
 
     def forward_losses(self, image, noise=None):
         """Lines 73-137 of the reference step.  `image` is in [-1, 1] (dataloader convention)."""
@@ -156,11 +175,11 @@ class FirstStepTrainer:
             l_cross, l_dist, l_reg = self.embed_loss.forward_labels(embed_1, r_ids_1, embed_2, r_ids_2, codebook)
         recon_1 = self.decoder(embed_1)
         recon_2 = self.decoder(embed_2)
-        l_rec_1 = ops.mse_loss(recon_1, clear_1)
-        l_rec_2 = ops.mse_loss(recon_2, clear_2)
+        rec_1, rec_2 = self._recon_terms(recon_1, clear_1), self._recon_terms(recon_2, clear_2)
+        l_rec_1, l_rec_2 = rec_1[0][0], rec_2[0][0]
         l_total = ops.weighted_sum(
-            [l_commit_1, l_commit_2, l_cross, l_dist, l_reg, l_rec_1, l_rec_2],
-            [w.commit, w.commit, w.cross, w.dist, w.reg, w.recon, w.recon])
+            [l_commit_1, l_commit_2, l_cross, l_dist, l_reg] + [t for t, _ in rec_1 + rec_2],
+            [w.commit, w.commit, w.cross, w.dist, w.reg] + [c for _, c in rec_1 + rec_2])
         return dict(total=l_total, commit_1=l_commit_1, commit_2=l_commit_2, cross=l_cross, dist=l_dist, reg=l_reg,
                     recon_l1=l_rec_1, recon_l2=l_rec_2, ids_1=ids_1, ids_2=ids_2, recon_1=recon_1, recon_2=recon_2,
                     embed_1=embed_1, embed_2=embed_2)

@@ -475,3 +475,37 @@ def synthetic_slices(batch, size, seed, device="cpu"):
     img = (field * 0.6 + 0.05 * torch.randn(batch, 1, size, size, generator=g)).clamp_(-1, 1)
     noise = 0.02 * torch.randn(batch, 1, size, size, generator=g)
     return img.to(device), noise.to(device)
+
+
+# ----------------------------------------------------------------------------------------------
+# CT windows and the multi-window reconstruction loss (utils/__init__.py:17-51, trainers/base.py:33-43, 290-314,
+# trainers/multi_window_trainer.py:93-118)
+# ----------------------------------------------------------------------------------------------
+LUNG_WINDOW = dict(width=1500, center=-550, scale=2.0)
+MEDIASTINAL_WINDOW = dict(width=400, center=20, scale=2.0)
+
+
+def window_normalize(image, width=1500, center=-550, scale=2.0):
+    """utils/__init__.py:17-28 on a tensor: clip to the window, map to [-scale/2, scale/2]."""
+    vmax, vmin = center + width // 2, center - width // 2
+    return ((torch.clamp(image, vmin, vmax) - vmin) / (vmax - vmin) - 0.5) * scale
+
+
+def window_denormalize(image, width, center, scale):
+    """utils/__init__.py:43-51"""
+    vmax, vmin = center + width // 2, center - width // 2
+    return (image / scale + 0.5) * (vmax - vmin) + vmin
+
+
+def to_window(image, dataset_window, target_window):
+    """base.py:290-314 (to_lung / to_mediastinal): dataset units -> Hounsfield units -> target window."""
+    return window_normalize(window_denormalize(image, **dataset_window), **target_window)
+
+
+def multi_window_recon(rec_1, clear_1, rec_2, clear_2, dataset_window, recon_weights):
+    """multi_window_trainer.py:93-118: mean over {full, lung, mediastinal} of w_i * (MSE view 1 + MSE view 2)."""
+    terms = []
+    for i, tw in enumerate((None, LUNG_WINDOW, MEDIASTINAL_WINDOW)):
+        f = (lambda t: t) if tw is None else (lambda t, tw=tw: to_window(t, dataset_window, tw))
+        terms.append(recon_weights[i] * (F.mse_loss(f(rec_1), f(clear_1)) + F.mse_loss(f(rec_2), f(clear_2))))
+    return torch.mean(torch.stack(terms))

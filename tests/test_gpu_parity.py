@@ -915,3 +915,38 @@ def test_recon_from_checkpoint_and_nifti(tmp_path):
     assert np.allclose(RR.load_from_nifti(out), ref)
     win = RR.reconstruct_file(e2, d2, edited, window=(2000, 0, 2.0), device=DEV)
     assert np.allclose(win, RR.normalize(RR.denormalize(ref, 2000, 0, 2.0), **RR.LUNG_WINDOW))
+
+
+def test_multi_window_recon_loss():
+    """windowed MSE kernel (value and gradient, clamped regions included) against the oracle's
+    to_window / F.mse_loss, and the multi-window first step's total against its own parts."""
+    from oracle import vqwnet_ref as O
+    from trainers import FirstStepTrainer, LossWeights
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    a = (torch.rand(2, 1, 24, 24, generator=g) * 3 - 1.5)
+    b = (torch.rand(2, 1, 24, 24, generator=g) * 3 - 1.5)
+    dsw = (2000, 0, 2.0)
+    for tw in (O.LUNG_WINDOW, O.MEDIASTINAL_WINDOW):
+        ra = a.clone().requires_grad_(True)
+        ref = F.mse_loss(O.to_window(ra, dict(width=2000, center=0, scale=2.0), tw), O.to_window(b, dict(width=2000, center=0, scale=2.0), tw))
+        (1.7 * ref).backward()
+        da = a.to(DEV).requires_grad_(True)
+        l = ops.window_mse_loss(da, b.to(DEV), dsw, (tw["width"], tw["center"], tw["scale"]))
+        (1.7 * l).backward()
+        assert_close(l, ref, 2e-5, "window mse")
+        assert_close(da.grad, ra.grad, 2e-4, "window mse grad", atol=1e-7)
+        assert float((ra.grad == 0).float().mean()) > 0.05          # the case really has clamped pixels
+    rw = (1.0, 0.5, 0.25)
+    w = LossWeights(commit=1.0, cross=0.5, dist=0.3, reg=0.2, recon=2.0)
+    tr = FirstStepTrainer(enc_filters=(4, 8, 8, 8, 8), dec_filters=(4, 8, 8, 8, 8), dict_size=6, device=DEV, loss_weight=w,
+                          multi_window=dict(dataset_window=dsw, recon_weights=rw))
+    img = (torch.rand(2, 1, 32, 32, generator=g) * 2 - 1).to(DEV)
+    out = tr.forward_losses(img)
+    c1, c2 = img.cpu(), torch.flip(img, dims=[3]).cpu()
+    l_rec = O.multi_window_recon(out["recon_1"].detach().cpu(), c1, out["recon_2"].detach().cpu(), c2,
+                                 dict(width=2000, center=0, scale=2.0), rw)
+    parts = w.commit * (out["commit_1"] + out["commit_2"]) + w.cross * out["cross"] + w.dist * out["dist"] + w.reg * out["reg"]
+    expect = parts.detach().cpu() + w.recon * l_rec
+    assert_close(out["total"], expect, 2e-5, "multi-window total")
+    tr.training_step(img)

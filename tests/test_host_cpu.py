@@ -254,3 +254,39 @@ def test_recon_file_helpers(tmp_path):
     x = np.array([-1.0, 0.0, 1.0])
     hu = RR.denormalize(x, 1500, -550, 2.0)
     assert np.allclose(hu, [-1300.0, -550.0, 200.0]) and np.allclose(RR.normalize(hu, **RR.LUNG_WINDOW), x)
+
+
+def test_ct_windows_and_dataset(tmp_path):
+    """CT window arithmetic (known Hounsfield answers), the affine+clamp form the windowed-MSE kernel
+    uses, and the slice dataset / loader over `<patient>/<x>_img_<n>.npy` files."""
+    from oracle import vqwnet_ref as O
+    from hipops import ops
+    from dataio import NCCLungDataset, get_data_loader, window_normalize
+    hu = torch.tensor([-2000.0, -1300.0, -550.0, 200.0, 900.0])
+    assert torch.allclose(O.window_normalize(hu, 1500, -550, 2.0), torch.tensor([-1.0, -1.0, 0.0, 1.0, 1.0]))
+    assert np.allclose(window_normalize(hu.numpy(), 1500, -550, 2.0), [-1, -1, 0, 1, 1])
+    assert torch.allclose(O.window_denormalize(torch.tensor([-1.0, 0.0, 1.0]), 400, 20, 2.0), torch.tensor([-180.0, 20.0, 220.0]))
+    ds_win = dict(width=2000, center=0, scale=2.0)
+    x = torch.linspace(-1.5, 1.5, 601)
+    for tw in (O.LUNG_WINDOW, O.MEDIASTINAL_WINDOW):
+        a, b, lo, hi = ops.window_map((2000, 0, 2.0), (tw["width"], tw["center"], tw["scale"]))
+        assert torch.allclose(torch.clamp(a * x + b, lo, hi), O.to_window(x, ds_win, tw), atol=1e-5)
+    # dataset: two patients, slices out of order on disk
+    for pid, ns in (("p001", (3, 1)), ("p002", (7,))):
+        os.makedirs(tmp_path / pid)
+        for n in ns:
+            np.save(tmp_path / pid / ("%s_img_%03d.npy" % (pid, n)), np.full((8, 8), -550.0 + 100 * n, dtype=np.float64))
+        np.save(tmp_path / pid / ("%s_lbl_001.npy" % pid), np.zeros((8, 8)))            # not an image file
+    ds = NCCLungDataset(str(tmp_path), None, 1500, -550, 2.0)
+    assert len(ds) == 3 and sorted((f["patient_id"], f["slice_num"]) for f in ds.files) == [("p001", 1), ("p001", 3), ("p002", 7)]
+    s = ds[0]
+    assert s["image"].dtype == np.float32 and s["image"].shape == (8, 8)
+    assert np.allclose(s["image"], (100.0 * s["slice_num"]) / 1500.0 * 2.0)
+    raw = NCCLungDataset(str(tmp_path))[0]["image"]
+    assert raw.min() <= -150.0 or raw.max() >= -450.0                                    # no window: Hounsfield units kept
+    dl = get_data_loader('test', 'NCCLungDataset', str(tmp_path), batch_size=2, num_workers=0, window_width=1500,
+                         window_center=-550, window_scale=2.0)
+    batches = list(dl)
+    assert [tuple(b["image"].shape) for b in batches] == [(2, 1, 8, 8), (1, 1, 8, 8)] and batches[0]["image"].dtype == torch.float32
+    with pytest.raises(NotImplementedError):
+        get_data_loader('train', 'CRCDataset', str(tmp_path), 2, 0)
