@@ -248,6 +248,10 @@ int vqw_window_mse_bwd(const float* a, const float* b, const float* gloss, float
 int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                   void* stream);
+/* the same update for many tensors in one launch: chunks_dev points to n_chunks device records
+ * {float* p; const float* g; float* m; float* v; int64_t n} (40 bytes each), one workgroup per record */
+int vqw_adam_multi(const void* chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float bias_corr1, float bias_corr2, void* stream);
 
 #ifdef __cplusplus
 }

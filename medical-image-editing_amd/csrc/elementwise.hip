@@ -293,6 +293,41 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
         v[i] = vi;
     }
 }
+// One launch for a whole parameter group (all tensors share the step count, hence the bias corrections): the table holds
+// one entry per chunk of a tensor; same per-element arithmetic as k_adam.
+struct AdamChunk {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+};
+__global__ void __launch_bounds__(256) k_adam_multi(const AdamChunk* __restrict__ chunks, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt) {
+    const AdamChunk c = chunks[blockIdx.x];
+    const float step = lr / bc1;
+    for (long i = threadIdx.x; i < c.n; i += 256) {
+        float gi = c.g[i], pi = c.p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        float mi = c.m[i] * b1 + (1.f - b1) * gi;
+        float vi = c.v[i] * b2 + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        c.p[i] = pi - step * (mi / denom);
+        c.m[i] = mi;
+        c.v[i] = vi;
+    }
+}
+extern "C" int vqw_adam_multi(const void* chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float bias_corr1, float bias_corr2, void* stream) {
+    VQW_CHECK(chunks_dev && n_chunks > 0, "vqw_adam_multi: bad arguments");
+    VQW_CHECK(bias_corr1 > 0.f && bias_corr2 > 0.f, "vqw_adam_multi: bias corrections must be positive");
+    static_assert(sizeof(AdamChunk) == 40, "chunk table layout is part of the ABI: 4 pointers + int64 count");
+    k_adam_multi<<<n_chunks, 256, 0, (hipStream_t)stream>>>((const AdamChunk*)chunks_dev, lr, beta1, beta2, eps, weight_decay,
+                                                            bias_corr1, sqrtf(bias_corr2));
+    VQW_LAUNCH_CHECK("vqw_adam_multi");
+    return VQW_OK;
+}
+
 extern "C" int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, float bias_corr1, float bias_corr2, void* stream) {
     VQW_CHECK(p && g && m && v && n > 0, "vqw_adam_step: bad arguments");

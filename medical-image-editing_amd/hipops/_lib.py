@@ -97,6 +97,7 @@ SIGNATURES = {
     "vqw_seg_losses_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqw_seg_losses_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqw_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
+    "vqw_adam_multi": (c_i, [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
 }
 
 _lib = None

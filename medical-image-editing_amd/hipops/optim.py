@@ -5,11 +5,17 @@ reference builds in trainers/base.py:165-175: same constructor arguments, same u
 rule, same state_dict layout ('step', 'exp_avg', 'exp_avg_sq' per parameter).
 """
 import ctypes
+import os
 
+import numpy as np
 import torch
 
 from . import _lib
 from . import ops as _ops
+
+
+MULTI_TENSOR = os.environ.get("VQW_ADAM_MULTI", "1") != "0"
+CHUNK = 1 << 16          # elements per workgroup of the multi-tensor launch
 
 
 class Adam(torch.optim.Optimizer):
@@ -28,6 +34,8 @@ class Adam(torch.optim.Optimizer):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            if MULTI_TENSOR and self._step_multi(L, st, group):
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -53,3 +61,40 @@ class Adam(torch.optim.Optimizer):
                                            1.0 - b1 ** t, 1.0 - b2 ** t, st), "vqw_adam_step")
         _ops.bump_weight_epoch()      # parameters changed through raw pointers: invalidate derived weight layouts
         return loss
+
+    def _step_multi(self, L, st, group):
+        """All tensors of the group in one launch.  Falls back (returns False) when the tensors do not share a step
+        count or a gradient needs a layout copy; the per-tensor path then handles the group."""
+        params = [p for p in group["params"] if p.grad is not None]
+        if not params:
+            return True
+        dev = params[0].device
+        steps = set()
+        for p in params:
+            if not p.is_cuda or p.device != dev or p.grad.stride() != p.stride():
+                return False
+            state = self.state[p]
+            if len(state) == 0:
+                state["step"] = 0
+                state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if state["exp_avg"].stride() != p.stride() or state["exp_avg_sq"].stride() != p.stride():
+                return False
+            steps.add(state["step"])
+        if len(steps) != 1:
+            return False
+        t = steps.pop() + 1
+        rows = []
+        for p in params:
+            state = self.state[p]
+            state["step"] = t
+            ptrs = (p.data_ptr(), p.grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr())
+            n = p.numel()
+            for off in range(0, n, CHUNK):
+                rows.append((ptrs[0] + 4 * off, ptrs[1] + 4 * off, ptrs[2] + 4 * off, ptrs[3] + 4 * off, min(CHUNK, n - off)))
+        table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).pin_memory().to(dev, non_blocking=True)
+        b1, b2 = group["betas"]
+        _lib.check(L.vqw_adam_multi(ctypes.c_void_p(table.data_ptr()), len(rows), group["lr"], b1, b2, group["eps"],
+                                    group["weight_decay"], 1.0 - b1 ** t, 1.0 - b2 ** t, st), "vqw_adam_multi")
+        table.record_stream(torch.cuda.current_stream())
+        return True
