@@ -421,8 +421,11 @@ def test_first_step_golden(golden, name):
                    loose_bound=lb)
 
 
-def test_step_vs_oracle_128():
-    """R-cfg at 128x128, batch 2, warm VQ state: HIP step vs the CPU oracle on the same seeded inputs."""
+@pytest.mark.parametrize("B,S", [(2, 128), (3, 96), (2, 80)])
+def test_step_vs_oracle_128(B, S):
+    """R-cfg at 128x128 (halo / tile kernels on every level that is a multiple of 32 wide), 96x96 (mixed: the 48-, 24-,
+    12- and 6-pixel levels fall back to the implicit-GEMM kernels, odd batch) and 80x80 (no level is a multiple of 32),
+    warm VQ state: HIP step vs the CPU oracle on the same seeded inputs."""
     from oracle import vqwnet_ref as O
     from trainers import FirstStepTrainer, FlipViews
     from networks import UNetEncoder, UNetDecoder
@@ -430,7 +433,6 @@ def test_step_vs_oracle_128():
     K = 10
     enc = UNetEncoder(1, [16, 32, 64, 128, 256], K, 0.999, 'torch', False, 1, True)
     dec = UNetDecoder(16, 1, [32, 64, 128, 256, 512], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
-    B, S = 2, 128
     with torch.no_grad():
         enc.vq.embed.mul_(0.7)
         enc.vq.cluster_size.fill_(B * S * S / K)
@@ -580,7 +582,7 @@ def test_extras_golden(golden):
 # --------------------------------------------------------------------------------------------------
 # edge cases
 # --------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,S", [(1, 16), (3, 32), (1, 64)])
+@pytest.mark.parametrize("B,S", [(1, 16), (3, 32), (1, 64), (2, 96), (1, 160)])
 def test_edge_sizes_forward_vs_oracle(B, S):
     """Batch 1 / odd batch and the smallest legal map (16x16: the deepest level is 1x1, InstanceNorm over one pixel
     gives exactly 0): train-mode forward of encoder + decoder against the oracle."""
