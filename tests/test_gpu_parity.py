@@ -60,6 +60,13 @@ CONV_CASES = [
     (2, 16, 32, 16, 0, False, 32, 3, 1, False, False),
     (3, 12, 32, 48, 0, False, 80, 3, 1, True, False),
     (1, 16, 64, 16, 0, False, 48, 3, 1, True, True),
+    # flattened phase-image kernel: dilated layers (ragged phase images, several planes per 256-position tile) and
+    # maps narrower than 32 pixels with a 64-wide cout tile
+    (2, 50, 38, 32, 0, False, 32, 3, 6, True, False),
+    (1, 96, 96, 32, 0, False, 32, 3, 18, False, True),
+    (1, 64, 64, 48, 0, False, 24, 3, 12, True, False),
+    (2, 16, 16, 64, 0, False, 128, 3, 1, True, False),
+    (3, 24, 40, 16, 0, False, 96, 3, 2, True, False),
 ]
 
 
