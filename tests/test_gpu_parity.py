@@ -60,8 +60,7 @@ CONV_CASES = [
     (2, 16, 32, 16, 0, False, 32, 3, 1, False, False),
     (3, 12, 32, 48, 0, False, 80, 3, 1, True, False),
     (1, 16, 64, 16, 0, False, 48, 3, 1, True, True),
-    # flattened phase-image kernel: dilated layers (ragged phase images, several planes per 256-position tile) and
-    # maps narrower than 32 pixels with a 64-wide cout tile
+    # more dilated / narrow shapes (ragged sizes, dilation larger than a tile, wide couts on a 16-pixel map)
     (2, 50, 38, 32, 0, False, 32, 3, 6, True, False),
     (1, 96, 96, 32, 0, False, 32, 3, 18, False, True),
     (1, 64, 64, 48, 0, False, 24, 3, 12, True, False),
