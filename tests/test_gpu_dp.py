@@ -85,3 +85,64 @@ def test_two_rank_dp_matches_single_process(tmp_path):
     assert max(errs) < 0.15 and sorted(errs)[len(errs) // 2] < 0.05, errs
     mean_total = 0.5 * (dp[0]["total"] + dp[1]["total"])
     assert abs(mean_total - single["total"]) <= 0.05 * abs(single["total"])
+
+
+WORKER2 = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]; out = sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "medical-image-editing_amd"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+from trainers import SecondStepTrainer, GanLossWeights
+from networks import UNetEncoder, UNetDecoder, NLayerDiscriminator
+from oracle.vqwnet_ref import synthetic_slices
+torch.manual_seed(6)
+K = 8
+enc = UNetEncoder(1, [16, 16, 32, 32, 32], K, 0.99, 'torch', False, 1, True)
+dec = UNetDecoder(16, 1, [16, 32, 32, 32, 64], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
+dis = NLayerDiscriminator(1, 1, n_filters=16, n_layers=3)
+B, S = 4, 64
+tr = SecondStepTrainer(enc, dec, dis, loss_weight=GanLossWeights(1.0, 0.2, 0.7), lr=1e-3, device="cuda:0", data_parallel=world > 1)
+img, _ = synthetic_slices(B, S, 12)
+lo, hi = (rank * B // world, (rank + 1) * B // world)
+o = tr.training_step(img[lo:hi].cuda())
+torch.cuda.synchronize()
+res = {"gen_total": float(o["gen_total"].detach()), "dis_total": float(o["dis_total"].detach()), "recon": float(o["recon"].detach()),
+       "ids": o["ids"].cpu(),
+       "bn": {k: v.cpu() for k, v in list(dec.state_dict().items()) + [("dis." + k, v) for k, v in dis.state_dict().items()] if "running_" in k},
+       "pdec": {k: p.detach().cpu() for k, p in list(dec.named_parameters())[:40:5]},
+       "pdis": {k: p.detach().cpu() for k, p in dis.named_parameters()}}
+torch.save(res, out + ".%d" % rank)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_second_step_two_rank_dp(tmp_path):
+    """SecondStepTrainer(data_parallel=True) on two ranks (gloo, one GPU) against one process on the whole batch:
+    identical replicas, BatchNorm running statistics of the global batch, parameters after the generator and the
+    discriminator update within rounding of the single-process step (losses are per-rank means, so averaged)."""
+    global WORKER
+    keep, WORKER = WORKER, WORKER2
+    try:
+        single = _run(1, tmp_path, "s2_single", 29631)[0]
+        dp = _run(2, tmp_path, "s2_dp", 29632)
+    finally:
+        WORKER = keep
+    for grp in ("pdec", "pdis"):
+        for k in dp[0][grp]:
+            assert torch.equal(dp[0][grp][k], dp[1][grp][k]), "ranks diverged on " + k
+    assert torch.equal(torch.cat([dp[0]["ids"], dp[1]["ids"]]), single["ids"])
+    for k in single["bn"]:
+        assert torch.allclose(dp[0]["bn"][k], single["bn"][k], rtol=2e-4, atol=2e-6), k
+    for key in ("gen_total", "dis_total", "recon"):
+        mean = 0.5 * (dp[0][key] + dp[1][key])
+        assert abs(mean - single[key]) <= 2e-4 * max(1.0, abs(single[key])), (key, mean, single[key])
+    worst = 0.0
+    for grp in ("pdec", "pdis"):
+        for k, v in single[grp].items():
+            d = float((dp[0][grp][k] - v).abs().max())
+            worst = max(worst, d)
+            assert d <= 2.5e-3, (k, d)            # one Adam step of lr 1e-3: a sign flip of a ~0 gradient moves 2e-3
+    assert worst > 0.0
