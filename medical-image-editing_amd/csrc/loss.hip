@@ -25,26 +25,42 @@ __global__ void __launch_bounds__(CL_BLOCK) k_cross_partial(const float* __restr
                                                             const float* __restrict__ cb, float* __restrict__ part, long HW,
                                                             int D, int K, int splits) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_acc = smem;  // [K][2]
+    float* s_acc = smem;  // [waves][K][2]: one slab per wave, single writer, folded in wave order (deterministic)
     const int b = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
-    for (int i = t; i < 2 * K; i += CL_BLOCK) s_acc[i] = 0.f;
+    constexpr int NWV = CL_BLOCK / 64;
+    for (int i = t; i < NWV * 2 * K; i += CL_BLOCK) s_acc[i] = 0.f;
     __syncthreads();
+    float* slab = s_acc + (t >> 6) * 2 * K;
     long per = (HW + splits - 1) / splits;
     long p0 = s * per, p1 = p0 + per < HW ? p0 + per : HW;
-    for (long p = p0 + t; p < p1; p += CL_BLOCK) {
-        int l = labels[(long)b * HW + p];
+    for (long base = p0; base < p1; base += CL_BLOCK) {            // wave-uniform trip count (shuffles below)
+        const long p = base + t;
+        int l = p < p1 ? labels[(long)b * HW + p] : 0;
+        float d2 = 0.f;
         if (l >= 1 && l <= K) {
             const float* e = embed + ((long)b * HW + p) * D;
             const float* c = cb + (long)(l - 1) * D;
-            float d2 = 0.f;
             for (int d = 0; d < D; ++d) { float a = e[d] - c[d]; d2 = fmaf(a, a, d2); }
-            atomicAdd(&s_acc[2 * (l - 1)], d2);
-            atomicAdd(&s_acc[2 * (l - 1) + 1], 1.f);
+        } else {
+            l = 0;
+        }
+        for (int k = 1; k <= K; ++k) {
+            const unsigned long long members = __ballot(l == k);
+            if (members == 0ull) continue;
+            float v = wave_sum_f(l == k ? d2 : 0.f);
+            if ((t & 63) == 0) {
+                slab[2 * (k - 1)] += v;
+                slab[2 * (k - 1) + 1] += (float)__popcll(members);
+            }
         }
     }
     __syncthreads();
     float* o = part + ((long)b * splits + s) * K * 2;
-    for (int i = t; i < 2 * K; i += CL_BLOCK) o[i] = s_acc[i];
+    for (int i = t; i < 2 * K; i += CL_BLOCK) {
+        float a = s_acc[i];
+        for (int w = 1; w < NWV; ++w) a += s_acc[w * 2 * K + i];
+        o[i] = a;
+    }
 }
 
 // dense variant: r[b][k][p] (NCHW float weights)
@@ -52,28 +68,42 @@ __global__ void __launch_bounds__(CL_BLOCK) k_cross_partial_dense(const float* _
                                                                   const float* __restrict__ cb, float* __restrict__ part,
                                                                   long HW, int D, int K, int splits) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_acc = smem;
+    float* s_acc = smem;  // [waves][K][2], as above
     const int b = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
-    for (int i = t; i < 2 * K; i += CL_BLOCK) s_acc[i] = 0.f;
+    constexpr int NWV = CL_BLOCK / 64;
+    for (int i = t; i < NWV * 2 * K; i += CL_BLOCK) s_acc[i] = 0.f;
     __syncthreads();
+    float* slab = s_acc + (t >> 6) * 2 * K;
     long per = (HW + splits - 1) / splits;
     long p0 = s * per, p1 = p0 + per < HW ? p0 + per : HW;
-    for (long p = p0 + t; p < p1; p += CL_BLOCK) {
-        const float* e = embed + ((long)b * HW + p) * D;
+    for (long base = p0; base < p1; base += CL_BLOCK) {
+        const long p = base + t;
+        const bool active = p < p1;
+        const float* e = embed + ((long)b * HW + (active ? p : p0)) * D;
         for (int k = 0; k < K; ++k) {
-            float w = r[((long)b * K + k) * HW + p];
+            float w = active ? r[((long)b * K + k) * HW + p] : 0.f;
+            float num = 0.f;
             if (w != 0.f) {
                 const float* c = cb + (long)k * D;
                 float d2 = 0.f;
                 for (int d = 0; d < D; ++d) { float a = e[d] - c[d]; d2 = fmaf(a, a, d2); }
-                atomicAdd(&s_acc[2 * k], d2 * w);
-                atomicAdd(&s_acc[2 * k + 1], w);
+                num = d2 * w;
+            }
+            if (__ballot(w != 0.f) == 0ull) continue;
+            float sn = wave_sum_f(num), sw = wave_sum_f(w);
+            if ((t & 63) == 0) {
+                slab[2 * k] += sn;
+                slab[2 * k + 1] += sw;
             }
         }
     }
     __syncthreads();
     float* o = part + ((long)b * splits + s) * K * 2;
-    for (int i = t; i < 2 * K; i += CL_BLOCK) o[i] = s_acc[i];
+    for (int i = t; i < 2 * K; i += CL_BLOCK) {
+        float a = s_acc[i];
+        for (int w = 1; w < NWV; ++w) a += s_acc[w * 2 * K + i];
+        o[i] = a;
+    }
 }
 
 // loss = mean over (b,k) with cnt != 0 of num/(cnt+eps); coef[b][k] = 1/((cnt+eps) * n_present) or 0.
@@ -124,7 +154,7 @@ extern "C" int vqw_cross_loss_fwd(const float* embed, const int32_t* labels, con
     VQW_CHECK(K <= 8192, "vqw_cross_loss_fwd: K too large");
     hipStream_t st = (hipStream_t)stream;
     int splits = cl_splits(B, HW);
-    k_cross_partial<<<dim3(splits, B), CL_BLOCK, 2 * K * sizeof(float), st>>>(embed, labels, codebook_kd, (float*)ws, HW, D, K, splits);
+    k_cross_partial<<<dim3(splits, B), CL_BLOCK, (CL_BLOCK / 64) * 2 * K * sizeof(float), st>>>(embed, labels, codebook_kd, (float*)ws, HW, D, K, splits);
     k_cross_finalize<<<1, 256, 0, st>>>((const float*)ws, loss, coef, B * K, K, splits);
     VQW_LAUNCH_CHECK("vqw_cross_loss_fwd");
     return VQW_OK;
@@ -137,7 +167,7 @@ extern "C" int vqw_cross_loss_dense_fwd(const float* embed, const float* r_nchw,
     VQW_CHECK(K <= 8192, "vqw_cross_loss_dense_fwd: K too large");
     hipStream_t st = (hipStream_t)stream;
     int splits = cl_splits(B, HW);
-    k_cross_partial_dense<<<dim3(splits, B), CL_BLOCK, 2 * K * sizeof(float), st>>>(embed, r_nchw, codebook_kd, (float*)ws, HW, D, K, splits);
+    k_cross_partial_dense<<<dim3(splits, B), CL_BLOCK, (CL_BLOCK / 64) * 2 * K * sizeof(float), st>>>(embed, r_nchw, codebook_kd, (float*)ws, HW, D, K, splits);
     k_cross_finalize<<<1, 256, 0, st>>>((const float*)ws, loss, coef, B * K, K, splits);
     VQW_LAUNCH_CHECK("vqw_cross_loss_dense_fwd");
     return VQW_OK;

@@ -15,7 +15,7 @@
 static inline int vq_blocks(long Npix) { return (int)imin(2048, ceil_div(Npix, VQ_BLOCK)); }
 
 static inline bool vq_lds_codebook(int D, int K) { return (long)K * D + K <= VQ_LDS_FLOATS; }
-static inline bool vq_lds_stats(int D, int K) { return (long)K * D + K + (long)K * (D + 1) <= VQ_LDS_FLOATS; }
+static inline bool vq_lds_stats(int D, int K) { return (long)K * D + K + 4L * K * (D + 1) <= VQ_LDS_FLOATS; }   // one statistics slab per wave
 
 // ---- large codebooks (BASELINE config 4: K = 1024, D = 256): score GEMM on the matrix cores + wave-per-pixel select
 #define VQ_GEMM_CHUNK 65536L          // pixels per score chunk (the K x N matrix is never held whole)
@@ -46,13 +46,13 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_cb = smem;                                   // [K][D] if LDS_CB
     float* s_nrm = smem + (LDS_CB ? K * D : 0);           // [K]
-    float* s_st = s_nrm + K;                              // [K*(D+1)] if LDS_ST: counts[K] then sum[d][k]
+    float* s_st = s_nrm + K;                              // [waves][K*(D+1)] if LDS_ST: counts[K] then sum[d][k], one slab per wave
     __shared__ double s_red[VQ_BLOCK / 64];
     const int t = threadIdx.x;
     if (LDS_CB)
         for (int i = t; i < K * D; i += VQ_BLOCK) s_cb[i] = embed[i];
     if (LDS_ST && want_stats)
-        for (int i = t; i < K * (D + 1); i += VQ_BLOCK) s_st[i] = 0.f;
+        for (int i = t; i < (VQ_BLOCK / 64) * K * (D + 1); i += VQ_BLOCK) s_st[i] = 0.f;
     for (int k = t; k < K; k += VQ_BLOCK) {
         float n2 = 0.f;
         for (int d = 0; d < D; ++d) { float e = embed[k * D + d]; n2 = fmaf(e, e, n2); }
@@ -61,7 +61,11 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
     __syncthreads();
     const float* cb = LDS_CB ? s_cb : embed;
     double csum = 0.0;
-    for (long p = (long)blockIdx.x * VQ_BLOCK + t; p < Npix; p += (long)gridDim.x * VQ_BLOCK) {
+    // wave-uniform trip count: the statistics below are reduced with wave shuffles, so every lane stays in the loop
+    // (lanes past the end compute on the last pixel and contribute nothing)
+    for (long base = (long)blockIdx.x * VQ_BLOCK; base < Npix; base += (long)gridDim.x * VQ_BLOCK) {
+        const bool active = base + t < Npix;
+        const long p = active ? base + t : Npix - 1;
         const float* xr = x + p * D;
         float xv[DT > 0 ? DT : 1];
         float x2 = 0.f;
@@ -90,7 +94,7 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
             float s = (2.f * dot - s_nrm[k]) - x2;
             if (s > best) { best = s; bi = k; }
         }
-        ids[p] = (int64_t)(bi + id_base);
+        if (active) ids[p] = (int64_t)(bi + id_base);
         const float* e = cb + bi * D;
         float* qr = q + p * D;
         float c = 0.f;
@@ -99,22 +103,44 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
             for (int d4 = 0; d4 < DT / 4; ++d4) {
                 float4 o;
                 o.x = e[4 * d4]; o.y = e[4 * d4 + 1]; o.z = e[4 * d4 + 2]; o.w = e[4 * d4 + 3];
-                ((float4*)qr)[d4] = o;
+                if (active) ((float4*)qr)[d4] = o;
                 float a0 = xv[4 * d4] - o.x, a1 = xv[4 * d4 + 1] - o.y, a2 = xv[4 * d4 + 2] - o.z, a3 = xv[4 * d4 + 3] - o.w;
                 c = fmaf(a0, a0, c); c = fmaf(a1, a1, c); c = fmaf(a2, a2, c); c = fmaf(a3, a3, c);
             }
         } else {
-            for (int d = 0; d < D; ++d) { float ev = e[d]; qr[d] = ev; float a = xr[d] - ev; c = fmaf(a, a, c); }
+            for (int d = 0; d < D; ++d) { float ev = e[d]; if (active) qr[d] = ev; float a = xr[d] - ev; c = fmaf(a, a, c); }
         }
-        csum += (double)c;
-        if (want_stats) {
-            float* st = LDS_ST ? s_st : stat_global;
-            atomicAdd(st + bi, 1.f);
+        if (active) csum += (double)c;
+        if (want_stats && LDS_ST) {
+            // deterministic: per code, a fixed-order wave butterfly of the member lanes' values, added by ONE lane into
+            // the wave's own LDS slab (no atomics: the summation order never depends on scheduling)
+            float* slab = s_st + (t >> 6) * K * (D + 1);
+            const int code = active ? bi : -1;
+            for (int k = 0; k < K; ++k) {
+                const unsigned long long members = __ballot(code == k);
+                if (members == 0ull) continue;
+                const bool mine = code == k;
+                if ((t & 63) == 0) slab[k] += (float)__popcll(members);
+                if (DT > 0) {
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        float v = wave_sum_f(mine ? xv[d] : 0.f);
+                        if ((t & 63) == 0) slab[K + d * K + k] += v;
+                    }
+                } else {
+                    for (int d = 0; d < D; ++d) {
+                        float v = wave_sum_f(mine ? xr[d] : 0.f);
+                        if ((t & 63) == 0) slab[K + d * K + k] += v;
+                    }
+                }
+            }
+        } else if (want_stats && active) {
+            atomicAdd(stat_global + bi, 1.f);
             if (DT > 0) {
 #pragma unroll
-                for (int d = 0; d < DT; ++d) atomicAdd(st + K + d * K + bi, xv[d]);
+                for (int d = 0; d < DT; ++d) atomicAdd(stat_global + K + d * K + bi, xv[d]);
             } else {
-                for (int d = 0; d < D; ++d) atomicAdd(st + K + d * K + bi, xr[d]);
+                for (int d = 0; d < D; ++d) atomicAdd(stat_global + K + d * K + bi, xr[d]);
             }
         }
     }
@@ -126,9 +152,14 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
         for (int w = 0; w < VQ_BLOCK / 64; ++w) a += s_red[w];
         commit_part[blockIdx.x] = a;
     }
-    if (LDS_ST && want_stats) {
+    if (LDS_ST && want_stats) {          // fold the wave slabs in wave order
         float* o = stat_part + (long)blockIdx.x * K * (D + 1);
-        for (int i = t; i < K * (D + 1); i += VQ_BLOCK) o[i] = s_st[i];
+        const int KD1 = K * (D + 1);
+        for (int i = t; i < KD1; i += VQ_BLOCK) {
+            float a = s_st[i];
+            for (int w = 1; w < VQ_BLOCK / 64; ++w) a += s_st[w * KD1 + i];
+            o[i] = a;
+        }
     }
 }
 
@@ -310,7 +341,7 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
     VQW_CHECK((((uintptr_t)x | (uintptr_t)q) & 15) == 0, "vqw_vq_fwd: x and q must be 16-byte aligned");
     bool lds_cb = vq_lds_codebook(D, K);
     bool lds_st = vq_lds_stats(D, K);
-    size_t lds_floats = (size_t)K + (lds_cb ? (size_t)K * D : 0) + (lds_st ? (size_t)KD1 : 0);
+    size_t lds_floats = (size_t)K + (lds_cb ? (size_t)K * D : 0) + (lds_st ? (size_t)(VQ_BLOCK / 64) * KD1 : 0);
     int want = stats != nullptr;
     float* sglob = spart;  // global accumulator (row 0) when not privatised
     if (want && !lds_st) {

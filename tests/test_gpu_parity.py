@@ -958,3 +958,26 @@ def test_multi_window_recon_loss():
     expect = parts.detach().cpu() + w.recon * l_rec
     assert_close(out["total"], expect, 2e-5, "multi-window total")
     tr.training_step(img)
+
+
+def test_training_step_is_bit_deterministic():
+    """Two runs of the same seeded training (fresh modules, three steps, two views on two streams, weight gradients on
+    the side stream) end in bit-identical parameters, codebook and losses: no result depends on kernel scheduling
+    (VQ statistics and the cross-loss partials are reduced in a fixed order; no float atomics on this path)."""
+    import bench
+    from trainers import FirstStepTrainer
+
+    def run():
+        torch.manual_seed(0)
+        tr = FirstStepTrainer(enc_filters=(16, 16, 32, 32, 32), dec_filters=(16, 32, 32, 32, 64), device=DEV)
+        pool = [bench.synthetic_batch(4, 64, 100 + s, torch.device(DEV)) for s in range(2)]
+        for i in range(3):
+            img, noise = pool[i % 2]
+            out = tr.training_step({"image": img}, noise=noise)
+        torch.cuda.synchronize()
+        ps = [p.detach().clone() for p in list(tr.encoder.parameters()) + list(tr.decoder.parameters())]
+        return ps, float(out["total"].detach()), tr.encoder.vq.embed.clone(), tr.encoder.vq.cluster_size.clone()
+    a, b = run(), run()
+    assert a[1] == b[1]
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
