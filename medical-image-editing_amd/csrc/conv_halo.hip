@@ -48,7 +48,7 @@ struct HaloArgs {
     unsigned nb0, nb1, nbw, nby;
 };
 
-template <int NW, int TH, int BN, int KC, bool WPERSIST>
+template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC>
 __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int KP = KC + 4;
@@ -130,8 +130,10 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
         const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
         const int cc = ch * KC;
-        // a chunk never straddles the two sources; everything below is wave-uniform selection, no branches
-        const bool from0 = cc < C0;
+        // a chunk never straddles the two sources; everything below is wave-uniform selection, no branches (single-source
+        // layers are a separate instantiation: choosing between two buffer descriptors compiles to a branch, and a
+        // basic-block boundary with stores in flight makes the compiler wait for them)
+        const bool from0 = !TWO_SRC || cc < C0;
         const bool up = from0 && up0;
         const __amdgpu_buffer_rsrc_t rs = from0 ? rs0 : rs1;
         const unsigned Csrc = from0 ? (unsigned)C0 : (unsigned)C1, nbs = from0 ? a.nb0 : a.nb1;
@@ -193,11 +195,14 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         co_off[j] = co < Cout ? (unsigned)co : 0xFFFFFFFFu;
     }
     const int col0 = 4 * (lane >> 5);
-    f32x16 acc[TM][TN], done[TM][TN];
+    f32x16 acc[TM][TN], done[TM][TN];      // done: the finished tile with bias (+ReLU) applied, waiting to be stored
     int done_t = -1;
+    // The stores take their data straight from `done` and one offset register per (row, cout tile); the pixel-column
+    // part of the address is a scalar offset.  A pending store pins its source registers until vmcnt says it is done, so
+    // stores fed from temporaries would make the code after them (the next prefetch) wait a full memory round trip.
     auto flush = [&]() {               // C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel column)
-        const bool valid = true;
-        const int sp = sp0 + done_t;
+        const bool pending = done_t >= 0;          // nothing finished: every offset is out of range, the stores are dropped
+        const int sp = sp0 + (pending ? done_t : 0);
         const int n = sp / per_img, rem = sp - n * per_img;
         const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
 #pragma unroll
@@ -205,14 +210,13 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int yy = ty * TH + wr * TM + i;
-                const bool ok = valid && co_off[j] != 0xFFFFFFFFu && yy < H;
+                const bool ok = pending && co_off[j] != 0xFFFFFFFFu && yy < H;
                 const unsigned base = (((unsigned)n * H + (unsigned)yy) * W + (unsigned)(tx * 32 + col0)) * (unsigned)Cout + co_off[j];
+                const int voff = ok ? (int)(base * 4u) : (int)a.nby;       // out of range: dropped by the hardware
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int col = (r & 3) + 8 * (r >> 2);
-                    float v = done[i][j][r] + bvv[j];
-                    v = a.relu ? fmaxf(v, 0.f) : v;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsy, ok ? (int)((base + (unsigned)col * Cout) * 4u) : (int)a.nby, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done[i][j][r]), rsy, voff, col * Cout * 4, 0);
                 }
             }
         }
@@ -221,8 +225,6 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     int cur = 0;
     for (int item = 0; item < nitems; ++item) {
         const int t = item / nch, ch = item - t * nch;
-        if (done_t >= 0) flush();      // wave-uniform
-        if (item + 1 < nitems) issue(item + 1);
         if (ch == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -249,6 +251,16 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         for (int g = 0; g < NG; ++g) {
             const int s = g & 1;
             if (g + 1 < NG) ldfrag(g + 1, s ^ 1);
+            if (g == 1) {
+                // The previous tile's stores and the next item's prefetch (address arithmetic, buffer loads) sit HERE,
+                // behind the first MFMA groups, so their vector instructions issue while the matrix pipe is busy
+                // instead of in front of the loop where both waves of a SIMD would leave it idle.
+                // No branches in this loop body: the last item prefetches itself again and every item "stores" (into
+                // the void when no tile is finished).  With conditional loads / commits the compiler cannot prove that
+                // a prefetch is always consumed before the next one and inserts waits that also drain the stores.
+                flush();
+                issue(item + 1 < nitems ? item + 1 : item);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -265,24 +277,29 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) done[i][j] = acc[i][j];
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r] + bvv[j];
+                        done[i][j][r] = a.relu ? fmaxf(v, 0.f) : v;
+                    }
             done_t = t;
         }
-        if (item + 1 < nitems) commit(cur ^ 1);
+        commit(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
-    if (done_t >= 0) flush();
+    flush();
 }
 
-template <int NW, int TH, int BN, int KC, bool WPERSIST>
+template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC = false>
 int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
                 hipStream_t st) {
     constexpr int KP = KC + 4;
     constexpr size_t lds = (size_t)(2 * (TH + 2) * HALO_W * KP + (WPERSIST ? 1 : 2) * 9 * BN * KP) * sizeof(float);
     static_assert(lds <= 160 * 1024, "halo tile does not fit the 160 KB LDS");
     static bool attr_set = false;
-    auto kern = k_conv_halo<NW, TH, BN, KC, WPERSIST>;
+    auto kern = k_conv_halo<NW, TH, BN, KC, WPERSIST, TWO_SRC>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             vqw_set_error("conv_halo: cannot raise the dynamic LDS limit");
@@ -310,7 +327,7 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     int kt = g_halo_kt > 0 ? g_halo_kt : even;
     if (kt > even) kt = even;
     a.kt = kt < 1 ? 1 : kt;
-    k_conv_halo<NW, TH, BN, KC, WPERSIST><<<ceil_div(a.nsp, a.kt) * a.ntn, 64 * NW, lds, st>>>(a);
+    k_conv_halo<NW, TH, BN, KC, WPERSIST, TWO_SRC><<<ceil_div(a.nsp, a.kt) * a.ntn, 64 * NW, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_halo");
     return VQW_OK;
 }
@@ -340,6 +357,10 @@ int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
     if (Cin == 16 && in.C1 == 0) {
         if (wide) return launch_halo<8, 8, 64, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st);
         return launch_halo<8, 8, 32, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st);
+    }
+    if (in.C1 > 0) {
+        if (wide) return launch_halo<8, 8, 64, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st);
+        return launch_halo<8, 8, 32, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st);
     }
     if (wide) return launch_halo<8, 8, 64, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
     return launch_halo<8, 8, 32, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
