@@ -457,13 +457,16 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
             rx[j] = buf_ld4(rsx, ok ? pix * xC * 4u + x_cb : nbx);
         }
     };
+    int committed = 0;
     auto commit = [&](int buf) {
         float* D = Ds + buf * WT_D;
         float* X = Xs + buf * WT_X;
+        const float once = committed < my_tiles ? 1.f : 0.f;      // the duplicate prefetch of the last tile is not a new tile
+        ++committed;
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
             *(float4*)&D[(tid + NT * j) * 4] = rd[j];
-            bsum.x += rd[j].x; bsum.y += rd[j].y; bsum.z += rd[j].z; bsum.w += rd[j].w;   // fused bias gradient
+            bsum.x += once * rd[j].x; bsum.y += once * rd[j].y; bsum.z += once * rd[j].z; bsum.w += once * rd[j].w;   // fused bias gradient
         }
 #pragma unroll
         for (int j = 0; j < LX; ++j) {
@@ -486,7 +489,6 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < my_tiles; ++t) {
-        if (t + 1 < my_tiles) issue(t + 1);
         const float* Dr = Ds + cur * WT_D + (wv * 32 + lk) * 32 + lcol;                 // a(k) = Dr[k * 32]
         const float* Xr = Xs + cur * WT_X + (wv * HALO_W + lk) * 32 + lcol;             // b(ky,kx,k) = Xr[(ky*34 + k + kx) * 32]
         float fa[2], fb[2][9];
@@ -502,12 +504,15 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
         for (int k = 0; k < 32; k += 2) {
             const int s = (k >> 1) & 1;
             if (k + 2 < 32) ldfrag(k + 2, s ^ 1);
+            // the next tile's prefetch sits behind the first MFMAs (its address arithmetic issues while the matrix pipe
+            // is busy); unconditional (the last tile fetches itself again) so that the loop body has no branches
+            if (k == 2) issue(t + 1 < my_tiles ? t + 1 : t);
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) acc[tp] = MFMA32(fa[s], fb[s][tp], acc[tp]);
             __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
         }
-        if (t + 1 < my_tiles) commit(cur ^ 1);
+        commit(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
