@@ -85,12 +85,35 @@ static int check_conv_args(const char* who, const float* src0, int C0, int up0, 
     return VQW_OK;
 }
 
+// images per launch such that no tensor of the launch exceeds the 32-bit descriptor range (N when everything fits)
+static int conv_batch_group(int N, int H, int W, int Cin, int Cout) {
+    const long c = Cin > Cout ? Cin : Cout;
+    const long per_image = (long)H * W * c * 4;
+    if ((long)N * per_image <= 0xFFFFFFE0L || per_image > 0xFFFFFFE0L) return N;      // fits, or not even one image does
+    long g = 0xFFFFFFE0L / per_image;
+    return (int)(g < 1 ? 1 : g);
+}
+
 extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* src1, int C1, const float* w_ohwi,
                               const float* bias, float* y, int N, int H, int W, int Cout, int ksize, int dil, int relu,
                               void* stream) {
     int rc = check_conv_args("vqw_conv2d_fwd", src0, C0, up0, src1, C1, N, H, W, Cout, ksize, dil);
     if (rc) return rc;
     VQW_CHECK(w_ohwi && y, "vqw_conv2d_fwd: weights and output must be set");
+    {   // The MFMA kernels address each tensor through a 32-bit buffer descriptor (4 GiB).  Larger batches (288 GB of
+        // HBM invite them) are run as consecutive image groups that fit: images are independent in a convolution.
+        const int g = conv_batch_group(N, H, W, C0 + C1, Cout);
+        if (g < N) {
+            for (int n0 = 0; n0 < N; n0 += g) {
+                const int nn = N - n0 < g ? N - n0 : g;
+                const size_t px = (size_t)n0 * H * W;
+                rc = vqw_conv2d_fwd(src0 + (up0 ? px / 4 : px) * C0, C0, up0, src1 ? src1 + px * C1 : nullptr, C1, w_ohwi, bias,
+                                    y + px * Cout, nn, H, W, Cout, ksize, dil, relu, stream);
+                if (rc) return rc;
+            }
+            return VQW_OK;
+        }
+    }
     ConvIn in{src0, src1, C0, C1, up0};
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
@@ -115,6 +138,10 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
 
 extern "C" size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, int ksize) {
     int Cin = C0 + C1;
+    if (N > 0 && H > 0 && W > 0) {          // > 4 GiB tensors run as image groups: size for a group
+        const int g = conv_batch_group(N, H, W, Cin, Cout);
+        if (g < N) return vqw_conv2d_wgrad_ws_bytes(C0, C1, g, H, W, Cout, ksize);
+    }
     long P = (long)N * H * W;
     long nout = (long)Cout * ksize * ksize * Cin;
     size_t direct = (size_t)conv_direct_wgrad_splits(nout, P) * nout;
@@ -132,6 +159,19 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     if (rc) return rc;
     VQW_CHECK(dy && dw_ohwi && ws, "vqw_conv2d_wgrad: dy, dw and workspace must be set");
     VQW_CHECK(ws_bytes >= vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ksize), "vqw_conv2d_wgrad: workspace too small");
+    {   // > 4 GiB tensors: image groups, the later ones accumulating into dW / dbias (see vqw_conv2d_fwd)
+        const int g = conv_batch_group(N, H, W, C0 + C1, Cout);
+        if (g < N) {
+            for (int n0 = 0; n0 < N; n0 += g) {
+                const int nn = N - n0 < g ? N - n0 : g;
+                const size_t px = (size_t)n0 * H * W;
+                rc = vqw_conv2d_wgrad(src0 + (up0 ? px / 4 : px) * C0, C0, up0, src1 ? src1 + px * C1 : nullptr, C1, dy + px * Cout,
+                                      dw_ohwi, dbias, ws, ws_bytes, nn, H, W, Cout, ksize, dil, (accumulate || n0 > 0) ? 1 : 0, stream);
+                if (rc) return rc;
+            }
+            return VQW_OK;
+        }
+    }
     ConvIn in{src0, src1, C0, C1, up0};
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)ws;

@@ -981,3 +981,34 @@ def test_training_step_is_bit_deterministic():
     assert a[1] == b[1]
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
+
+
+def test_conv_tensors_beyond_4gib_run_as_image_groups():
+    """A conv whose activation tensors exceed the 32-bit buffer-descriptor range (4 GiB) is run by the library as
+    consecutive image groups: forward, input gradient and (accumulated) weight gradient equal the same work done in
+    explicit halves that fit."""
+    ops = _ops()
+    N, C, S = 18, 256, 512                       # 18 x 512 x 512 x 256 fp32 = 4.8 GB per tensor
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(N, C, S, S, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, C, 3, 3, device=DEV, generator=g) * 0.02).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(C, device=DEV, generator=g)
+    assert x.numel() * 4 > 2 ** 32
+
+    gy = torch.randn(N, C, S, S, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+
+    def run(xs, gys):
+        xs = xs.detach().requires_grad_(True)
+        ws, bs = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
+        y = ops.conv2d(xs, ws, bs)
+        y.backward(gys)
+        torch.cuda.synchronize()
+        return y.detach(), xs.grad, ws.grad, bs.grad
+    y, gx, gw, gb = run(x, gy)
+    h = N // 2
+    y1, gx1, gw1, gb1 = run(x[:h], gy[:h])
+    y2, gx2, gw2, gb2 = run(x[h:], gy[h:])
+    assert torch.equal(y[:h], y1) and torch.equal(y[h:], y2)
+    assert torch.equal(gx[:h], gx1) and torch.equal(gx[h:], gx2)
+    assert_close(gw, gw1 + gw2, 2e-5, "dw over image groups")
+    assert_close(gb, gb1 + gb2, 1e-4, "db over image groups", atol=1e-2)
