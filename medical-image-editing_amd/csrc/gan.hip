@@ -76,6 +76,133 @@ __global__ void __launch_bounds__(256) k_sconv_dgrad(const float* __restrict__ g
     }
 }
 
+// ---- the discriminator's 1-channel ends (1 -> 64 stride 2 in front, 512 -> 1 stride 1 at the back), 4x4 taps -----------
+// forward, Cin = 1: a thread owns one output pixel and four couts; the 16 input taps are read once into registers
+// (neighbouring threads of a pixel read the same addresses: broadcast), the 4 x 16 weights come from LDS.
+__global__ void __launch_bounds__(256) k_sconv_fwd_c1(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int N, int H, int W,
+                                                      int Ho, int Wo, int Cout, int stride, int pad, float slope) {
+    extern __shared__ float sw[];                          // [Cout][16]
+    for (int i = threadIdx.x; i < Cout * 16; i += 256) sw[i] = w[i];
+    __syncthreads();
+    const int C4 = Cout >> 2;
+    long total = (long)N * Ho * Wo * C4;
+    long gstride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        int c4 = (int)(i % C4);
+        long p = i / C4;
+        int xo = (int)(p % Wo);
+        long q = p / Wo;
+        int yo = (int)(q % Ho);
+        int n = (int)(q / Ho);
+        const float* img = x + (long)n * H * W;
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            int hy = yo * stride - pad + (t >> 2), wx = xo * stride - pad + (t & 3);
+            v[t] = ((unsigned)hy < (unsigned)H && (unsigned)wx < (unsigned)W) ? img[(long)hy * W + wx] : 0.f;
+        }
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = c4 * 4 + k;
+            float acc = bias ? bias[co] : 0.f;
+            const float* wr = sw + co * 16;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc = fmaf(v[t], wr[t], acc);
+            o[k] = lrelu(acc, slope);
+        }
+        *(float4*)(y + p * Cout + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+// input gradient, Cin = 1: a wave per input pixel group ... one thread per input pixel; the (at most 16) contributing
+// taps each read a contiguous Cout-vector of gy; weights w[co][t] from LDS transposed to [t][co]
+__global__ void __launch_bounds__(256) k_sconv_dgrad_c1(const float* __restrict__ gy, const float* __restrict__ w,
+                                                        float* __restrict__ gx, int N, int H, int W, int Ho, int Wo, int Cout,
+                                                        int stride, int pad) {
+    extern __shared__ float sw[];                          // [16][Cout]
+    for (int i = threadIdx.x; i < Cout * 16; i += 256) sw[(i & 15) * Cout + (i >> 4)] = w[i];
+    __syncthreads();
+    long total = (long)N * H * W;
+    long gstride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        int xx = (int)(i % W);
+        long q = i / W;
+        int yy = (int)(q % H);
+        int n = (int)(q / H);
+        float acc = 0.f;
+        for (int t = 0; t < 16; ++t) {
+            int ny = yy + pad - (t >> 2), nx = xx + pad - (t & 3);
+            if (ny < 0 || nx < 0 || ny % stride || nx % stride) continue;
+            int yo = ny / stride, xo = nx / stride;
+            if (yo >= Ho || xo >= Wo) continue;
+            const float4* g = (const float4*)(gy + (((long)n * Ho + yo) * Wo + xo) * Cout);
+            const float4* wr = (const float4*)(sw + t * Cout);
+            for (int c = 0; c < (Cout >> 2); ++c) {
+                float4 a = g[c], b = wr[c];
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
+        }
+        gx[i] = acc;
+    }
+}
+// forward, Cout = 1: one wave per output pixel, lanes over the input channels (float4 each), butterfly sum
+__global__ void __launch_bounds__(256) k_sconv_fwd_o1(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int N, int H, int W,
+                                                      int Ho, int Wo, int Cin, int stride, int pad, float slope) {
+    const int lane = threadIdx.x & 63;
+    long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+    const long total = (long)N * Ho * Wo;
+    for (long p = wave; p < total; p += nw) {
+        int xo = (int)(p % Wo);
+        long q = p / Wo;
+        int yo = (int)(q % Ho);
+        int n = (int)(q / Ho);
+        float acc = 0.f;
+        for (int t = 0; t < 16; ++t) {
+            int hy = yo * stride - pad + (t >> 2), wx = xo * stride - pad + (t & 3);
+            if ((unsigned)hy >= (unsigned)H || (unsigned)wx >= (unsigned)W) continue;      // wave-uniform
+            const float* s = x + (((long)n * H + hy) * W + wx) * Cin;
+            const float* wr = w + (long)t * Cin;
+            for (int c = lane * 4; c < Cin; c += 256) {
+                float4 a = *(const float4*)(s + c), b = *(const float4*)(wr + c);
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) y[p] = lrelu(acc + (bias ? bias[0] : 0.f), slope);
+    }
+}
+// input gradient, Cout = 1: gx[p][ci] = sum_t w[t][ci] * gy[out pixel of tap t]; thread per (pixel, 4 channels)
+__global__ void __launch_bounds__(256) k_sconv_dgrad_o1(const float* __restrict__ gy, const float* __restrict__ w,
+                                                        float* __restrict__ gx, int N, int H, int W, int Ho, int Wo, int Cin,
+                                                        int stride, int pad) {
+    const int C4 = Cin >> 2;
+    long total = (long)N * H * W * C4;
+    long gstride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gstride) {
+        int c4 = (int)(i % C4);
+        long p = i / C4;
+        int xx = (int)(p % W);
+        long q = p / W;
+        int yy = (int)(q % H);
+        int n = (int)(q / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < 16; ++t) {
+            int ny = yy + pad - (t >> 2), nx = xx + pad - (t & 3);
+            if (ny < 0 || nx < 0 || ny % stride || nx % stride) continue;
+            int yo = ny / stride, xo = nx / stride;
+            if (yo >= Ho || xo >= Wo) continue;
+            const float g = gy[((long)n * Ho + yo) * Wo + xo];
+            const float4 b = *(const float4*)(w + (long)t * Cin + c4 * 4);
+            acc.x = fmaf(g, b.x, acc.x); acc.y = fmaf(g, b.y, acc.y); acc.z = fmaf(g, b.z, acc.z); acc.w = fmaf(g, b.w, acc.w);
+        }
+        *(float4*)(gx + p * Cin + c4 * 4) = acc;
+    }
+}
+
 // weight gradient: workgroup = (co, tap, pixel split); threads stride over (pixel, ci); partial[split][co][tap][ci]
 __global__ void __launch_bounds__(256) k_sconv_wgrad(const float* __restrict__ x, const float* __restrict__ gy,
                                                      float* __restrict__ part, int N, int H, int W, int Ho, int Wo, int Cin,
@@ -253,7 +380,14 @@ extern "C" int vqw_sconv_fwd(const float* x, const float* w_ohwi, const float* b
         return crop_pad((const float*)ws, y, N, H, W, Ho, Wo, Cout, st);                  // ... cropped to (H-1) x (W-1)
     }
     long total = (long)N * Ho * Wo * Cout;
-    k_sconv_fwd<<<stream_grid(total, 256), 256, 0, st>>>(x, w_ohwi, bias, y, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad, slope);
+    if (ks == 4 && Cin == 1 && Cout % 4 == 0 && Cout <= 1024 && (((uintptr_t)y) & 15) == 0) {
+        k_sconv_fwd_c1<<<stream_grid(total / 4, 256), 256, Cout * 16 * sizeof(float), st>>>(x, w_ohwi, bias, y, N, H, W, Ho, Wo, Cout,
+                                                                                             stride, pad, slope);
+    } else if (ks == 4 && Cout == 1 && Cin % 4 == 0 && (((uintptr_t)x | (uintptr_t)w_ohwi) & 15) == 0) {
+        k_sconv_fwd_o1<<<stream_grid(total * 64, 256), 256, 0, st>>>(x, w_ohwi, bias, y, N, H, W, Ho, Wo, Cin, stride, pad, slope);
+    } else {
+        k_sconv_fwd<<<stream_grid(total, 256), 256, 0, st>>>(x, w_ohwi, bias, y, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad, slope);
+    }
     VQW_LAUNCH_CHECK("vqw_sconv_fwd");
     return VQW_OK;
 }
@@ -283,7 +417,13 @@ extern "C" int vqw_sconv_dgrad(const float* gy, const float* w_ohwi, float* gx, 
         return conv_k4s1_grid(gpad, wsf, nullptr, gx, N, H, W, Cout, Cin, 2, st);
     }
     long total = (long)N * H * W * Cin;
-    k_sconv_dgrad<<<stream_grid(total, 256), 256, 0, st>>>(gy, w_ohwi, gx, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad);
+    if (ks == 4 && Cin == 1 && Cout % 4 == 0 && Cout <= 1024 && (((uintptr_t)gy) & 15) == 0) {
+        k_sconv_dgrad_c1<<<stream_grid(total, 256), 256, Cout * 16 * sizeof(float), st>>>(gy, w_ohwi, gx, N, H, W, Ho, Wo, Cout, stride, pad);
+    } else if (ks == 4 && Cout == 1 && Cin % 4 == 0 && (((uintptr_t)gx | (uintptr_t)w_ohwi) & 15) == 0) {
+        k_sconv_dgrad_o1<<<stream_grid(total / 4, 256), 256, 0, st>>>(gy, w_ohwi, gx, N, H, W, Ho, Wo, Cin, stride, pad);
+    } else {
+        k_sconv_dgrad<<<stream_grid(total, 256), 256, 0, st>>>(gy, w_ohwi, gx, N, H, W, Ho, Wo, Cin, Cout, ks, stride, pad);
+    }
     VQW_LAUNCH_CHECK("vqw_sconv_dgrad");
     return VQW_OK;
 }
