@@ -25,6 +25,7 @@ static int env_int(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+static const int g_halo16 = env_int("VQW_HALO16", 1);        // 0: 16-cout layers on the 32-wide tile (A/B)
 static const int g_halo_kt = env_int("VQW_HALO_KT", 0);     // tuning aid: spatial tiles per workgroup (0 = default)
 // Workgroups of the one-per-CU kernels in this file.  256 = every CU of an MI355X.  A smaller value leaves CUs whose
 // LDS is not taken for kernels of other streams that need LDS of their own (e.g. RCCL collectives in data-parallel
@@ -51,12 +52,16 @@ struct HaloArgs {
 template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC>
 __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     constexpr int NT = 64 * NW;
-    constexpr int KP = KC + 4;
+    // BN == 16: the 16-cout layers run on v_mfma_f32_16x16x4_f32 (a 32-wide tile would be half padding); a row of 32
+    // pixels is two 16-pixel M blocks, rows are padded to 24 floats (conflict-free for its (pixel, k-quarter) lanes)
+    constexpr bool M16 = BN == 16;
+    constexpr int KP = M16 ? 24 : KC + 4;
     constexpr int C4 = KC / 4;
     constexpr int WC = (BN / 32 > 1 && NW > TH) ? 2 : 1;     // waves across N
     constexpr int WR = NW / WC;                               // waves across tile rows
-    constexpr int TM = TH / WR, TN = BN / 32 / WC;
-    static_assert(WR * TM == TH && WC * TN * 32 == BN, "wave grid must tile the workgroup tile");
+    constexpr int TM = TH / WR, TN = M16 ? 1 : BN / 32 / WC;
+    static_assert(WR * TM == TH && (M16 || WC * TN * 32 == BN), "wave grid must tile the workgroup tile");
+    static_assert(!M16 || KC == 16, "the 16-wide path takes 16-channel chunks");
     constexpr int HPIX = (TH + 2) * HALO_W;
     constexpr int HF = HPIX * C4;                 // float4 per halo chunk
     constexpr int LH = (HF + NT - 1) / NT;
@@ -176,8 +181,8 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     const int wr = wv / WC, wc = wv % WC;
     const int lrow = lane & 31, lk = (lane >> 5) * 4;
     // fragment bases (floats): A = pixel (row wr*TM + i, column lrow) of the halo at tap (0,0); B = cout wc*TN*32 + j*32 + lrow
-    const int a_base = ((wr * TM) * HALO_W + lrow) * KP + lk;
-    const int b_base = (wc * TN * 32 + lrow) * KP + lk;
+    const int a_base = M16 ? ((wr * TM) * HALO_W + (lane & 15)) * KP + (lane >> 4) * 4 : ((wr * TM) * HALO_W + lrow) * KP + lk;
+    const int b_base = M16 ? (lane & 15) * KP + (lane >> 4) * 4 : (wc * TN * 32 + lrow) * KP + lk;
 
     // Finished tiles are written one iteration late, BEFORE the next prefetch is issued, and through raw buffer stores
     // (an invalid row / cout gets the out-of-range offset and is dropped by the hardware: no branches).  Reason: gfx9
@@ -190,12 +195,13 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     unsigned co_off[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int co = co_base + (wc * TN + j) * 32 + (lane & 31);
+        const int co = M16 ? co_base + (lane & 15) : co_base + (wc * TN + j) * 32 + (lane & 31);
         bvv[j] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
         co_off[j] = co < Cout ? (unsigned)co : 0xFFFFFFFFu;
     }
-    const int col0 = 4 * (lane >> 5);
+    const int col0 = M16 ? 4 * (lane >> 4) : 4 * (lane >> 5);
     f32x16 acc[TM][TN], done[TM][TN];      // done: the finished tile with bias (+ReLU) applied, waiting to be stored
+    f32x4 acc4[TM][2], done4[TM][2];       // 16-wide path: two 16-pixel blocks per row, C/D = 4 pixel rows x 16 couts per lane
     int done_t = -1;
     // The stores take their data straight from `done` and one offset register per (row, cout tile); the pixel-column
     // part of the address is a scalar offset.  A pending store pins its source registers until vmcnt says it is done, so
@@ -213,10 +219,18 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
                 const bool ok = pending && co_off[j] != 0xFFFFFFFFu && yy < H;
                 const unsigned base = (((unsigned)n * H + (unsigned)yy) * W + (unsigned)(tx * 32 + col0)) * (unsigned)Cout + co_off[j];
                 const int voff = ok ? (int)(base * 4u) : (int)a.nby;       // out of range: dropped by the hardware
+                if constexpr (M16) {          // 16x16 C/D layout: col = lane&15 (cout), pixel = blk*16 + 4*(lane>>4) + r
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int col = (r & 3) + 8 * (r >> 2);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done[i][j][r]), rsy, voff, col * Cout * 4, 0);
+                    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done4[i][blk][r]), rsy, voff, (blk * 16 + r) * Cout * 4, 0);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = (r & 3) + 8 * (r >> 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done[i][j][r]), rsy, voff, col * Cout * 4, 0);
+                    }
                 }
             }
         }
@@ -227,55 +241,96 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         const int t = item / nch, ch = item - t * nch;
         if (ch == 0) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc4[i][blk][r] = 0.f;
+            }
         }
         const float* Hc = Hs + cur * HBUF + a_base;
         const float* Wc = Ws + (WPERSIST ? 0 : cur * WBUF) + b_base;
         // fragment reads run one group (4 k-steps) ahead of the MFMAs that consume them, so a wave's LDS latency hides
         // behind its own matrix work instead of relying on the partner wave
-        constexpr int KG = KC / 8, NG = 9 * KG;
-        float4 av[2][TM], bv[2][TN];
-        auto ldfrag = [&](int g, int s) {
-            const int tap = g / KG, kg = g % KG, ky = tap / 3, kx = tap % 3;
+        if constexpr (M16) {
+            // one group per tap: lane (pixel m = lane&15, k-quarter q = lane>>4) reads channels 4q..4q+3 of its pixel
+            // (block blk adds 16 pixels) and of cout n = lane&15; MFMA j of the group contracts channels {j, 4+j, 8+j, 12+j}
+            float4 av[2][TM][2], bv[2];
+            auto ldfrag = [&](int tap, int s) {
+                const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[s][i] = *(const float4*)&Hc[((i + ky) * HALO_W + kx) * KP + kg * 8];
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[s][j] = *(const float4*)&Wc[(tap * BN + j * 32) * KP + kg * 8];
-        };
-        ldfrag(0, 0);
+                    for (int blk = 0; blk < 2; ++blk)
+                        av[s][i][blk] = *(const float4*)&Hc[((i + ky) * HALO_W + kx + blk * 16) * KP];
+                bv[s] = *(const float4*)&Wc[(tap * 16) * KP];
+            };
+            ldfrag(0, 0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int s = g & 1;
-            if (g + 1 < NG) ldfrag(g + 1, s ^ 1);
-            if (g == 1) {
-                // The previous tile's stores and the next item's prefetch (address arithmetic, buffer loads) sit HERE,
-                // behind the first MFMA groups, so their vector instructions issue while the matrix pipe is busy
-                // instead of in front of the loop where both waves of a SIMD would leave it idle.
-                // No branches in this loop body: the last item prefetches itself again and every item "stores" (into
-                // the void when no tile is finished).  With conditional loads / commits the compiler cannot prove that
-                // a prefetch is always consumed before the next one and inserts waits that also drain the stores.
-                flush();
-                issue(item + 1 < nitems ? item + 1 : item);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = MFMA32(av[s][i].x, bv[s][j].x, acc[i][j]);
-                    acc[i][j] = MFMA32(av[s][i].y, bv[s][j].y, acc[i][j]);
-                    acc[i][j] = MFMA32(av[s][i].z, bv[s][j].z, acc[i][j]);
-                    acc[i][j] = MFMA32(av[s][i].w, bv[s][j].w, acc[i][j]);
+            for (int tap = 0; tap < 9; ++tap) {
+                const int s = tap & 1;
+                if (tap + 1 < 9) ldfrag(tap + 1, s ^ 1);
+                if (tap == 1) {
+                    flush();
+                    issue(item + 1 < nitems ? item + 1 : item);
                 }
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);          // next group's LDS reads first ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... then this group's MFMAs
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        acc4[i][blk] = MFMA16(av[s][i][blk].x, bv[s].x, acc4[i][blk]);
+                        acc4[i][blk] = MFMA16(av[s][i][blk].y, bv[s].y, acc4[i][blk]);
+                        acc4[i][blk] = MFMA16(av[s][i][blk].z, bv[s].z, acc4[i][blk]);
+                        acc4[i][blk] = MFMA16(av[s][i][blk].w, bv[s].w, acc4[i][blk]);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * TM, 0);
+            }
+        } else {
+            constexpr int KG = KC / 8, NG = 9 * KG;
+            float4 av[2][TM], bv[2][TN];
+            auto ldfrag = [&](int g, int s) {
+                const int tap = g / KG, kg = g % KG, ky = tap / 3, kx = tap % 3;
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) av[s][i] = *(const float4*)&Hc[((i + ky) * HALO_W + kx) * KP + kg * 8];
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) bv[s][j] = *(const float4*)&Wc[(tap * BN + j * 32) * KP + kg * 8];
+            };
+            ldfrag(0, 0);
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int s = g & 1;
+                if (g + 1 < NG) ldfrag(g + 1, s ^ 1);
+                if (g == 1) {
+                    // The previous tile's stores and the next item's prefetch (address arithmetic, buffer loads) sit HERE,
+                    // behind the first MFMA groups, so their vector instructions issue while the matrix pipe is busy
+                    // instead of in front of the loop where both waves of a SIMD would leave it idle.
+                    // No branches in this loop body: the last item prefetches itself again and every item "stores" (into
+                    // the void when no tile is finished).  With conditional loads / commits the compiler cannot prove that
+                    // a prefetch is always consumed before the next one and inserts waits that also drain the stores.
+                    flush();
+                    issue(item + 1 < nitems ? item + 1 : item);
+                }
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = MFMA32(av[s][i].x, bv[s][j].x, acc[i][j]);
+                        acc[i][j] = MFMA32(av[s][i].y, bv[s][j].y, acc[i][j]);
+                        acc[i][j] = MFMA32(av[s][i].z, bv[s][j].z, acc[i][j]);
+                        acc[i][j] = MFMA32(av[s][i].w, bv[s][j].w, acc[i][j]);
+                    }
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);          // next group's LDS reads first ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... then this group's MFMAs
+            }
         }
         if (ch == nch - 1) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -283,6 +338,14 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
                         const float v = acc[i][j][r] + bvv[j];
                         done[i][j][r] = a.relu ? fmaxf(v, 0.f) : v;
                     }
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc4[i][blk][r] + bvv[0];
+                        done4[i][blk][r] = a.relu ? fmaxf(v, 0.f) : v;
+                    }
+            }
             done_t = t;
         }
         commit(cur ^ 1);
@@ -295,7 +358,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
 template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC = false>
 int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
                 hipStream_t st) {
-    constexpr int KP = KC + 4;
+    constexpr int KP = BN == 16 ? 24 : KC + 4;
     constexpr size_t lds = (size_t)(2 * (TH + 2) * HALO_W * KP + (WPERSIST ? 1 : 2) * 9 * BN * KP) * sizeof(float);
     static_assert(lds <= 160 * 1024, "halo tile does not fit the 160 KB LDS");
     static bool attr_set = false;
@@ -349,6 +412,11 @@ bool conv_halo_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, i
 int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
                   hipStream_t st) {
     const int Cin = in.C0 + in.C1;
+    if (Cout <= 16 && g_halo16) {       // 16-cout layers: 16x16x4 MFMA, 16 x 32 pixel tiles
+        if (Cin == 16 && in.C1 == 0) return launch_halo<8, 16, 16, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st);
+        if (in.C1 > 0) return launch_halo<8, 16, 16, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st);
+        return launch_halo<8, 16, 16, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
+    }
     const bool wide = Cout > 32;        // 64-wide cout tile
     if (Cin == 32 && in.C1 == 0) {      // single chunk: weights stay in LDS
         if (wide) return launch_halo<8, 4, 64, 32, true>(in, w, bias, y, N, H, W, Cout, relu, st);

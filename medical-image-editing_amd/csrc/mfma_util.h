@@ -3,6 +3,8 @@
 #include "common.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // Bijective XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run
 // of tiles (neighbouring pixel tiles share halo rows and all N tiles of a pixel tile share the A operand in L2).

@@ -60,6 +60,10 @@ CONV_CASES = [
     (2, 16, 32, 16, 0, False, 32, 3, 1, False, False),
     (3, 12, 32, 48, 0, False, 80, 3, 1, True, False),
     (1, 16, 64, 16, 0, False, 48, 3, 1, True, True),
+    # 16-cout layers on the 16x16x4 MFMA path of the halo kernel (16 x 32 pixel tiles, ragged H, two sources)
+    (2, 32, 32, 16, 0, False, 16, 3, 1, True, True),
+    (1, 40, 64, 48, 0, False, 16, 3, 1, True, False),
+    (2, 48, 32, 32, 16, True, 16, 3, 1, False, False),
     # more dilated / narrow shapes (ragged sizes, dilation larger than a tile, wide couts on a 16-pixel map)
     (2, 50, 38, 32, 0, False, 32, 3, 6, True, False),
     (1, 96, 96, 32, 0, False, 32, 3, 18, False, True),
