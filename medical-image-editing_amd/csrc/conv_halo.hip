@@ -463,6 +463,10 @@ constexpr int WT_TH = 8;
 constexpr int WT_D = WT_TH * 32 * 32;                 // floats per dY tile
 constexpr int WT_X = (WT_TH + 2) * HALO_W * 32;       // floats per X halo
 
+// MB x NB = 2 x 2: the 32 x 32 (co x ci) tile on v_mfma_f32_32x32x2_f32.  Smaller values: 16-wide sides on
+// v_mfma_f32_16x16x4_f32 for layers with <= 16 couts and / or <= 16 input channels (a padded 32-wide side would waste
+// half or three quarters of the matrix work).
+template <int MB, int NB>
 __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
     constexpr int NT = 512;
     constexpr int LD = WT_TH * 32 * 8 / NT;                       // 4 dY float4 per thread
@@ -543,11 +547,20 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
         }
     };
 
+    constexpr bool FULL = MB == 2 && NB == 2;
     f32x16 acc[9];
+    f32x4 acc4[9][MB][NB];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc4[t][mb][nb][r] = 0.f;
+    }
 
     const int lcol = lane & 31, lk = lane >> 5;
     if (my_tiles > 0) {
@@ -557,28 +570,59 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
     __syncthreads();
     int cur = 0;
     for (int t = 0; t < my_tiles; ++t) {
-        const float* Dr = Ds + cur * WT_D + (wv * 32 + lk) * 32 + lcol;                 // a(k) = Dr[k * 32]
-        const float* Xr = Xs + cur * WT_X + (wv * HALO_W + lk) * 32 + lcol;             // b(ky,kx,k) = Xr[(ky*34 + k + kx) * 32]
-        float fa[2], fb[2][9];
-        auto ldfrag = [&](int k, int s) {
-            fa[s] = Dr[k * 32];
+        if constexpr (FULL) {
+            const float* Dr = Ds + cur * WT_D + (wv * 32 + lk) * 32 + lcol;                 // a(k) = Dr[k * 32]
+            const float* Xr = Xs + cur * WT_X + (wv * HALO_W + lk) * 32 + lcol;             // b(ky,kx,k) = Xr[(ky*34 + k + kx) * 32]
+            float fa[2], fb[2][9];
+            auto ldfrag = [&](int k, int s) {
+                fa[s] = Dr[k * 32];
+    #pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+    #pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) fb[s][ky * 3 + kx] = Xr[(ky * HALO_W + k + kx) * 32];
+            };
+            ldfrag(0, 0);
+    #pragma unroll
+            for (int k = 0; k < 32; k += 2) {
+                const int s = (k >> 1) & 1;
+                if (k + 2 < 32) ldfrag(k + 2, s ^ 1);
+                // the next tile's prefetch sits behind the first MFMAs (its address arithmetic issues while the matrix pipe
+                // is busy); unconditional (the last tile fetches itself again) so that the loop body has no branches
+                if (k == 2) issue(t + 1 < my_tiles ? t + 1 : t);
+    #pragma unroll
+                for (int tp = 0; tp < 9; ++tp) acc[tp] = MFMA32(fa[s], fb[s][tp], acc[tp]);
+                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+            }
+        } else {
+            // 16x16x4: lane (channel idx = lane&15, pixel q = lane>>4) of a 4-pixel k-step
+            const int idx = lane & 15, q = lane >> 4;
+            const float* Dr = Ds + cur * WT_D + (wv * 32 + q) * 32 + idx;                // a(mb, k) = Dr[k * 32 + mb * 16]
+            const float* Xr = Xs + cur * WT_X + (wv * HALO_W + q) * 32 + idx;            // b(tap, nb, k) = Xr[(ky*34 + k + kx) * 32 + nb * 16]
+            float fa[2][MB], fb[2][9][NB];
+            auto ldfrag = [&](int k, int s) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int mb = 0; mb < MB; ++mb) fa[s][mb] = Dr[k * 32 + mb * 16];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) fb[s][ky * 3 + kx] = Xr[(ky * HALO_W + k + kx) * 32];
-        };
-        ldfrag(0, 0);
+                for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-        for (int k = 0; k < 32; k += 2) {
-            const int s = (k >> 1) & 1;
-            if (k + 2 < 32) ldfrag(k + 2, s ^ 1);
-            // the next tile's prefetch sits behind the first MFMAs (its address arithmetic issues while the matrix pipe
-            // is busy); unconditional (the last tile fetches itself again) so that the loop body has no branches
-            if (k == 2) issue(t + 1 < my_tiles ? t + 1 : t);
+                    for (int nb = 0; nb < NB; ++nb) fb[s][tp][nb] = Xr[((tp / 3) * HALO_W + k + tp % 3) * 32 + nb * 16];
+            };
+            ldfrag(0, 0);
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) acc[tp] = MFMA32(fa[s], fb[s][tp], acc[tp]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+            for (int k = 0; k < 32; k += 4) {
+                const int s = (k >> 2) & 1;
+                if (k + 4 < 32) ldfrag(k + 4, s ^ 1);
+                if (k == 4) issue(t + 1 < my_tiles ? t + 1 : t);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) acc4[tp][mb][nb] = MFMA16(fa[s][mb], fb[s][tp][nb], acc4[tp][mb][nb]);
+                __builtin_amdgcn_sched_group_barrier(0x100, MB + 9 * NB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 9 * MB * NB, 0);
+            }
         }
         commit(cur ^ 1);
         __syncthreads();
@@ -601,10 +645,20 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+        if constexpr (FULL) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            red[wv * 1024 + row * 32 + (lane & 31)] = acc[t][r];
+            for (int r = 0; r < 16; ++r) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                red[wv * 1024 + row * 32 + (lane & 31)] = acc[t][r];
+            }
+        } else {          // 16x16 C/D layout: col = lane&15 (ci), row = 4*(lane>>4) + r (co); sides not computed stay unread
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[wv * 1024 + (mb * 16 + 4 * (lane >> 4) + r) * 32 + nb * 16 + (lane & 15)] = acc4[t][mb][nb][r];
         }
         __syncthreads();
 #pragma unroll
@@ -646,7 +700,10 @@ int conv_wgrad_tile(const ConvIn& in, const float* dy, float* ws, float* bpart, 
     static_assert(lds <= 160 * 1024, "wgrad tiles do not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_wgrad_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_wgrad_tile<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_wgrad_tile<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_wgrad_tile<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_wgrad_tile<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             vqw_set_error("conv_wgrad_tile: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
@@ -662,7 +719,11 @@ int conv_wgrad_tile(const ConvIn& in, const float* dy, float* ws, float* bpart, 
     a.nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4);
     a.nb1 = (unsigned)(P * in.C1 * 4);
     a.nbd = (unsigned)(P * Cout * 4);
-    k_conv_wgrad_tile<<<a.ntiles * nsb, 512, lds, st>>>(a);
+    const bool m16 = g_halo16 && Cout <= 16, n16 = g_halo16 && Cin <= 16;
+    if (m16 && n16) k_conv_wgrad_tile<1, 1><<<a.ntiles * nsb, 512, lds, st>>>(a);
+    else if (m16) k_conv_wgrad_tile<1, 2><<<a.ntiles * nsb, 512, lds, st>>>(a);
+    else if (n16) k_conv_wgrad_tile<2, 1><<<a.ntiles * nsb, 512, lds, st>>>(a);
+    else k_conv_wgrad_tile<2, 2><<<a.ntiles * nsb, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wgrad_tile");
     return VQW_OK;
 }
