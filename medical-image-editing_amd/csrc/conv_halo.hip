@@ -150,11 +150,12 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
             const int yy = y0 + h_y[j], xx = x0 + h_x[j];
             const bool ok = h_ok[j] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
             const unsigned pix = img + (unsigned)((yy >> sh) * Wsrc + (xx >> sh));
-            rh[j] = buf_ld4(rs, ok ? (pix * Csrc + cb) * 4u : nbs);
+            const unsigned off = (pix * Csrc + cb) * 4u;      // evaluated for every slot: a select, not an exec-masked block
+            rh[j] = buf_ld4(rs, sel_u32(ok, off, nbs));
         }
         if constexpr (!WPERSIST) {
 #pragma unroll
-            for (int j = 0; j < LW; ++j) rw[j] = buf_ld4(rsw, w_off[j] == a.nbw ? a.nbw : w_off[j] + (unsigned)cc * 4u);
+            for (int j = 0; j < LW; ++j) rw[j] = buf_ld4(rsw, sel_u32(w_off[j] == a.nbw, a.nbw, w_off[j] + (unsigned)cc * 4u));
         }
     };
     auto commit = [&](int buf) {       // registers -> LDS buffer `buf`
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
                 const int yy = ty * TH + wr * TM + i;
                 const bool ok = pending && co_off[j] != 0xFFFFFFFFu && yy < H;
                 const unsigned base = (((unsigned)n * H + (unsigned)yy) * W + (unsigned)(tx * 32 + col0)) * (unsigned)Cout + co_off[j];
-                const int voff = ok ? (int)(base * 4u) : (int)a.nby;       // out of range: dropped by the hardware
+                const int voff = (int)sel_u32(ok, base * 4u, a.nby);       // out of range: dropped by the hardware
                 if constexpr (M16) {          // 16x16 C/D layout: col = lane&15 (cout), pixel = blk*16 + 4*(lane>>4) + r
 #pragma unroll
                     for (int blk = 0; blk < 2; ++blk)

@@ -28,3 +28,8 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
     f.x = __uint_as_float(a); f.y = __uint_as_float(b); f.z = __uint_as_float(c); f.w = __uint_as_float(d);
     return f;
 }
+
+// A select between two values that are both evaluated.  Written as `c ? f(x) : k` the address arithmetic of f lands in
+// an exec-masked block of its own; basic-block boundaries inside an MFMA loop keep the scheduler from spreading the
+// prefetch / store instructions between the MFMAs (they end up in one run during which the matrix pipe idles).
+__device__ __forceinline__ unsigned sel_u32(bool c, unsigned a, unsigned b) { return c ? a : b; }

@@ -539,7 +539,11 @@ def test_extras_golden(golden):
     y = dec(x)
     (y * g.t("dec_ps/R", DEV)).sum().backward()
     assert_close(y, g["dec_ps/y"], 2e-4, "decoder (pixel shuffle) y")
-    assert_close(x.grad, g["dec_ps/gx"], 5e-3, "decoder (pixel shuffle) gx")
+    # conditioning: at 32x32 the bottom levels normalise 2x2 / 4x4 planes, and the reference's own fp32 result is 5.3e-3
+    # (relative L2) away from the same computation in fp64 (measured with the reference modules on CPU, one and eight
+    # threads agree to 1e-6).  Two fp32 implementations are therefore expected to differ by that order; the forward
+    # value above is the tight gate.
+    assert_close(x.grad, g["dec_ps/gx"], 1.5e-2, "decoder (pixel shuffle) gx")
     gmax = max(float(g[k]) for k in g.files if k.startswith("dec_ps/gnorm."))
     for k, p in dec.named_parameters():
         ref = float(g["dec_ps/gnorm." + k])
