@@ -127,44 +127,47 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         w_off[j] = (ok && co < Cout) ? (((unsigned)co * 9 + tap) * Cin + c4 * 4) * 4u : a.nbw;
     }
 
+    // ---- prefetch of the next (tile, chunk) item: global -> registers, in pieces -----------------------------------
+    // The address arithmetic, buffer loads and the previous tile's stores of an item are cut into SLOTS of a few vector
+    // instructions each, and one slot is placed behind each MFMA of the item's second fragment group onwards
+    // (sched_barrier keeps them there).  Left to itself the scheduler emits them as one run of ~200 instructions
+    // between two MFMAs; both waves of a SIMD reach that run together (they leave the barrier together), so the matrix
+    // pipe idled for the length of it once per item.  Everything is select-based ('&' instead of '&&', both arms of
+    // a ?: evaluated): no exec-masked blocks, the item body is one basic block.
     float4 rh[LH], rw[WPERSIST ? 1 : LW];
-    auto issue = [&](int item) {       // global -> registers for item (tile, chunk)
-        const int t = item / nch, ch = item - t * nch;
-        const int sp = sp0 + t;
-        const int n = sp / per_img, rem = sp - n * per_img;
-        const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
-        const int y0 = ty * TH - 1, x0 = tx * 32 - 1;
+    // wave-uniform state of the prefetch (set by issue_setup, used by the slots)
+    __amdgpu_buffer_rsrc_t i_rs = rs0;
+    unsigned i_Csrc = 0, i_nbs = 0, i_cb = 0, i_img = 0, i_cc4 = 0;
+    int i_sh = 0, i_Wsrc = 0, i_y0 = 0, i_x0 = 0;
+    auto issue_setup = [&](int n, int tx, int ty, int ch) {
         const int cc = ch * KC;
-        // a chunk never straddles the two sources; everything below is wave-uniform selection, no branches (single-source
-        // layers are a separate instantiation: choosing between two buffer descriptors compiles to a branch, and a
-        // basic-block boundary with stores in flight makes the compiler wait for them)
+        // a chunk never straddles the two sources (single-source layers are a separate instantiation)
         const bool from0 = !TWO_SRC || cc < C0;
         const bool up = from0 && up0;
-        const __amdgpu_buffer_rsrc_t rs = from0 ? rs0 : rs1;
-        const unsigned Csrc = from0 ? (unsigned)C0 : (unsigned)C1, nbs = from0 ? a.nb0 : a.nb1;
-        const unsigned cb = (unsigned)(from0 ? cc : cc - C0) + h_c;
-        const unsigned img = up ? (unsigned)n * Hs2 * Ws2 : (unsigned)n * H * W;
-        const int sh = up ? 1 : 0, Wsrc = up ? Ws2 : W;
-#pragma unroll
-        for (int j = 0; j < LH; ++j) {
-            const int yy = y0 + h_y[j], xx = x0 + h_x[j];
-            const bool ok = h_ok[j] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const unsigned pix = img + (unsigned)((yy >> sh) * Wsrc + (xx >> sh));
-            const unsigned off = (pix * Csrc + cb) * 4u;      // evaluated for every slot: a select, not an exec-masked block
-            rh[j] = buf_ld4(rs, sel_u32(ok, off, nbs));
-        }
-        if constexpr (!WPERSIST) {
-#pragma unroll
-            for (int j = 0; j < LW; ++j) rw[j] = buf_ld4(rsw, sel_u32(w_off[j] == a.nbw, a.nbw, w_off[j] + (unsigned)cc * 4u));
-        }
+        i_rs = from0 ? rs0 : rs1;
+        i_Csrc = from0 ? (unsigned)C0 : (unsigned)C1;
+        i_nbs = from0 ? a.nb0 : a.nb1;
+        i_cb = (unsigned)(from0 ? cc : cc - C0) + h_c;
+        i_img = up ? (unsigned)n * Hs2 * Ws2 : (unsigned)n * H * W;
+        i_sh = up ? 1 : 0;
+        i_Wsrc = up ? Ws2 : W;
+        i_y0 = ty * TH - 1;
+        i_x0 = tx * 32 - 1;
+        i_cc4 = (unsigned)cc * 4u;
     };
-    auto commit = [&](int buf) {       // registers -> LDS buffer `buf`
-#pragma unroll
-        for (int j = 0; j < LH; ++j) *(float4*)&Hs[buf * HBUF + h_lds[j]] = rh[j];
-        if constexpr (!WPERSIST) {
-#pragma unroll
-            for (int j = 0; j < LW; ++j) *(float4*)&Ws[buf * WBUF + w_lds[j]] = rw[j];
-        }
+    auto issue_h = [&](int j) {
+        const int yy = i_y0 + h_y[j], xx = i_x0 + h_x[j];
+        const bool ok = h_ok[j] & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);     // '&': no short-circuit blocks
+        const unsigned pix = i_img + (unsigned)((yy >> i_sh) * i_Wsrc + (xx >> i_sh));
+        rh[j] = buf_ld4(i_rs, sel_u32(ok, (pix * i_Csrc + i_cb) * 4u, i_nbs));
+    };
+    auto issue_w = [&](int j) {
+        if constexpr (!WPERSIST) rw[j] = buf_ld4(rsw, sel_u32(w_off[j] == a.nbw, a.nbw, w_off[j] + i_cc4));
+    };
+    // registers -> LDS buffer `buf`, one float4 per piece
+    auto commit_h = [&](int j, int buf) { *(float4*)&Hs[buf * HBUF + h_lds[j]] = rh[j]; };
+    auto commit_w = [&](int j, int buf) {
+        if constexpr (!WPERSIST) *(float4*)&Ws[buf * WBUF + w_lds[j]] = rw[j];
     };
 
     if (nitems <= 0) return;           // uniform per workgroup
@@ -175,8 +178,24 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
             *(float4*)&Ws[w_lds[j]] = v;
         }
     }
-    issue(0);
-    commit(0);
+    // tile coordinates are carried incrementally (tiles of a workgroup are consecutive: down a column strip, then the
+    // next strip, then the next image): no integer divisions in the item loop
+    int cn, ctx, cty, ch = 0;
+    {
+        cn = sp0 / per_img;
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    issue_setup(cn, ctx, cty, 0);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) issue_h(j);
+#pragma unroll
+    for (int j = 0; j < LW; ++j) issue_w(j);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) commit_h(j, 0);
+#pragma unroll
+    for (int j = 0; j < LW; ++j) commit_w(j, 0);
     __syncthreads();
 
     const int wr = wv / WC, wc = wv % WC;
@@ -185,12 +204,11 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     const int a_base = M16 ? ((wr * TM) * HALO_W + (lane & 15)) * KP + (lane >> 4) * 4 : ((wr * TM) * HALO_W + lrow) * KP + lk;
     const int b_base = M16 ? (lane & 15) * KP + (lane >> 4) * 4 : (wc * TN * 32 + lrow) * KP + lk;
 
-    // Finished tiles are written one iteration late, BEFORE the next prefetch is issued, and through raw buffer stores
-    // (an invalid row / cout gets the out-of-range offset and is dropped by the hardware: no branches).  Reason: gfx9
+    // Finished tiles are written one item late, through raw buffer stores (an invalid row / cout gets the out-of-range
+    // offset and is dropped by the hardware: no branches) that are older than the item's prefetch loads.  Reason: gfx9
     // counts loads and stores in one vmcnt and the compiler treats the mix as unordered, so stores issued between a
-    // prefetch and its use turn every later wait into vmcnt(0), one of them inside the MFMA loop.  With the stores
-    // older than the loads, the single wait before the LDS commit finds both long finished.  (Same-box A/B: +6 % on
-    // 32->64, +2.5 % on 160->32, -1.5 % on the widest layers, equal on average: the partner wave was hiding most of it.)
+    // prefetch and its use turn every later wait into vmcnt(0); with the stores older than the loads, the wait in front
+    // of the LDS commit finds both long finished.
     const __amdgpu_buffer_rsrc_t rsy = make_rsrc(a.y, a.nby);
     float bvv[TN];
     unsigned co_off[TN];
@@ -203,43 +221,55 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     const int col0 = M16 ? 4 * (lane >> 4) : 4 * (lane >> 5);
     f32x16 acc[TM][TN], done[TM][TN];      // done: the finished tile with bias (+ReLU) applied, waiting to be stored
     f32x4 acc4[TM][2], done4[TM][2];       // 16-wide path: two 16-pixel blocks per row, C/D = 4 pixel rows x 16 couts per lane
-    int done_t = -1;
-    // The stores take their data straight from `done` and one offset register per (row, cout tile); the pixel-column
-    // part of the address is a scalar offset.  A pending store pins its source registers until vmcnt says it is done, so
-    // stores fed from temporaries would make the code after them (the next prefetch) wait a full memory round trip.
-    auto flush = [&]() {               // C/D layout: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel column)
-        const bool pending = done_t >= 0;          // nothing finished: every offset is out of range, the stores are dropped
-        const int sp = sp0 + (pending ? done_t : 0);
-        const int n = sp / per_img, rem = sp - n * per_img;
-        const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
+    const float lo = a.relu ? 0.f : -__builtin_inff();      // ReLU epilogue = max against 0, no ReLU = max against -inf
+    bool pending = false;                  // a finished tile waits in `done`
+    int dn = 0, dtx = 0, dty = 0;          // its coordinates
+    // The stores take their data straight from `done` and one offset register per piece; the pixel-column part of the
+    // address is a scalar offset.  A pending store pins its source registers until vmcnt says it is done, so stores fed
+    // from temporaries would make the code after them wait a full memory round trip.
+    // C/D layout (32x32): col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel column)
+    constexpr int NFP = M16 ? TM : 2 * TM * TN;          // store pieces of 8 stores
+    auto flush_piece = [&](int s) {
+        const int i = M16 ? s : (s >> 1) % TM, j = M16 ? 0 : (s >> 1) / TM, half = s & 1;
+        const int yy = dty * TH + wr * TM + i;
+        const bool ok = pending & (co_off[j] != 0xFFFFFFFFu) & (yy < H);
+        const unsigned base = (((unsigned)dn * H + (unsigned)yy) * W + (unsigned)(dtx * 32 + col0)) * (unsigned)Cout + co_off[j];
+        const int voff = (int)sel_u32(ok, base * 4u, a.nby);       // nothing finished / out of range: dropped by the hardware
+        if constexpr (M16) {          // 16x16 C/D layout: col = lane&15 (cout), pixel = blk*16 + 4*(lane>>4) + r
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+            for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int yy = ty * TH + wr * TM + i;
-                const bool ok = pending && co_off[j] != 0xFFFFFFFFu && yy < H;
-                const unsigned base = (((unsigned)n * H + (unsigned)yy) * W + (unsigned)(tx * 32 + col0)) * (unsigned)Cout + co_off[j];
-                const int voff = (int)sel_u32(ok, base * 4u, a.nby);       // out of range: dropped by the hardware
-                if constexpr (M16) {          // 16x16 C/D layout: col = lane&15 (cout), pixel = blk*16 + 4*(lane>>4) + r
+                for (int r = 0; r < 4; ++r)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done4[i][blk][r]), rsy, voff, (blk * 16 + r) * Cout * 4, 0);
+        } else {
 #pragma unroll
-                    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done4[i][blk][r]), rsy, voff, (blk * 16 + r) * Cout * 4, 0);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int col = (r & 3) + 8 * (r >> 2);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done[i][j][r]), rsy, voff, col * Cout * 4, 0);
-                    }
-                }
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int r = half * 8 + r8;
+                const int col = (r & 3) + 8 * (r >> 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done[i][j][r]), rsy, voff, col * Cout * 4, 0);
             }
         }
-        done_t = -1;
     };
+    constexpr int NLW = WPERSIST ? 0 : LW;
+    constexpr int NSLOT = NFP + LH + NLW;                 // stores, then loads: MFMA positions [0, NSLOT) behind group 0
+    // The LDS commit of the prefetched item (buffer cur^1: free since the barrier that ended the previous item) is also
+    // spread behind MFMAs, in the second half of the item, when the loads have long landed.  At the end of an item only
+    // the barrier is left; before, all eight waves wrote their 3-8 float4 there together (LDS write bandwidth:
+    // 22-58 KB per item at 128 B/clk) with the matrix pipe empty.
+    constexpr int NMF = M16 ? 8 * 8 * TM : (9 * (KC / 8) - 1) * 4 * TM * TN;     // MFMA positions behind group 0
+    constexpr int NCOM = LH + NLW;
+    constexpr int CS = (NMF / 2 > NSLOT ? NMF / 2 : NSLOT);
+    static_assert(CS + NCOM <= NMF, "more slots than MFMAs to hide them behind");
     int cur = 0;
+    auto slot = [&](int s) {           // s is a compile-time constant after unrolling
+        if (s < NFP) flush_piece(s);
+        else if (s < NFP + LH) issue_h(s - NFP);
+        else if (s < NSLOT) issue_w(s - NFP - LH);
+        else if (s >= CS && s < CS + LH) commit_h(s - CS, cur ^ 1);
+        else if (s >= CS + LH && s < CS + NCOM) commit_w(s - CS - LH, cur ^ 1);
+    };
+    auto slotted = [&](int s0, int n) { return s0 >= 0 && (s0 < NSLOT || (s0 + n > CS && s0 < CS + NCOM)); };
     for (int item = 0; item < nitems; ++item) {
-        const int t = item / nch, ch = item - t * nch;
         if (ch == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -253,6 +283,17 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
                     for (int r = 0; r < 4; ++r) acc4[i][blk][r] = 0.f;
             }
         }
+        // next item = next chunk of this tile, or chunk 0 of the next tile.  Past the last item the coordinates run off
+        // the workgroup's share: those loads read another tile or nothing (out-of-range offsets return 0) and their
+        // LDS copy is never consumed.
+        const int nxch = ch + 1 == nch ? 0 : ch + 1;
+        const int adv = ch + 1 == nch ? 1 : 0;
+        const int ty1 = cty + adv, wy = ty1 == a.tilesY ? 1 : 0;
+        const int nty = wy ? 0 : ty1;
+        const int tx1 = ctx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        const int ntx = wx ? 0 : tx1;
+        const int nn = cn + wx;
+        issue_setup(nn, ntx, nty, nxch);
         const float* Hc = Hs + cur * HBUF + a_base;
         const float* Wc = Ws + (WPERSIST ? 0 : cur * WBUF) + b_base;
         // fragment reads run one group (4 k-steps) ahead of the MFMAs that consume them, so a wave's LDS latency hides
@@ -270,29 +311,35 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
                         av[s][i][blk] = *(const float4*)&Hc[((i + ky) * HALO_W + kx + blk * 16) * KP];
                 bv[s] = *(const float4*)&Wc[(tap * 16) * KP];
             };
+            constexpr int GM = 8 * TM;         // MFMAs per group
             ldfrag(0, 0);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int s = tap & 1;
                 if (tap + 1 < 9) ldfrag(tap + 1, s ^ 1);
-                if (tap == 1) {
-                    flush();
-                    issue(item + 1 < nitems ? item + 1 : item);
-                }
+                const bool sl = slotted((tap - 1) * GM, GM);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int blk = 0; blk < 2; ++blk) {
+                        const int m0 = (tap - 1) * GM + (i * 2 + blk) * 4;
                         acc4[i][blk] = MFMA16(av[s][i][blk].x, bv[s].x, acc4[i][blk]);
+                        if (sl) { slot(m0); __builtin_amdgcn_sched_barrier(0); }
                         acc4[i][blk] = MFMA16(av[s][i][blk].y, bv[s].y, acc4[i][blk]);
+                        if (sl) { slot(m0 + 1); __builtin_amdgcn_sched_barrier(0); }
                         acc4[i][blk] = MFMA16(av[s][i][blk].z, bv[s].z, acc4[i][blk]);
+                        if (sl) { slot(m0 + 2); __builtin_amdgcn_sched_barrier(0); }
                         acc4[i][blk] = MFMA16(av[s][i][blk].w, bv[s].w, acc4[i][blk]);
+                        if (sl) { slot(m0 + 3); __builtin_amdgcn_sched_barrier(0); }
                     }
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8 * TM, 0);
+                if (!sl) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2 * TM + 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8 * TM, 0);
+                }
             }
         } else {
             constexpr int KG = KC / 8, NG = 9 * KG;
+            constexpr int GM = 4 * TM * TN;    // MFMAs per group
             float4 av[2][TM], bv[2][TN];
             auto ldfrag = [&](int g, int s) {
                 const int tap = g / KG, kg = g % KG, ky = tap / 3, kx = tap % 3;
@@ -306,54 +353,49 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
             for (int g = 0; g < NG; ++g) {
                 const int s = g & 1;
                 if (g + 1 < NG) ldfrag(g + 1, s ^ 1);
-                if (g == 1) {
-                    // The previous tile's stores and the next item's prefetch (address arithmetic, buffer loads) sit HERE,
-                    // behind the first MFMA groups, so their vector instructions issue while the matrix pipe is busy
-                    // instead of in front of the loop where both waves of a SIMD would leave it idle.
-                    // No branches in this loop body: the last item prefetches itself again and every item "stores" (into
-                    // the void when no tile is finished).  With conditional loads / commits the compiler cannot prove that
-                    // a prefetch is always consumed before the next one and inserts waits that also drain the stores.
-                    flush();
-                    issue(item + 1 < nitems ? item + 1 : item);
-                }
+                const bool sl = slotted((g - 1) * GM, GM);
     #pragma unroll
                 for (int i = 0; i < TM; ++i)
     #pragma unroll
                     for (int j = 0; j < TN; ++j) {
+                        const int m0 = (g - 1) * GM + (i * TN + j) * 4;
                         acc[i][j] = MFMA32(av[s][i].x, bv[s][j].x, acc[i][j]);
+                        if (sl) { slot(m0); __builtin_amdgcn_sched_barrier(0); }
                         acc[i][j] = MFMA32(av[s][i].y, bv[s][j].y, acc[i][j]);
+                        if (sl) { slot(m0 + 1); __builtin_amdgcn_sched_barrier(0); }
                         acc[i][j] = MFMA32(av[s][i].z, bv[s][j].z, acc[i][j]);
+                        if (sl) { slot(m0 + 2); __builtin_amdgcn_sched_barrier(0); }
                         acc[i][j] = MFMA32(av[s][i].w, bv[s][j].w, acc[i][j]);
+                        if (sl) { slot(m0 + 3); __builtin_amdgcn_sched_barrier(0); }
                     }
-                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);          // next group's LDS reads first ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);      // ... then this group's MFMAs
+                if (!sl) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);          // next group's LDS reads first ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, GM, 0);               // ... then this group's MFMAs
+                }
             }
         }
+        pending = false;               // the slots above stored it
         if (ch == nch - 1) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[i][j][r] + bvv[j];
-                        done[i][j][r] = a.relu ? fmaxf(v, 0.f) : v;
-                    }
+                    for (int r = 0; r < 16; ++r) done[i][j][r] = fmaxf(acc[i][j][r] + bvv[j], lo);
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = acc4[i][blk][r] + bvv[0];
-                        done4[i][blk][r] = a.relu ? fmaxf(v, 0.f) : v;
-                    }
+                    for (int r = 0; r < 4; ++r) done4[i][blk][r] = fmaxf(acc4[i][blk][r] + bvv[0], lo);
             }
-            done_t = t;
+            pending = true;
+            dn = cn; dtx = ctx; dty = cty;
         }
-        commit(cur ^ 1);
-        __syncthreads();
+        ch = nxch; cn = nn; ctx = ntx; cty = nty;
+        __syncthreads();               // the item's slots committed buffer cur^1
         cur ^= 1;
     }
-    flush();
+#pragma unroll
+    for (int s = 0; s < NFP; ++s) flush_piece(s);
 }
 
 template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC = false>
