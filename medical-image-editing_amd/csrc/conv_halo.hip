@@ -546,48 +546,36 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
     float4 rd[LD], rx[LX];
     float4 bsum;
     bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
-    auto issue = [&](int t) {
-        const int sp = sp0 + t;
-        const int n = sp / per_img, rem = sp - n * per_img;
-        const int tx = rem / a.tilesY, ty = rem - tx * a.tilesY;
-        const int y0 = ty * WT_TH, x0 = tx * 32;
-        int ps = pslot;
-        asm volatile("" : "+v"(ps));               // keep the per-slot coordinates out of long-lived registers
-#pragma unroll
-        for (int j = 0; j < LD; ++j) {
-            const int pix = ps + 64 * j;            // 0..255
-            const int yy = y0 + (pix >> 5), xx = x0 + (pix & 31);
-            const bool ok = d_ok && yy < H;
-            const unsigned p = ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
-            rd[j] = buf_ld4(rsd, ok ? (p * (unsigned)Cout + d_c) * 4u : a.nbd);
-        }
-#pragma unroll
-        for (int j = 0; j < LX; ++j) {
-            const int hp = ps + 64 * j;             // 0..339 valid
-            const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-            const bool ok = hp < (WT_TH + 2) * HALO_W && x_cok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            const unsigned pix = x_up ? ((unsigned)n * Hs2 + (unsigned)(yy >> 1)) * Ws2 + (unsigned)(xx >> 1)
-                                      : ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
-            rx[j] = buf_ld4(rsx, ok ? pix * xC * 4u + x_cb : nbx);
-        }
+    // Prefetch of the next tile (global -> registers) and its LDS commit, in pieces that are placed behind single MFMAs
+    // of the tile loop (see k_conv_halo): select-based addresses, no exec-masked blocks, one basic block per tile.
+    const int x_sh = x_up ? 1 : 0, x_Hs = x_up ? Hs2 : H, x_Ws = x_up ? Ws2 : W;
+    int i_n = 0, i_y0 = 0, i_x0 = 0;
+    auto issue_setup = [&](int n, int tx, int ty) { i_n = n; i_y0 = ty * WT_TH; i_x0 = tx * 32; };
+    auto issue_d = [&](int j) {
+        const int pix = pslot + 64 * j;             // 0..255
+        const int yy = i_y0 + (pix >> 5), xx = i_x0 + (pix & 31);
+        const bool ok = d_ok & (yy < H);
+        const unsigned p = ((unsigned)i_n * H + (unsigned)yy) * W + (unsigned)xx;
+        rd[j] = buf_ld4(rsd, sel_u32(ok, (p * (unsigned)Cout + d_c) * 4u, a.nbd));
     };
-    int committed = 0;
-    auto commit = [&](int buf) {
-        float* D = Ds + buf * WT_D;
-        float* X = Xs + buf * WT_X;
-        const float once = committed < my_tiles ? 1.f : 0.f;      // the duplicate prefetch of the last tile is not a new tile
-        ++committed;
-#pragma unroll
-        for (int j = 0; j < LD; ++j) {
-            *(float4*)&D[(tid + NT * j) * 4] = rd[j];
-            bsum.x += once * rd[j].x; bsum.y += once * rd[j].y; bsum.z += once * rd[j].z; bsum.w += once * rd[j].w;   // fused bias gradient
-        }
-#pragma unroll
-        for (int j = 0; j < LX; ++j) {
-            const int f = tid + NT * j;
-            if (XF % NT == 0 || f < XF) *(float4*)&X[f * 4] = rx[j];
-        }
+    auto issue_x = [&](int j) {
+        const int hp = pslot + 64 * j;              // 0..339 valid
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int yy = i_y0 - 1 + hy, xx = i_x0 - 1 + hx;
+        const bool ok = (hp < (WT_TH + 2) * HALO_W) & x_cok & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+        const unsigned pix = ((unsigned)i_n * x_Hs + (unsigned)(yy >> x_sh)) * x_Ws + (unsigned)(xx >> x_sh);
+        rx[j] = buf_ld4(rsx, sel_u32(ok, pix * xC * 4u + x_cb, nbx));
+    };
+    // `once`: 1 when the committed tile is one of this workgroup's (the prefetch behind the last tile runs off its share)
+    auto commit_d = [&](int j, int buf, float once) {
+        *(float4*)&Ds[buf * WT_D + (tid + NT * j) * 4] = rd[j];
+        bsum.x += once * rd[j].x; bsum.y += once * rd[j].y; bsum.z += once * rd[j].z; bsum.w += once * rd[j].w;   // fused bias gradient
+    };
+    float* const xdummy = smem + 2 * (WT_D + WT_X) + tid * 4;      // slots past the halo park their write here
+    auto commit_x = [&](int j, int buf) {
+        const int f = tid + NT * j;
+        float* dst = (XF % NT == 0 || f < XF) ? &Xs[buf * WT_X + f * 4] : xdummy;
+        *(float4*)dst = rx[j];
     };
 
     constexpr bool FULL = MB == 2 && NB == 2;
@@ -606,13 +594,50 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
     }
 
     const int lcol = lane & 31, lk = lane >> 5;
+    // tile coordinates carried incrementally (consecutive tiles: down a column strip, next strip, next image)
+    int cn = sp0 / per_img, ctx, cty;
+    {
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
     if (my_tiles > 0) {
-        issue(0);
-        commit(0);
+        issue_setup(cn, ctx, cty);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) issue_d(j);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) issue_x(j);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) commit_d(j, 0, 1.f);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) commit_x(j, 0);
     }
     __syncthreads();
     int cur = 0;
+    constexpr int GM = FULL ? 9 : 9 * MB * NB;       // MFMAs per k-step
+    constexpr int NKS = FULL ? 16 : 8;               // k-steps per tile
+    constexpr int NMF = (NKS - 1) * GM;              // MFMA positions behind the first k-step
+    constexpr int NSLOT = LD + LX;                   // loads: positions [0, NSLOT); commits: [CS, CS + NSLOT) in the second half
+    constexpr int CS = NMF / 2 > NSLOT ? NMF / 2 : NSLOT;
+    static_assert(CS + NSLOT <= NMF, "more slots than MFMAs to hide them behind");
+    float once = 0.f;
+    auto slot = [&](int s) {
+        if (s < LD) issue_d(s);
+        else if (s < NSLOT) issue_x(s - LD);
+        else if (s >= CS && s < CS + LD) commit_d(s - CS, cur ^ 1, once);
+        else if (s >= CS + LD && s < CS + NSLOT) commit_x(s - CS - LD, cur ^ 1);
+    };
+    auto slotted = [&](int s0) { return s0 >= 0 && (s0 < NSLOT || (s0 + GM > CS && s0 < CS + NSLOT)); };
     for (int t = 0; t < my_tiles; ++t) {
+        {   // next tile (past the last one the loads read another tile or nothing; their LDS copy is never consumed)
+            const int ty1 = cty + 1, wy = ty1 == a.tilesY ? 1 : 0;
+            cty = wy ? 0 : ty1;
+            const int tx1 = ctx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+            ctx = wx ? 0 : tx1;
+            cn += wx;
+            issue_setup(cn, ctx, cty);
+            once = t + 1 < my_tiles ? 1.f : 0.f;
+        }
         if constexpr (FULL) {
             const float* Dr = Ds + cur * WT_D + (wv * 32 + lk) * 32 + lcol;                 // a(k) = Dr[k * 32]
             const float* Xr = Xs + cur * WT_X + (wv * HALO_W + lk) * 32 + lcol;             // b(ky,kx,k) = Xr[(ky*34 + k + kx) * 32]
@@ -629,13 +654,17 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
             for (int k = 0; k < 32; k += 2) {
                 const int s = (k >> 1) & 1;
                 if (k + 2 < 32) ldfrag(k + 2, s ^ 1);
-                // the next tile's prefetch sits behind the first MFMAs (its address arithmetic issues while the matrix pipe
-                // is busy); unconditional (the last tile fetches itself again) so that the loop body has no branches
-                if (k == 2) issue(t + 1 < my_tiles ? t + 1 : t);
+                const int s0 = ((k >> 1) - 1) * GM;
+                const bool sl = slotted(s0);
     #pragma unroll
-                for (int tp = 0; tp < 9; ++tp) acc[tp] = MFMA32(fa[s], fb[s][tp], acc[tp]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+                for (int tp = 0; tp < 9; ++tp) {
+                    acc[tp] = MFMA32(fa[s], fb[s][tp], acc[tp]);
+                    if (sl) { slot(s0 + tp); __builtin_amdgcn_sched_barrier(0); }
+                }
+                if (!sl) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+                }
             }
         } else {
             // 16x16x4: lane (channel idx = lane&15, pixel q = lane>>4) of a 4-pixel k-step
@@ -656,19 +685,24 @@ __global__ void __launch_bounds__(512, 1) k_conv_wgrad_tile(WgTileArgs a) {
             for (int k = 0; k < 32; k += 4) {
                 const int s = (k >> 2) & 1;
                 if (k + 4 < 32) ldfrag(k + 4, s ^ 1);
-                if (k == 4) issue(t + 1 < my_tiles ? t + 1 : t);
+                const int s0 = ((k >> 2) - 1) * GM;
+                const bool sl = slotted(s0);
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
                     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) acc4[tp][mb][nb] = MFMA16(fa[s][mb], fb[s][tp][nb], acc4[tp][mb][nb]);
-                __builtin_amdgcn_sched_group_barrier(0x100, MB + 9 * NB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 9 * MB * NB, 0);
+                        for (int nb = 0; nb < NB; ++nb) {
+                            acc4[tp][mb][nb] = MFMA16(fa[s][mb], fb[s][tp][nb], acc4[tp][mb][nb]);
+                            if (sl) { slot(s0 + (tp * MB + mb) * NB + nb); __builtin_amdgcn_sched_barrier(0); }
+                        }
+                if (!sl) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, MB + 9 * NB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 9 * MB * NB, 0);
+                }
             }
         }
-        commit(cur ^ 1);
-        __syncthreads();
+        __syncthreads();               // the tile's slots committed buffer cur^1
         cur ^= 1;
     }
 
@@ -739,7 +773,7 @@ int conv_wgrad_tile_blocks(int Cin, int Cout, int N, int H, int W, int max_block
 }
 int conv_wgrad_tile(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st) {
-    constexpr size_t lds = (size_t)2 * (WT_D + WT_X) * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * (WT_D + WT_X) + 512 * 4) * sizeof(float);      // + one parking float4 per thread
     static_assert(lds <= 160 * 1024, "wgrad tiles do not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
