@@ -117,6 +117,18 @@ __global__ void __launch_bounds__(1024) k_reduce_rows(const float* __restrict__ 
     if (i < n) {
         int r = g;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        for (; r + 112 < rows; r += 128) {          // many slabs (split-K of the small 1x1 layers): eight loads in flight
+            a0 += part[(long)r * n + i];
+            a1 += part[(long)(r + 16) * n + i];
+            a2 += part[(long)(r + 32) * n + i];
+            a3 += part[(long)(r + 48) * n + i];
+            b0 += part[(long)(r + 64) * n + i];
+            b1 += part[(long)(r + 80) * n + i];
+            b2 += part[(long)(r + 96) * n + i];
+            b3 += part[(long)(r + 112) * n + i];
+        }
+        a0 += b0; a1 += b1; a2 += b2; a3 += b3;
         for (; r + 48 < rows; r += 64) {
             a0 += part[(long)r * n + i];
             a1 += part[(long)(r + 16) * n + i];

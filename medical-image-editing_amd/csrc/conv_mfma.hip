@@ -310,11 +310,16 @@ static int dispatch_fwd(const ConvIn& in, const float* w, const float* bias, flo
     auto cost = [&](int bn, double eff) { return (double)ceil_div(Cout, bn) * bn / eff; };
     const double c128 = cost(128, 1.0), c64 = cost(64, 0.82), c32 = cost(32, 0.70);
     const bool deep = geo.ntaps * ceil_div(Cin, k32 ? 32 : 16) >= 12;      // enough chunks to amortise the deeper prologue
-    if (c128 <= c64 && c128 <= c32) {
+    // small pixel counts (the 16 x 16 level: 8192 pixels per view): 128 x 128 tiles give at most one workgroup per CU,
+    // or leave half the CUs idle (256 couts: 128 workgroups); the 64-wide tile doubles the grid and two workgroups
+    // share a CU
+    const long wg128 = (long)ceil_div((long)N * H * W, 128) * ceil_div(Cout, 128);
+    const bool small_grid = wg128 <= 256 && Cout % 64 == 0 && k32;
+    if (c128 <= c64 && c128 <= c32 && !small_grid) {
         if (k32) return launch_fwd<128, 128, 64, 64, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
         return launch_fwd<128, 128, 64, 64, 16, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
     }
-    if (c64 <= c32) {
+    if (c64 <= c32 || small_grid) {
         if (k32 && deep) return launch_fwd<128, 64, 64, 32, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
         if (k32) return launch_fwd<128, 64, 64, 32, 32, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
         return launch_fwd<128, 64, 64, 32, 16, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
@@ -1042,14 +1047,24 @@ bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks) {
 
 static inline int wg_tile(int c) { return c > 64 ? 128 : (c > 32 ? 64 : 32); }
 
+// Split-K factor of the per-tap wgrad kernel: as many pixel ranges as fill the GPU ONCE with resident workgroups.
+// Tiles up to 64 x 64 are single-wave workgroups with 16-32 KB of LDS: ten of them fit a CU, and the small 1x1 layers
+// that use them are HBM-bound streams which need that many waves to keep enough loads in flight (16->32 1x1 at 256^2:
+// 512 one-wave workgroups = 2 waves per CU read at 1 TB/s).  The 128-wide tiles are MFMA-bound: a second, partly
+// filled round of workgroups and short K ranges (slab write + reduction per range) cost more than they balance.
 static inline int wgrad_splits(int Cin, int Cout, int ks, long P) {
     int bm = wg_tile(Cout), bn = wg_tile(Cin);
     long tiles = (long)ceil_div(Cout, bm) * ceil_div(Cin, bn) * ks * ks;
-    int s = ceil_div(1024, tiles);                      // ~4 workgroups per CU
+    const int nw = (bm > 64 ? 2 : 1) * (bn > 64 ? 2 : 1);                 // waves per workgroup
+    const long lds = 2L * 32 * (bm + bn) * 4;                             // KP = 32 pixels, double-buffered
+    long per_cu = 160 * 1024 / lds;
+    if (per_cu * nw > 12) per_cu = 12 / nw;
+    if (per_cu < 1) per_cu = 1;
+    long s = 256 * per_cu / tiles;                                        // floor: one round
     long cap = P / 256 > 1 ? P / 256 : 1;               // at least 256 pixels per split
-    if (s > cap) s = (int)cap;
-    if (s > 512) s = 512;
-    return s < 1 ? 1 : s;
+    if (s > cap) s = cap;
+    if (s > 4096) s = 4096;
+    return s < 1 ? 1 : (int)s;
 }
 
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P) {

@@ -89,14 +89,28 @@ __global__ void __launch_bounds__(256) k_stem_wgrad(const float* __restrict__ x,
     for (int i = threadIdx.x; i < CO * NA; i += 256)
         part[(long)blockIdx.x * CO * NA + i] = (sred[0][i] + sred[1][i]) + (sred[2][i] + sred[3][i]);
 }
+// sum over rows of column `col` of part[nb][ncols]; 256 threads, the same association every run
+__device__ __forceinline__ float block_colsum(const float* __restrict__ part, int nb, int ncols, int col) {
+    __shared__ float sred_c[256];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nb; b += 256) s += part[(long)b * ncols + col];
+    sred_c[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sred_c[threadIdx.x] += sred_c[threadIdx.x + w];
+        __syncthreads();
+    }
+    return sred_c[0];
+}
 // partial rows [nb][CO][10] -> dw [CO][taps] (+ db [CO])
 __global__ void k_stem_wgrad_finalize(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nb, int CO,
                                       int taps, int acc) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= CO * 10) return;
-    int c = i / 10, t = i % 10;
-    float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += part[(long)b * CO * 10 + i];
+    // one workgroup per output: 256 threads take the rows round-robin, fixed-order tree through LDS (one thread walking
+    // all rows made this launch, not the streaming kernel in front of it, the longer of the two)
+    const int i = blockIdx.x;
+    const float s = block_colsum(part, nb, CO * 10, i);
+    if (threadIdx.x != 0) return;
+    const int c = i / 10, t = i % 10;
     if (t < taps) dw[c * taps + t] = acc ? dw[c * taps + t] + s : s;
     else if (t == 9 && db) db[c] = acc ? db[c] + s : s;
 }
@@ -120,7 +134,7 @@ int conv_stem_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
     int nb = imin(STEM_WG_BLOCKS, imax(1, (int)(((long)N * H * W + 255) / 256)));
     if (Cout != 16) { vqw_set_error("conv_stem_wgrad: only Cout == 16"); return VQW_ERR_ARG; }
     k_stem_wgrad<16><<<nb, 256, 0, st>>>(in.src0, dy, ws, N, H, W, ks, dil);
-    k_stem_wgrad_finalize<<<ceil_div(Cout * 10, 256), 256, 0, st>>>(ws, dw, dbias, nb, Cout, ks * ks, acc);
+    k_stem_wgrad_finalize<<<Cout * 10, 256, 0, st>>>(ws, dw, dbias, nb, Cout, ks * ks, acc);
     VQW_LAUNCH_CHECK("conv_stem_wgrad");
     return VQW_OK;
 }
@@ -156,13 +170,35 @@ __global__ void __launch_bounds__(256) k_head_wgrad(const float* __restrict__ x,
     float bs = 0.f;
     const long per = (P + gridDim.x - 1) / gridDim.x;
     const long p0 = blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
-    if (tr < rows)
-        for (long p = p0 + tr; p < p1; p += rows) {
+    if (tr < rows) {
+        // four pixel rows per trip: four independent loads in flight per thread (one load per trip left the stream
+        // latency-bound at ~1 TB/s); the partial sums are folded in a fixed order
+        float4 b1, b2, b3;
+        b1.x = b1.y = b1.z = b1.w = b2.x = b2.y = b2.z = b2.w = b3.x = b3.y = b3.z = b3.w = 0.f;
+        float bs1 = 0.f, bs2 = 0.f, bs3 = 0.f;
+        long p = p0 + tr;
+        for (; p + 3L * rows < p1; p += 4L * rows) {
+            const float g0 = dy[p], g1 = dy[p + rows], g2 = dy[p + 2L * rows], g3 = dy[p + 3L * rows];
+            const float4 v0 = ((const float4*)(x + p * Cin))[tc];
+            const float4 v1 = ((const float4*)(x + (p + rows) * Cin))[tc];
+            const float4 v2 = ((const float4*)(x + (p + 2L * rows) * Cin))[tc];
+            const float4 v3 = ((const float4*)(x + (p + 3L * rows) * Cin))[tc];
+            a.x = fmaf(g0, v0.x, a.x); a.y = fmaf(g0, v0.y, a.y); a.z = fmaf(g0, v0.z, a.z); a.w = fmaf(g0, v0.w, a.w);
+            b1.x = fmaf(g1, v1.x, b1.x); b1.y = fmaf(g1, v1.y, b1.y); b1.z = fmaf(g1, v1.z, b1.z); b1.w = fmaf(g1, v1.w, b1.w);
+            b2.x = fmaf(g2, v2.x, b2.x); b2.y = fmaf(g2, v2.y, b2.y); b2.z = fmaf(g2, v2.z, b2.z); b2.w = fmaf(g2, v2.w, b2.w);
+            b3.x = fmaf(g3, v3.x, b3.x); b3.y = fmaf(g3, v3.y, b3.y); b3.z = fmaf(g3, v3.z, b3.z); b3.w = fmaf(g3, v3.w, b3.w);
+            if (tc == 0) { bs += g0; bs1 += g1; bs2 += g2; bs3 += g3; }
+        }
+        for (; p < p1; p += rows) {
             float g = dy[p];
             float4 v = ((const float4*)(x + p * Cin))[tc];
             a.x = fmaf(g, v.x, a.x); a.y = fmaf(g, v.y, a.y); a.z = fmaf(g, v.z, a.z); a.w = fmaf(g, v.w, a.w);
             if (tc == 0) bs += g;
         }
+        a.x = (a.x + b1.x) + (b2.x + b3.x); a.y = (a.y + b1.y) + (b2.y + b3.y);
+        a.z = (a.z + b1.z) + (b2.z + b3.z); a.w = (a.w + b1.w) + (b2.w + b3.w);
+        bs = (bs + bs1) + (bs2 + bs3);
+    }
     sacc[threadIdx.x * 4] = a.x; sacc[threadIdx.x * 4 + 1] = a.y; sacc[threadIdx.x * 4 + 2] = a.z; sacc[threadIdx.x * 4 + 3] = a.w;
     sacc[1024 + threadIdx.x] = bs;
     __syncthreads();
@@ -178,10 +214,9 @@ __global__ void __launch_bounds__(256) k_head_wgrad(const float* __restrict__ x,
     }
 }
 __global__ void k_head_wgrad_finalize(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nb, int Cin, int acc) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > Cin) return;
-    float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += part[(long)b * (Cin + 1) + i];
+    const int i = blockIdx.x;          // one workgroup per output (see k_stem_wgrad_finalize)
+    const float s = block_colsum(part, nb, Cin + 1, i);
+    if (threadIdx.x != 0) return;
     if (i < Cin) dw[i] = acc ? dw[i] + s : s;
     else if (db) db[0] = acc ? db[0] + s : s;
 }
@@ -198,7 +233,7 @@ size_t conv_head_wgrad_ws_floats(int Cin) { return (size_t)HEAD_WG_BLOCKS * (Cin
 int conv_head_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, float* ws, long P, int acc, hipStream_t st) {
     int nb = (int)imin(HEAD_WG_BLOCKS, imax(1, (int)(P / 2048)));
     k_head_wgrad<<<nb, 256, 0, st>>>(in.src0, dy, ws, P, in.C0);
-    k_head_wgrad_finalize<<<1, 512, 0, st>>>(ws, dw, dbias, nb, in.C0, acc);
+    k_head_wgrad_finalize<<<in.C0 + 1, 256, 0, st>>>(ws, dw, dbias, nb, in.C0, acc);
     VQW_LAUNCH_CHECK("conv_head_wgrad");
     return VQW_OK;
 }
