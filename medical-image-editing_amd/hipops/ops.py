@@ -816,14 +816,22 @@ def window_mse_loss(a, b, dataset_window, target_window):
     return _WindowMse.apply(a, b.detach(), *window_map(dataset_window, target_window))
 
 
+_wsum_weights = {}
+
+
 class _WeightedSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *terms):
         dev = terms[0].device
         _dev(*terms)
         terms = [t.reshape(()).contiguous() for t in terms]
-        ptrs = torch.tensor([t.data_ptr() for t in terms], dtype=torch.int64).to(dev, non_blocking=False)
-        w = torch.tensor(list(weights), dtype=torch.float32).to(dev)
+        # pinned staging + asynchronous copies: a blocking copy of pageable memory synchronises the stream, i.e. the host
+        # would wait here for the whole forward pass and only then start to enqueue the backward pass
+        ptrs = torch.tensor([t.data_ptr() for t in terms], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+        key = (tuple(weights), dev)
+        w = _wsum_weights.get(key)
+        if w is None:
+            w = _wsum_weights[key] = torch.tensor(list(weights), dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
         out = torch.empty((), dtype=torch.float32, device=dev)
         _lib.check(_L().vqw_weighted_sum(_p(ptrs), _p(w), len(terms), _p(out), _st()), "vqw_weighted_sum")
         ctx.weights = list(weights)
