@@ -103,13 +103,34 @@ def reset_pending(params):
             p._vqw_pending = 0
 
 
-def wgrad_stream(device):
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+# Weight gradients alternate between WGRAD_LANES side streams (a parameter keeps its lane: the second view accumulates
+# into the first view's result).  One layer's slab reduction (a short, latency-bound launch that depends on the layer's
+# wgrad kernel) then overlaps the next layer's wgrad kernel; on a single stream those gaps were exposed, most of all
+# in the last tenth of the step when only weight gradients are left to run.  With gradient-ready listeners (data
+# parallel: buckets are flattened on the stream that announces their last gradient) everything stays on lane 0.
+WGRAD_LANES = max(1, int(os.environ.get("VQW_WGRAD_LANES", "2")))
+_lane_counter = 0
+
+
+def wgrad_stream(device, lane=0):
+    dev = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = (dev, lane)
     st = _side_streams.get(key)
     if st is None:
-        st = torch.cuda.Stream(device=key)
+        st = torch.cuda.Stream(device=dev)
         _side_streams[key] = st
     return st
+
+
+def _wgrad_lane(param):
+    global _lane_counter
+    if WGRAD_LANES == 1 or grad_ready_listeners:
+        return 0
+    lane = param.__dict__.get("_vqw_lane")
+    if lane is None:
+        lane = param.__dict__["_vqw_lane"] = _lane_counter % WGRAD_LANES
+        _lane_counter += 1
+    return lane
 
 
 def _join_side_stream():
@@ -229,7 +250,7 @@ def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, 
     global _join_queued
     L = _L()
     main = torch.cuda.current_stream()
-    side = wgrad_stream(gy.device)
+    side = wgrad_stream(gy.device, _wgrad_lane(weight))
     ev = main.record_event()
     C0 = x0.shape[1]
     C1 = 0 if x1 is None else x1.shape[1]
@@ -398,7 +419,7 @@ def _deferred_wgrad_cat(wa, ba, wb, bb, x0, gy, ks, N, H, W):
     global _join_queued
     L = _L()
     main = torch.cuda.current_stream()
-    side = wgrad_stream(gy.device)
+    side = wgrad_stream(gy.device, _wgrad_lane(wa))
     ev = main.record_event()
     Ca, Cin = wa.shape[0], wa.shape[1]
     Ct = Ca + wb.shape[0]

@@ -118,17 +118,20 @@ class FirstStepTrainer:
             feat_2 = self.encoder.feature_extraction(noised_2)
         embed_1, l_commit_1, ids_1 = self.encoder(noised_1)
         r_ids_1 = self.views.cross_ids(ids_1, 1)
+        ev1 = s1.record_event()
         with torch.cuda.stream(s2):
             embed_2, l_commit_2, ids_2 = self.encoder.vq(feat_2, id_base=1)       # ordered after view 1's update
             ids_2 = torch.transpose(ids_2, 1, 2)
             r_ids_2 = self.views.cross_ids(ids_2, 2)
-            ev2 = s2.record_event()
-        s1.wait_event(ev2)
-        for t in (embed_2, r_ids_2, ids_2):
-            t.record_stream(s1)
-        s2.wait_event(s1.record_event())          # r_ids_1 / embed_1 are read on s2 only through autograd; keep order simple
-        codebook = self.encoder.vq.get_codebook()
-        l_cross, l_dist, l_reg = self.embed_loss.forward_labels(embed_1, r_ids_1, embed_2, r_ids_2, codebook)
+            # The embedding loss runs on view 2's stream.  Autograd replays a node on the stream of its forward and in
+            # reverse creation order: on stream 1 the loss's (tiny) backward would queue behind ALL of view 1's decoder
+            # backward, and view 2's encoder backward, which needs its gradient, would start only then (stream 2 idle
+            # for the last fifth of the step).  On stream 2 it follows view 2's decoder backward directly.
+            s2.wait_event(ev1)
+            for t in (embed_1, r_ids_1):
+                t.record_stream(s2)
+            codebook = self.encoder.vq.get_codebook()
+            l_cross, l_dist, l_reg = self.embed_loss.forward_labels(embed_1, r_ids_1, embed_2, r_ids_2, codebook)
         recon_1 = self.decoder(embed_1)
         rec_1 = self._recon_terms(recon_1, clear_1)
         with torch.cuda.stream(s2):
@@ -136,7 +139,8 @@ class FirstStepTrainer:
             rec_2 = self._recon_terms(recon_2, clear_2)
             ev2 = s2.record_event()
         s1.wait_event(ev2)
-        for t in [l_commit_2, recon_2] + [t for t, _ in rec_2]:
+        for t in [l_commit_2, recon_2, l_cross, embed_2, r_ids_2, ids_2] + [t for t, _ in rec_2] + \
+                [t for t in (l_dist, l_reg) if torch.is_tensor(t)]:
             t.record_stream(s1)
         l_rec_1, l_rec_2 = rec_1[0][0], rec_2[0][0]
         l_total = ops.weighted_sum(
