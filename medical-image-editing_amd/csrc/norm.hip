@@ -185,17 +185,24 @@ struct FStats {
     __device__ void operator()(long i, int, int, float& a, float& b) const { float v = x[i]; a = v; b = v * v; }
 };
 
-__global__ void k_inorm_finalize(const double* __restrict__ part, float* __restrict__ mr, int NC, int C, int splits,
-                                 double inv_hw, float eps) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NC) return;
+// One WAVE per (n, c): lane s holds the partial of split s (splits <= 64), summed by the fixed butterfly.  A thread per
+// plane walking its splits one dependent load after the other made these launches ~13 us each; they sit on the
+// dependency chain between the reduction and the apply pass of every normalisation.
+static_assert(PLANE_MAX_SPLITS <= 64, "one lane per split");
+__global__ void __launch_bounds__(256) k_inorm_finalize(const double* __restrict__ part, float* __restrict__ mr, int NC, int C,
+                                                        int splits, double inv_hw, float eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;
+    if (i >= NC) return;              // wave-uniform
     int n = i / C, c = i % C;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < splits; ++s) {
+    if (s < splits) {
         const double* o = part + (((long)n * splits + s) * C + c) * 2;
-        a += o[0];
-        b += o[1];
+        a = o[0];
+        b = o[1];
     }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (s != 0) return;
     double mean = a * inv_hw;
     double var = b * inv_hw - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -271,7 +278,7 @@ extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff
         FStats f{x};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     }
-    k_inorm_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>((const double*)ws, mean_rstd, N * C, C, splits,
+    k_inorm_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>((const double*)ws, mean_rstd, N * C, C, splits,
                                                                  1.0 / (double)HW, eps);
     long total = (long)N * HW * C;
     if ((C & 3) == 0 && (y_cstride & 3) == 0 && (y_coff & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
@@ -301,17 +308,20 @@ struct FInBwd {
     }
 };
 
-__global__ void k_plane_sum_finalize(const double* __restrict__ part, float* __restrict__ out, int NC, int C, int splits,
-                                     double scale) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) k_plane_sum_finalize(const double* __restrict__ part, float* __restrict__ out, int NC, int C,
+                                                            int splits, double scale) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;       // one wave per (n, c), see k_inorm_finalize
     if (i >= NC) return;
     int n = i / C, c = i % C;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < splits; ++s) {
+    if (s < splits) {
         const double* o = part + (((long)n * splits + s) * C + c) * 2;
-        a += o[0];
-        b += o[1];
+        a = o[0];
+        b = o[1];
     }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (s != 0) return;
     out[2 * i] = (float)(a * scale);
     out[2 * i + 1] = (float)(b * scale);
 }
@@ -359,7 +369,7 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
         FInBwd<0> f{x, mean_rstd, gy, C, gy_cstride, gy_coff};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
     }
-    k_plane_sum_finalize<<<ceil_div((long)N * C, 256), 256, 0, st>>>(part, means, N * C, C, splits, 1.0 / (double)HW);
+    k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, means, N * C, C, splits, 1.0 / (double)HW);
     if ((C & 3) == 0 && (gy_cstride & 3) == 0 && (gy_coff & 3) == 0 &&
         ((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)mean_rstd | (uintptr_t)means) & 15) == 0)) {
         long t4 = total / 4;
@@ -373,27 +383,27 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm statistics (per channel over N*H*W) -> double sums[C][2] so ranks can be summed (SyncBN).
-// sums[c] = sum over `rows` partial rows; workgroup = 16 channels x 16 row groups, fixed-order tree -> deterministic
+// sums[c] = sum over `rows` partial rows; one workgroup per channel: 256 threads take the rows round-robin, then a
+// fixed-order tree through LDS -> deterministic (16 row groups per channel walked 128 rows each one load after the other)
 __global__ void __launch_bounds__(256) k_channel_sum_finalize(const double* __restrict__ part, double* __restrict__ sums, int C, int rows) {
-    __shared__ double sa[16][17], sb[16][17];
-    const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cx;
+    __shared__ double sa[256], sb[256];
+    const int c = blockIdx.x, t = threadIdx.x;
     double a = 0.0, b = 0.0;
-    if (c < C) {
-        for (int r = g; r < rows; r += 16) {
-            const double* o = part + ((long)r * C + c) * 2;
-            a += o[0];
-            b += o[1];
-        }
+    for (int r = t; r < rows; r += 256) {
+        const double* o = part + ((long)r * C + c) * 2;
+        a += o[0];
+        b += o[1];
     }
-    sa[g][cx] = a;
-    sb[g][cx] = b;
+    sa[t] = a;
+    sb[t] = b;
     __syncthreads();
-    if (g == 0 && c < C) {
-        double ta = 0.0, tb = 0.0;
-        for (int k = 0; k < 16; ++k) { ta += sa[k][cx]; tb += sb[k][cx]; }
-        sums[2 * c] = ta;
-        sums[2 * c + 1] = tb;
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { sa[t] += sa[t + w]; sb[t] += sb[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        sums[2 * c] = sa[0];
+        sums[2 * c + 1] = sb[0];
     }
 }
 
@@ -410,7 +420,7 @@ extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size
         FStats f{x};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     }
-    k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    k_channel_sum_finalize<<<C, 256, 0, st>>>((const double*)ws, sums, C, N * splits);
     VQW_LAUNCH_CHECK("vqw_bn_partial_stats");
     return VQW_OK;
 }
@@ -548,7 +558,7 @@ extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, cons
         FSpadeBwd<0> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta, C, gb_stride};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
     }
-    k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    k_channel_sum_finalize<<<C, 256, 0, st>>>((const double*)ws, sums, C, N * splits);
     VQW_LAUNCH_CHECK("vqw_spade_bwd_reduce");
     return VQW_OK;
 }
@@ -691,7 +701,7 @@ extern "C" int vqw_bn_affine_bwd_reduce(const float* x, const float* mean_rstd, 
     int splits = plane_splits(N, HW);
     FBnAffineBwd f{x, mean_rstd, gamma, beta, gy, slope};
     k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
-    k_channel_sum_finalize<<<ceil_div(C, 16), 256, 0, st>>>((const double*)ws, sums, C, N * splits);
+    k_channel_sum_finalize<<<C, 256, 0, st>>>((const double*)ws, sums, C, N * splits);
     VQW_LAUNCH_CHECK("vqw_bn_affine_bwd_reduce");
     return VQW_OK;
 }

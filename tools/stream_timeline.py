@@ -4,7 +4,10 @@
 then the longest intervals in which no MFMA kernel runs, with what runs instead.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing
-    python tools/stream_timeline.py DIR/t_kernel_trace.csv
+    python tools/stream_timeline.py DIR/t_kernel_trace.csv [bin_ms] [steps_back]
+
+steps_back: which step to look at, counted from the end (1 = last).  A default `bench.py` run ends with three serialised
+steps (the roofline pass), so its last concurrent step is steps_back = 4.
 """
 import collections
 import csv
@@ -39,7 +42,7 @@ def cover(L, a, b):
     return tot
 
 
-def main(path, binms=5.0):
+def main(path, binms=5.0, back=1):
     rows = list(csv.DictReader(open(path)))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"]) for r in rows)
     adam = [i for i, e in enumerate(ev) if "adam" in e[2].lower()]
@@ -49,7 +52,7 @@ def main(path, binms=5.0):
             groups[-1].append(i)
         else:
             groups.append([i])
-    t0, t1 = ev[groups[-2][-1]][1], ev[groups[-1][-1]][1]
+    t0, t1 = ev[groups[-back - 1][-1]][1], ev[groups[-back][-1]][1]
     win = [e for e in ev if e[0] >= t0 and e[1] <= t1]
     print("step %.1f ms, %d kernels" % ((t1 - t0) / 1e6, len(win)))
     streams = collections.defaultdict(list)
@@ -91,4 +94,4 @@ def main(path, binms=5.0):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 5.0)
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 5.0, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
