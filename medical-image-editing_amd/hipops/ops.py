@@ -106,8 +106,9 @@ def reset_pending(params):
 # Weight gradients alternate between WGRAD_LANES side streams (a parameter keeps its lane: the second view accumulates
 # into the first view's result).  One layer's slab reduction (a short, latency-bound launch that depends on the layer's
 # wgrad kernel) then overlaps the next layer's wgrad kernel; on a single stream those gaps were exposed, most of all
-# in the last tenth of the step when only weight gradients are left to run.  With gradient-ready listeners (data
-# parallel: buckets are flattened on the stream that announces their last gradient) everything stays on lane 0.
+# in the last tenth of the step when only weight gradients are left to run.  A gradient-ready listener that reads
+# gradients of several parameters (data parallel: a bucket is flattened on the lane that announces its last gradient)
+# orders its lane after the others first: sync_wgrad_lanes().
 WGRAD_LANES = max(1, int(os.environ.get("VQW_WGRAD_LANES", "2")))
 _lane_counter = 0
 
@@ -122,9 +123,19 @@ def wgrad_stream(device, lane=0):
     return st
 
 
+def sync_wgrad_lanes():
+    """Order the current stream after everything enqueued so far on the weight-gradient lanes."""
+    if not _side_streams:
+        return
+    cur = torch.cuda.current_stream()
+    for st in _side_streams.values():
+        if st.device == cur.device and st != cur:
+            cur.wait_stream(st)
+
+
 def _wgrad_lane(param):
     global _lane_counter
-    if WGRAD_LANES == 1 or grad_ready_listeners:
+    if WGRAD_LANES == 1:
         return 0
     lane = param.__dict__.get("_vqw_lane")
     if lane is None:

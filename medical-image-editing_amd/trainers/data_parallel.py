@@ -40,9 +40,11 @@ class GradientAllReducer:
         # out-of-band on the side stream announce themselves via hipops.ops.grad_ready_listeners (when importable)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self._armed = False
+        self._sync_lanes = None
         try:
             from hipops import ops as _ops
             _ops.grad_ready_listeners.append(self._on_grad_listener)
+            self._sync_lanes = _ops.sync_wgrad_lanes
         except Exception:       # plain torch modules (CPU tests)
             pass
 
@@ -70,6 +72,8 @@ class GradientAllReducer:
 
     def _launch(self, bi):
         grads = [p.grad for p in self.buckets[bi]]
+        if self._sync_lanes is not None:
+            self._sync_lanes()      # the bucket's gradients were written on several weight-gradient lanes
         # flatten in MEMORY order (grads may be channels_last): view each as its dense storage
         views = [_dense_1d(g) for g in grads]
         flat = torch.cat(views)
