@@ -126,6 +126,11 @@ int vqw_relu_bwd(const float* y, const float* gy, float* gx, long n, void* strea
 int vqw_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int vqw_maxpool2_bwd(const float* x, const float* gy, const float* g_skip /*nullable*/, float* gx,
                      int N, int H, int W, int C, void* stream);
+/* ResBlock tail backward in one pass (blocks.py:29-36: out = ReLU(a + b); pooled = MaxPool2d(2)(out)):
+ * gx = [out > 0] * (g_out + g_pooled routed to each 2x2 window's arg-max) = d/da = d/db.  Either gradient may be
+ * NULL (that output unused).  H, W even, C % 4 == 0, 16-byte aligned tensors.                                  */
+int vqw_res_tail_bwd(const float* out, const float* g_pooled /*nullable*/, const float* g_out /*nullable*/, float* gx,
+                     int N, int H, int W, int C, void* stream);
 int vqw_tanh_fwd(const float* x, float* y, long n, void* stream);
 int vqw_tanh_bwd(const float* y, const float* gy, float* gx, long n, void* stream);
 int vqw_affine(const float* x, float* y, float scale, float shift, long n, void* stream); /* utils norm/denorm */

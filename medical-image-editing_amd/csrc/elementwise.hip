@@ -124,6 +124,64 @@ extern "C" int vqw_maxpool2_bwd(const float* x, const float* gy, const float* g_
     return VQW_OK;
 }
 
+// Backward of the ResBlock tail  out = ReLU(a + b); pooled = MaxPool2d(2)(out)  (blocks.py:29-36) in one pass:
+//   g = [out > 0] * (g_out + g_pooled routed to the arg-max of its 2x2 window),  da = db = g.
+// Replaces max-pool backward + autograd's add of the two gradients of `out` + ReLU backward (three kernels, eight
+// full-resolution tensor passes) by one kernel with three and a quarter.  Thread = one 2x2 window x 4 channels.
+// Ties go to the first maximum in row-major window order like ATen (and k_maxpool2_bwd).  H, W even, C % 4 == 0.
+__global__ void __launch_bounds__(256) k_res_tail_bwd4(const float4* __restrict__ out, const float4* __restrict__ gp,
+                                                       const float4* __restrict__ go, float4* __restrict__ gx, int N, int H,
+                                                       int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const long b = (((long)n * H + 2 * ho) * W + 2 * wo) * C4 + c;
+        const long idx[4] = {b, b + C4, b + (long)W * C4, b + (long)W * C4 + C4};
+        float4 v[4], g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = out[idx[k]];
+        const float4 gy = gp ? gp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = go ? go[idx[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* vf = (const float*)v;
+        float* gf = (float*)g;
+        const float gyf[4] = {gy.x, gy.y, gy.z, gy.w};
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float m = vf[ch];
+            int am = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (vf[4 * k + ch] > m) { m = vf[4 * k + ch]; am = k; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = gf[4 * k + ch] + (k == am ? gyf[ch] : 0.f);
+                gf[4 * k + ch] = vf[4 * k + ch] > 0.f ? t : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gx[idx[k]] = g[k];
+    }
+}
+extern "C" int vqw_res_tail_bwd(const float* out, const float* g_pooled, const float* g_out, float* gx, int N, int H, int W,
+                                int C, void* stream) {
+    VQW_CHECK(out && gx && (g_pooled || g_out) && N > 0 && C > 0, "vqw_res_tail_bwd: bad arguments");
+    VQW_CHECK((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0 && H >= 2 && W >= 2, "vqw_res_tail_bwd: needs even H, W and C %% 4 == 0");
+    VQW_CHECK(((((uintptr_t)out | (uintptr_t)g_pooled | (uintptr_t)g_out | (uintptr_t)gx) & 15) == 0), "vqw_res_tail_bwd: 16-byte alignment");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    k_res_tail_bwd4<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)out, (const float4*)g_pooled,
+                                                                               (const float4*)g_out, (float4*)gx, N, H, W, C / 4);
+    VQW_LAUNCH_CHECK("vqw_res_tail_bwd");
+    return VQW_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ void k_tanh_fwd(const float* __restrict__ x, float* __restrict__ y, long n) {
     long stride = (long)gridDim.x * blockDim.x;

@@ -51,6 +51,7 @@ SIGNATURES = {
     "vqw_relu_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "vqw_maxpool2_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_maxpool2_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_res_tail_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_tanh_fwd": (c_i, [c_p, c_p, c_l, c_p]),
     "vqw_tanh_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "vqw_affine": (c_i, [c_p, c_p, c_f, c_f, c_l, c_p]),

@@ -745,6 +745,46 @@ def maxpool2(x):
     return _MaxPool2.apply(x)
 
 
+class _ResTail(torch.autograd.Function):
+    """out = ReLU(a + b); pooled = MaxPool2d(2)(out) as ONE autograd node (blocks.py:29-36).  `out` has two consumers (the
+    pooling and the skip connection): as separate nodes their gradients meet in autograd's add, then pass the ReLU mask —
+    three kernels over full-resolution tensors; here one (vqw_res_tail_bwd)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _dev(a, b)
+        a, b = nhwc(a), nhwc(b)
+        if a.shape != b.shape:
+            raise RuntimeError("res_tail: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        N, C, H, W = a.shape
+        L = _L()
+        out = torch.empty_like(a, memory_format=CL)
+        _lib.check(L.vqw_add(_p(a), _p(b), _p(out), a.numel(), 1, _st()), "vqw_add")
+        pooled = empty_nhwc(N, C, H // 2, W // 2, a)
+        _lib.check(L.vqw_maxpool2_fwd(_p(out), _p(pooled), N, H, W, C, _st()), "vqw_maxpool2_fwd")
+        ctx.save_for_backward(out)
+        return pooled, out
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_out):
+        (out,) = ctx.saved_tensors
+        N, C, H, W = out.shape
+        gp = nhwc(g_pooled) if g_pooled is not None else None
+        go = nhwc(g_out) if g_out is not None else None
+        gx = torch.empty_like(out, memory_format=CL)
+        _lib.check(_L().vqw_res_tail_bwd(_p(out), _p(gp), _p(go), _p(gx), N, H, W, C, _st()), "vqw_res_tail_bwd")
+        return gx, gx
+
+
+def res_tail(a, b):
+    """(MaxPool2d(2)(ReLU(a + b)), ReLU(a + b)); falls back to the separate operators for odd sizes / channel counts."""
+    N, C, H, W = a.shape
+    if (H | W) & 1 or C & 3:
+        out = add(a, b, relu=True)
+        return maxpool2(out), out
+    return _ResTail.apply(a, b)
+
+
 class _Tanh(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

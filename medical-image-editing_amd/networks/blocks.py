@@ -76,8 +76,7 @@ class ResBlock(nn.Module):
 
     def forward(self, x):
         identity = self.downsample(x)
-        out = ops.add(self.double_conv(x), identity, relu=True)
-        return ops.maxpool2(out), out
+        return ops.res_tail(self.double_conv(x), identity)      # (pooled, out) with a single backward kernel
 
 
 class DoubleConv(nn.Module):

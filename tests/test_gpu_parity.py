@@ -189,6 +189,42 @@ def test_maxpool_ties_route_to_first():
     assert torch.equal(dx.grad.cpu(), xr.grad)
 
 
+def test_res_tail_matches_separate_ops_and_aten():
+    """ResBlock tail as one autograd node (out = ReLU(a + b); pooled = MaxPool2d(2)(out)): values and both input
+    gradients are bit-identical to the separate add / max-pool operators and to ATen on CPU, with exact ties (a
+    piecewise-constant map), negative pre-activations and either output unused."""
+    ops = _ops()
+    torch.manual_seed(7)
+    a = torch.randn(2, 8, 12, 16)
+    b = torch.randn(2, 8, 12, 16)
+    a[0, :, :6] = torch.round(a[0, :, :6])          # ties inside 2x2 windows
+    b[0, :, :6] = torch.round(b[0, :, :6])
+    rp, ro = torch.randn(2, 8, 6, 8), torch.randn(2, 8, 12, 16)
+    for use_p, use_o in ((True, True), (True, False), (False, True)):
+        ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        out = F.relu(ar + br)
+        pooled = F.max_pool2d(out, 2)
+        ((pooled * rp).sum() * use_p + (out * ro).sum() * use_o).backward()
+        grads = []
+        for fused in (True, False):
+            ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+            if fused:
+                pd, od = ops.res_tail(ad, bd)
+            else:
+                od = ops.add(ad, bd, relu=True)
+                pd = ops.maxpool2(od)
+            assert torch.equal(pd.cpu(), pooled.detach()) and torch.equal(od.cpu(), out.detach())
+            loss = 0
+            if use_p:
+                loss = loss + (pd * rp.to(DEV)).sum()
+            if use_o:
+                loss = loss + (od * ro.to(DEV)).sum()
+            loss.backward()
+            grads.append((ad.grad.cpu(), bd.grad.cpu()))
+        assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+        assert torch.equal(grads[0][0], ar.grad) and torch.equal(grads[0][1], br.grad)
+
+
 # --------------------------------------------------------------------------------------------------
 # blocks against the reference's golden vectors
 # --------------------------------------------------------------------------------------------------
