@@ -110,6 +110,9 @@ int vqw_bn_eval_stats(const float* running_mean, const float* running_var, float
  * (gamma = gb, beta = gb + C). */
 int vqw_spade_fwd(const float* x, const float* mean_rstd /*[C][2]*/, const float* gamma,
                   const float* beta, int gb_stride, float* y, long P, int C, int relu, void* stream);
+/* the same with the block's residual added after the activation: y = act(...) + res (blocks.py:134, `shortcut + main`) */
+int vqw_spade_fwd_res(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
+                      const float* res, float* y, long P, int C, int relu, void* stream);
 /* backward, phase 1: dgamma, dbeta and per-channel sums [sum dxhat, sum dxhat*xhat] */
 int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                          const float* gy, float* dgamma, float* dbeta, int gb_stride,
@@ -126,9 +129,10 @@ int vqw_relu_bwd(const float* y, const float* gy, float* gx, long n, void* strea
 int vqw_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int vqw_maxpool2_bwd(const float* x, const float* gy, const float* g_skip /*nullable*/, float* gx,
                      int N, int H, int W, int C, void* stream);
-/* ResBlock tail backward in one pass (blocks.py:29-36: out = ReLU(a + b); pooled = MaxPool2d(2)(out)):
+/* ResBlock tail (blocks.py:29-36: out = ReLU(a + b); pooled = MaxPool2d(2)(out)), forward and backward in one pass each:
  * gx = [out > 0] * (g_out + g_pooled routed to each 2x2 window's arg-max) = d/da = d/db.  Either gradient may be
  * NULL (that output unused).  H, W even, C % 4 == 0, 16-byte aligned tensors.                                  */
+int vqw_res_tail_fwd(const float* a, const float* b, float* out, float* pooled, int N, int H, int W, int C, void* stream);
 int vqw_res_tail_bwd(const float* out, const float* g_pooled /*nullable*/, const float* g_out /*nullable*/, float* gx,
                      int N, int H, int W, int C, void* stream);
 int vqw_tanh_fwd(const float* x, float* y, long n, void* stream);

@@ -170,6 +170,47 @@ __global__ void __launch_bounds__(256) k_res_tail_bwd4(const float4* __restrict_
         for (int k = 0; k < 4; ++k) gx[idx[k]] = g[k];
     }
 }
+// forward of the same tail: out = ReLU(a + b) and pooled = max over each 2x2 window, one pass (the separate operators
+// read `out` back for the pooling)
+__global__ void __launch_bounds__(256) k_res_tail_fwd4(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                       float4* __restrict__ out, float4* __restrict__ pooled, int N, int H, int W,
+                                                       int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const long base = (((long)n * H + 2 * ho) * W + 2 * wo) * C4 + c;
+        const long idx[4] = {base, base + C4, base + (long)W * C4, base + (long)W * C4 + C4};
+        float4 m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 x = a[idx[k]], y = b[idx[k]];
+            float4 o;
+            o.x = fmaxf(x.x + y.x, 0.f); o.y = fmaxf(x.y + y.y, 0.f); o.z = fmaxf(x.z + y.z, 0.f); o.w = fmaxf(x.w + y.w, 0.f);
+            out[idx[k]] = o;
+            if (k == 0) m = o;
+            else { m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w); }
+        }
+        pooled[i] = m;
+    }
+}
+extern "C" int vqw_res_tail_fwd(const float* a, const float* b, float* out, float* pooled, int N, int H, int W, int C,
+                                void* stream) {
+    VQW_CHECK(a && b && out && pooled && N > 0 && C > 0, "vqw_res_tail_fwd: bad arguments");
+    VQW_CHECK((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0 && H >= 2 && W >= 2, "vqw_res_tail_fwd: needs even H, W and C %% 4 == 0");
+    VQW_CHECK(((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)pooled) & 15) == 0), "vqw_res_tail_fwd: 16-byte alignment");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    k_res_tail_fwd4<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)a, (const float4*)b, (float4*)out,
+                                                                               (float4*)pooled, N, H, W, C / 4);
+    VQW_LAUNCH_CHECK("vqw_res_tail_fwd");
+    return VQW_OK;
+}
 extern "C" int vqw_res_tail_bwd(const float* out, const float* g_pooled, const float* g_out, float* gx, int N, int H, int W,
                                 int C, void* stream) {
     VQW_CHECK(out && gx && (g_pooled || g_out) && N > 0 && C > 0, "vqw_res_tail_bwd: bad arguments");

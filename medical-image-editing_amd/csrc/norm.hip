@@ -478,7 +478,8 @@ __global__ void k_spade_fwd(const float* __restrict__ x, const float* __restrict
 template <int RELU>
 __global__ void __launch_bounds__(256) k_spade_fwd4(const float4* __restrict__ x, const float* __restrict__ mr,
                                                     const float4* __restrict__ gamma, const float4* __restrict__ beta,
-                                                    float4* __restrict__ y, long total4, int C4, int gbs4) {
+                                                    float4* __restrict__ y, long total4, int C4, int gbs4,
+                                                    const float4* __restrict__ res = nullptr) {
     long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
         int c4 = (int)(i % C4);
@@ -490,8 +491,25 @@ __global__ void __launch_bounds__(256) k_spade_fwd4(const float4* __restrict__ x
         o.z = (v.z - m1.x) * m1.y * (1.f + ga.z) + be.z;
         o.w = (v.w - m1.z) * m1.w * (1.f + ga.w) + be.w;
         if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (res) {      // residual added AFTER the activation (StyledResUpBlock: shortcut + main path, blocks.py:134)
+            const float4 r = res[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
         y[i] = o;
     }
+}
+// y = act(spade(x)) + res: the block's final `shortcut + main` (blocks.py:134) inside the last modulation kernel
+extern "C" int vqw_spade_fwd_res(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
+                                 const float* res, float* y, long P, int C, int relu, void* stream) {
+    VQW_CHECK(x && mean_rstd && gamma && beta && res && y && P > 0 && C > 0 && gb_stride >= C, "vqw_spade_fwd_res: bad arguments");
+    VQW_CHECK((C & 3) == 0 && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(y) && al16(mean_rstd) && al16(res),
+              "vqw_spade_fwd_res: needs C %% 4 == 0 and 16-byte aligned tensors");
+    const long t4 = P * C / 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) k_spade_fwd4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4, (const float4*)res);
+    else k_spade_fwd4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4, (const float4*)res);
+    VQW_LAUNCH_CHECK("vqw_spade_fwd_res");
+    return VQW_OK;
 }
 extern "C" int vqw_spade_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
                              float* y, long P, int C, int relu, void* stream) {

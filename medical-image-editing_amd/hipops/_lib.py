@@ -45,12 +45,14 @@ SIGNATURES = {
     "vqw_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_f, c_f, c_i, c_p]),
     "vqw_bn_eval_stats": (c_i, [c_p, c_p, c_p, c_f, c_i, c_p]),
     "vqw_spade_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_p]),
+    "vqw_spade_fwd_res": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_i, c_p]),
     "vqw_spade_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_spade_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_d, c_p, c_l, c_i, c_i, c_i, c_p]),
     "vqw_add": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),
     "vqw_relu_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),
     "vqw_maxpool2_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_maxpool2_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_res_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_res_tail_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_tanh_fwd": (c_i, [c_p, c_p, c_l, c_p]),
     "vqw_tanh_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),

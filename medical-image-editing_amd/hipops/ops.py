@@ -615,8 +615,8 @@ def _dist_on():
 
 class _Spade(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt):
-        _dev(x, gamma, beta)
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt, res=None):
+        _dev(x, gamma, beta, res)
         x, gamma = nhwc(x), nhwc(gamma)
         N, C, H, W = x.shape
         # beta=None: `gamma` holds [gamma | beta] as 2C channels (conv2d_cat)
@@ -650,9 +650,17 @@ class _Spade(torch.autograd.Function):
         else:
             _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
         y = torch.empty_like(x, memory_format=CL)
-        _lib.check(L.vqw_spade_fwd(_p(x), _p(mr), gptr, bptr, gbs, _p(y), N * H * W, C, int(relu), _st()), "vqw_spade_fwd")
+        if res is not None:         # y = act(...) + res: the block's `shortcut + main` inside this kernel
+            res = nhwc(res)
+            if res.shape != x.shape:
+                raise RuntimeError("spade_norm: residual shape %s does not match %s" % (tuple(res.shape), tuple(x.shape)))
+            _lib.check(L.vqw_spade_fwd_res(_p(x), _p(mr), gptr, bptr, gbs, _p(res), _p(y), N * H * W, C, int(relu), _st()),
+                       "vqw_spade_fwd_res")
+        else:
+            _lib.check(L.vqw_spade_fwd(_p(x), _p(mr), gptr, bptr, gbs, _p(y), N * H * W, C, int(relu), _st()), "vqw_spade_fwd")
         ctx.save_for_backward(x, gamma, beta, mr)
         ctx.cfg = (training, relu, count, sync, fused)
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -679,13 +687,17 @@ class _Spade(torch.autograd.Function):
             dist.all_reduce(sums)
         _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), gptr, bptr, gbs, _p(gy), _p(sums), count, _p(gx), N * H * W, C,
                                          int(relu), int(training), _st()), "vqw_spade_bwd_apply")
-        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None, (gy if ctx.has_res else None)
 
 
 def spade_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, sync=True,
-               num_batches_tracked=None):
+               num_batches_tracked=None, residual=None):
+    """residual: added AFTER the activation (y = act(spade(x)) + residual); needs C % 4 == 0."""
+    if residual is not None and (x.shape[1] & 3 or gamma.shape[1] & 3):
+        return add(spade_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync,
+                              num_batches_tracked), residual)
     return _Spade.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu),
-                        bool(sync), num_batches_tracked)
+                        bool(sync), num_batches_tracked, residual)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -759,9 +771,8 @@ class _ResTail(torch.autograd.Function):
         N, C, H, W = a.shape
         L = _L()
         out = torch.empty_like(a, memory_format=CL)
-        _lib.check(L.vqw_add(_p(a), _p(b), _p(out), a.numel(), 1, _st()), "vqw_add")
         pooled = empty_nhwc(N, C, H // 2, W // 2, a)
-        _lib.check(L.vqw_maxpool2_fwd(_p(out), _p(pooled), N, H, W, C, _st()), "vqw_maxpool2_fwd")
+        _lib.check(L.vqw_res_tail_fwd(_p(a), _p(b), _p(out), _p(pooled), N, H, W, C, _st()), "vqw_res_tail_fwd")
         ctx.save_for_backward(out)
         return pooled, out
 

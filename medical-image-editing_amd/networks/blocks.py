@@ -124,12 +124,12 @@ class StyledDenorm(nn.Module):
             return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias), None
         return self.mlp_gamma(actv), self.mlp_beta(actv)
 
-    def forward(self, x, style, relu=False, maps=None):
+    def forward(self, x, style, relu=False, maps=None, residual=None):
         bn = self.param_free_norm
         gamma, beta = maps if maps is not None else self.style_maps(style)
         return ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
                               momentum=bn.momentum, eps=bn.eps, relu=relu,
-                              num_batches_tracked=bn.num_batches_tracked if self.training else None)
+                              num_batches_tracked=bn.num_batches_tracked if self.training else None, residual=residual)
 
 
 class PixelShuffle(nn.Module):
@@ -190,5 +190,4 @@ class StyledResUpBlock(nn.Module):
         br.join(*m1, *m2)
         h = self.norm1(h, skip_input, relu=True, maps=m1)
         h = self.conv2(h)
-        h = self.norm2(h, skip_input, relu=self.use_output_act, maps=m2)
-        return ops.add(s, h)
+        return self.norm2(h, skip_input, relu=self.use_output_act, maps=m2, residual=s)      # shortcut + main, in the kernel
