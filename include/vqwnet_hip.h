@@ -57,6 +57,14 @@ int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* src1, int C1
  * dX = vqw_conv2d_fwd(dY, Cout, 0, NULL, 0, wt, NULL, dX, N,H,W, Cin, ksize, dil, 0).
  * relu=1 fuses nn.ReLU into the epilogue (blocks.py:75-77 mlp_shared).             */
 int vqw_pack_dgrad_weights(const float* w_ohwi, float* wt, int Cout, int Cin, int ksize, void* stream);
+/* conv -> InstanceNorm (blocks.py:45-49): the convolution's epilogue also leaves the norm's statistics as per-tile
+ * partial sums part[N][parts][Cout][2] (sum, sum of squares; fp32 over one tile, the norm sums tiles in double), so
+ * the norm skips its reduction pass (vqw_inorm_fwd_parts).  ..._stats_parts() returns `parts` for a shape, 0 when
+ * the shape is not served by the halo-tile kernel (then use vqw_conv2d_fwd + vqw_inorm_fwd).  No ReLU epilogue.   */
+int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H, int W, int Cout, int ksize, int dil);
+int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const float* src1, int C1,
+                         const float* w_ohwi, const float* bias, float* y, float* part,
+                         int N, int H, int W, int Cout, int ksize, int dil, void* stream);
 size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, int ksize);
 /* dW[co][ky][kx][ci] (OHWI) and, if dbias != NULL, dbias[co] = sum_p dY.
  * accumulate=1 adds into dw / dbias (a layer used by both views of a step: one gradient buffer, no extra pass). */
@@ -91,6 +99,9 @@ size_t vqw_plane_ws_bytes(int N, int C, int HW);
  * (cstride == C, c_off == 0 for a plain tensor): the ASPP concat (aspp.py:47) is written in place. */
 int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd /*[N][C][2]*/,
                   void* ws, size_t ws_bytes, int N, int HW, int C, float eps, int relu, void* stream);
+/* the same with the statistics taken from the producing convolution's partials (vqw_conv2d_fwd_stats) */
+int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, const float* part,
+                        int nparts, int N, int HW, int C, float eps, int relu, void* stream);
 int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
                   float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
 

@@ -136,6 +136,32 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
     return conv_direct_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
 }
 
+// Convolution that also leaves the InstanceNorm statistics of its output (per-tile partial sums from the epilogue of the
+// halo-tile kernel): the norm that follows (blocks.py:45-49: conv -> InstanceNorm -> ReLU) skips its own reduction pass.
+// ..._stats_parts() = partial (sum, sum of squares) pairs per (image, channel), 0 when the shape is not served.
+extern "C" int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H, int W, int Cout, int ksize, int dil) {
+    ConvIn in{nullptr, nullptr, C0, C1, up0};
+    if (g_conv_backend != 0 || N <= 0 || !conv_mfma_fwd_ok(in, Cout, ksize) || !conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return 0;
+    if (conv_batch_group(N, H, W, C0 + C1, Cout) < N) return 0;
+    return conv_halo_stat_tiles(in, H, W, Cout);
+}
+extern "C" int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const float* src1, int C1, const float* w_ohwi,
+                                    const float* bias, float* y, float* part, int N, int H, int W, int Cout, int ksize, int dil,
+                                    void* stream) {
+    int rc = check_conv_args("vqw_conv2d_fwd_stats", src0, C0, up0, src1, C1, N, H, W, Cout, ksize, dil);
+    if (rc) return rc;
+    VQW_CHECK(w_ohwi && y && part, "vqw_conv2d_fwd_stats: weights, output and partials must be set");
+    VQW_CHECK(vqw_conv2d_fwd_stats_parts(C0, C1, up0, N, H, W, Cout, ksize, dil) > 0,
+              "vqw_conv2d_fwd_stats: shape not served by the halo-tile kernel (query vqw_conv2d_fwd_stats_parts)");
+    ConvIn in{src0, src1, C0, C1, up0};
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
+    const double px = (double)N * H * W;
+    const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
+    ProfScope ps(0, flops, st, bytes);
+    return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, 0, st, part);
+}
+
 extern "C" size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, int ksize) {
     int Cin = C0 + C1;
     if (N > 0 && H > 0 && W > 0) {          // > 4 GiB tensors run as image groups: size for a group

@@ -33,7 +33,8 @@ int conv_wgrad_tile(const ConvIn& in, const float* dy, float* ws, float* bpart, 
                     hipStream_t st);
 bool conv_halo_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
 int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
-                  hipStream_t st);
+                  hipStream_t st, float* stats = nullptr);
+int conv_halo_stat_tiles(const ConvIn& in, int H, int W, int Cout);     // partials per plane written when `stats` is set
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
 bool conv_up2_ok(int Cin, int Cout, long Plow);
 size_t conv_up2_ws_floats(int Cin, int Cout);

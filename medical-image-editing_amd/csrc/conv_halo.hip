@@ -47,6 +47,7 @@ struct HaloArgs {
     int kt;                    // consecutive spatial tiles per workgroup
     int relu;
     unsigned nb0, nb1, nbw, nby;
+    float* stats;              // optional [N][tilesY*tilesX][Cout][2]: per-tile (sum, sum of squares) of the output
 };
 
 template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC>
@@ -73,6 +74,11 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                              // [2][HBUF]
     float* Ws = smem + 2 * HBUF;                   // [WPERSIST ? 1 : 2][WBUF]
+    // InstanceNorm statistics of the output, fused: every wave leaves the column sums of its tile rows here, after the
+    // item's barrier BN threads fold the TH rows in a fixed order and write one (sum, sum of squares) pair per cout and
+    // tile; the norm's finalize sums the tiles of a plane in double.  Two buffers: a fold reads while the next tile's
+    // rows may already be written (the fold of tile k and the row sums of tile k+1 are one barrier apart).
+    float* Rs = smem + 2 * HBUF + (WPERSIST ? 1 : 2) * WBUF;      // [2][TH][BN][2]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int H = a.H, W = a.W, Cout = a.Cout;
@@ -269,6 +275,21 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         else if (s >= CS + LH && s < CS + NCOM) commit_w(s - CS - LH, cur ^ 1);
     };
     auto slotted = [&](int s0, int n) { return s0 >= 0 && (s0 < NSLOT || (s0 + n > CS && s0 < CS + NCOM)); };
+    int fold_t = -1, spar = 0;         // tile whose row sums wait in Rs[spar] (-1: none)
+    auto fold_stats = [&]() {          // after the barrier that follows a finished tile
+        if (fold_t < 0) return;        // uniform
+        if (tid < BN && co_base + tid < Cout) {
+            const float* R = Rs + spar * (TH * BN * 2) + tid * 2;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < TH; ++r) { s1 += R[r * BN * 2]; s2 += R[r * BN * 2 + 1]; }
+            float* o = a.stats + ((size_t)fold_t * Cout + co_base + tid) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+        fold_t = -1;
+        spar ^= 1;
+    };
     for (int item = 0; item < nitems; ++item) {
         if (ch == 0) {
 #pragma unroll
@@ -389,10 +410,39 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
             }
             pending = true;
             dn = cn; dtx = ctx; dty = cty;
+            if (a.stats) {             // uniform
+                float* R = Rs + spar * (TH * BN * 2);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float rv = (cty * TH + wr * TM + i) < H ? 1.f : 0.f;       // rows below the image do not count
+                    if constexpr (M16) {      // lane: cout = lane&15, pixels blk*16 + 4*(lane>>4) + r
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float v = done4[i][blk][r]; s1 += v; s2 = fmaf(v, v, s2); }
+                        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                        if (lane < 16) { R[((wr * TM + i) * BN + lane) * 2] = s1 * rv; R[((wr * TM + i) * BN + lane) * 2 + 1] = s2 * rv; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {    // lane: cout = lane&31, 16 of the row's 32 pixels; the other half in lane^32
+                            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { const float v = done[i][j][r]; s1 += v; s2 = fmaf(v, v, s2); }
+                            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                            const int col = (wc * TN + j) * 32 + (lane & 31);
+                            if (lane < 32) { R[((wr * TM + i) * BN + col) * 2] = s1 * rv; R[((wr * TM + i) * BN + col) * 2 + 1] = s2 * rv; }
+                        }
+                    }
+                }
+                fold_t = (dn * a.tilesX + dtx) * a.tilesY + dty;
+            }
         }
         ch = nxch; cn = nn; ctx = ntx; cty = nty;
         __syncthreads();               // the item's slots committed buffer cur^1
         cur ^= 1;
+        fold_stats();
     }
 #pragma unroll
     for (int s = 0; s < NFP; ++s) flush_piece(s);
@@ -400,9 +450,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
 
 template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC = false>
 int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
-                hipStream_t st) {
+                hipStream_t st, float* stats) {
     constexpr int KP = BN == 16 ? 24 : KC + 4;
-    constexpr size_t lds = (size_t)(2 * (TH + 2) * HALO_W * KP + (WPERSIST ? 1 : 2) * 9 * BN * KP) * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * (TH + 2) * HALO_W * KP + (WPERSIST ? 1 : 2) * 9 * BN * KP + 2 * TH * BN * 2) * sizeof(float);
     static_assert(lds <= 160 * 1024, "halo tile does not fit the 160 KB LDS");
     static bool attr_set = false;
     auto kern = k_conv_halo<NW, TH, BN, KC, WPERSIST, TWO_SRC>;
@@ -419,6 +469,7 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     a.tilesY = ceil_div(H, TH); a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
     a.ntn = ceil_div(Cout, BN); a.nch = (in.C0 + in.C1) / KC;
     a.relu = relu;
+    a.stats = stats;
     const long P = (long)N * H * W;
     a.nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4);
     a.nb1 = (unsigned)(P * in.C1 * 4);
@@ -452,29 +503,38 @@ bool conv_halo_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, i
     return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
 }
 
+// rows per tile of the variant conv_halo_fwd picks (the statistics partials are per tile)
+static int halo_tile_rows(const ConvIn& in, int Cout) {
+    const int Cin = in.C0 + in.C1;
+    if (Cout <= 16 && g_halo16) return 16;
+    if (Cin == 32 && in.C1 == 0 && Cout > 32) return 4;
+    return 8;
+}
+int conv_halo_stat_tiles(const ConvIn& in, int H, int W, int Cout) { return ceil_div(H, halo_tile_rows(in, Cout)) * (W / 32); }
+
 int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
-                  hipStream_t st) {
+                  hipStream_t st, float* stats) {
     const int Cin = in.C0 + in.C1;
     if (Cout <= 16 && g_halo16) {       // 16-cout layers: 16x16x4 MFMA, 16 x 32 pixel tiles
-        if (Cin == 16 && in.C1 == 0) return launch_halo<8, 16, 16, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st);
-        if (in.C1 > 0) return launch_halo<8, 16, 16, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st);
-        return launch_halo<8, 16, 16, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
+        if (Cin == 16 && in.C1 == 0) return launch_halo<8, 16, 16, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
+        if (in.C1 > 0) return launch_halo<8, 16, 16, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
+        return launch_halo<8, 16, 16, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
     }
     const bool wide = Cout > 32;        // 64-wide cout tile
     if (Cin == 32 && in.C1 == 0) {      // single chunk: weights stay in LDS
-        if (wide) return launch_halo<8, 4, 64, 32, true>(in, w, bias, y, N, H, W, Cout, relu, st);
-        return launch_halo<8, 8, 32, 32, true>(in, w, bias, y, N, H, W, Cout, relu, st);
+        if (wide) return launch_halo<8, 4, 64, 32, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
+        return launch_halo<8, 8, 32, 32, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
     }
     if (Cin == 16 && in.C1 == 0) {
-        if (wide) return launch_halo<8, 8, 64, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st);
-        return launch_halo<8, 8, 32, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st);
+        if (wide) return launch_halo<8, 8, 64, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
+        return launch_halo<8, 8, 32, 16, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
     }
     if (in.C1 > 0) {
-        if (wide) return launch_halo<8, 8, 64, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st);
-        return launch_halo<8, 8, 32, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st);
+        if (wide) return launch_halo<8, 8, 64, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
+        return launch_halo<8, 8, 32, 16, false, true>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
     }
-    if (wide) return launch_halo<8, 8, 64, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
-    return launch_halo<8, 8, 32, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st);
+    if (wide) return launch_halo<8, 8, 64, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
+    return launch_halo<8, 8, 32, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
 }
 
 // =============================================================================================

@@ -264,6 +264,45 @@ __global__ void k_inorm_bwd_apply4(const float4* __restrict__ x, const float* __
     }
 }
 
+// statistics from per-tile float partials part[n][nparts][C][2] (written by the conv that produced x): one wave per
+// (n, c), lanes take the tiles round-robin and sum in double, fixed butterfly
+__global__ void __launch_bounds__(256) k_inorm_finalize_parts(const float* __restrict__ part, float* __restrict__ mr, int NC, int C,
+                                                              int nparts, double inv_hw, float eps) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;
+    if (i >= NC) return;              // wave-uniform
+    const int n = i / C, c = i % C;
+    double a = 0.0, b = 0.0;
+    for (int t = s; t < nparts; t += 64) {
+        const float* o = part + (((long)n * nparts + t) * C + c) * 2;
+        a += (double)o[0];
+        b += (double)o[1];
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (s != 0) return;
+    double mean = a * inv_hw;
+    double var = b * inv_hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+extern "C" int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, const float* part,
+                                   int nparts, int N, int HW, int C, float eps, int relu, void* stream) {
+    VQW_CHECK(x && y && mean_rstd && part && nparts > 0 && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd_parts: bad arguments");
+    VQW_CHECK(y_coff >= 0 && y_coff + C <= y_cstride, "vqw_inorm_fwd_parts: output channel slice [%d,%d) outside stride %d", y_coff, y_coff + C, y_cstride);
+    hipStream_t st = (hipStream_t)stream;
+    k_inorm_finalize_parts<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, mean_rstd, N * C, C, nparts, 1.0 / (double)HW, eps);
+    long total = (long)N * HW * C;
+    if ((C & 3) == 0 && (y_cstride & 3) == 0 && (y_coff & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
+        long t4 = total / 4;
+        if (relu) k_inorm_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
+        else k_inorm_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
+    } else if (relu) k_inorm_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
+    else k_inorm_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
+    VQW_LAUNCH_CHECK("vqw_inorm_fwd_parts");
+    return VQW_OK;
+}
+
 extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, void* ws,
                              size_t ws_bytes, int N, int HW, int C, float eps, int relu, void* stream) {
     VQW_CHECK(x && y && mean_rstd && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd: bad arguments");

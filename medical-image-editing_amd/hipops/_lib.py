@@ -27,6 +27,8 @@ SIGNATURES = {
     "vqw_profile_end": (c_i, [c_p]),
     "vqw_conv2d_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_pack_dgrad_weights": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "vqw_conv2d_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "vqw_conv2d_fwd_stats": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv2d_wgrad_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv2d_wgrad": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
@@ -40,6 +42,7 @@ SIGNATURES = {
     "vqw_input_grad_gather": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_plane_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "vqw_inorm_fwd": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "vqw_inorm_fwd_parts": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "vqw_inorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_bn_partial_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_f, c_f, c_i, c_p]),

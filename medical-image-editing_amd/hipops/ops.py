@@ -301,9 +301,12 @@ def _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dil, relu=False):
     return y
 
 
+CONV_STATS = os.environ.get("VQW_CONV_STATS", "1") != "0"      # 0: InstanceNorm always reduces itself (A/B timing)
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, dilation, up0, relu):
+    def forward(ctx, x0, x1, weight, bias, dilation, up0, relu, want_stats=False):
         _dev(x0, x1, weight, bias)
         x0 = nhwc(x0)
         x1 = nhwc(x1) if x1 is not None else None
@@ -312,6 +315,7 @@ class _Conv2d(torch.autograd.Function):
         N = x0.shape[0]
         H, W = (x0.shape[2] * 2, x0.shape[3] * 2) if up0 else (x0.shape[2], x0.shape[3])
         c1 = 0 if x1 is None else x1.shape[1]
+        part = None
         if x0.shape[1] + c1 != Cin:
             raise RuntimeError("conv2d: input channels %d+%d do not match weight %s" % (x0.shape[1], c1, tuple(weight.shape)))
         if x1 is not None and (x1.shape[0] != N or x1.shape[2] != H or x1.shape[3] != W):
@@ -333,7 +337,16 @@ class _Conv2d(torch.autograd.Function):
             _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
                        "vqw_conv3x3_up2_fwd")
         else:
-            y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
+            nparts = 0
+            if want_stats and not relu:
+                nparts = _L().vqw_conv2d_fwd_stats_parts(x0.shape[1], c1, int(up0), N, H, W, Cout, ks, dilation)
+            if nparts > 0:      # the epilogue leaves the following InstanceNorm's statistics (per-tile partial sums)
+                y = empty_nhwc(N, Cout, H, W, x0)
+                part = torch.empty(N * nparts * Cout * 2, dtype=torch.float32, device=x0.device)
+                _lib.check(_L().vqw_conv2d_fwd_stats(_p(x0), x0.shape[1], int(up0), _p(x1), c1, _p(w), _p(bias), _p(y), _p(part),
+                                                     N, H, W, Cout, ks, dilation, _st()), "vqw_conv2d_fwd_stats")
+            else:
+                y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
         ctx.up_ws = up_ws
         ctx.save_for_backward(x0, x1, w, y if relu else None)
         ctx.cfg = (dilation, up0, ks, N, H, W, Cout, bias is not None)
@@ -343,10 +356,14 @@ class _Conv2d(torch.autograd.Function):
         if ctx.defer:
             ctx.params = (weight, bias)
             weight._vqw_pending = getattr(weight, "_vqw_pending", 0) + 1
+        if want_stats:
+            if part is not None:
+                ctx.mark_non_differentiable(part)
+            return y, part
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *_):
         x0, x1, w, y_relu = ctx.saved_tensors
         dilation, up0, ks, N, H, W, Cout, has_bias = ctx.cfg
         L = _L()
@@ -392,13 +409,17 @@ class _Conv2d(torch.autograd.Function):
             gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
             gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
             _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, False, ctx.up_ws is not None)
-        return g0, g1, gw, gb, None, None, None
+        return g0, g1, gw, gb, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False):
+def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, want_stats=False):
     """'same' conv (k in {1,3}, stride 1) of the virtual input [up2x(x) | skip] (channel concat);
-    relu=True fuses nn.ReLU into the epilogue."""
-    return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu))
+    relu=True fuses nn.ReLU into the epilogue.  want_stats=True returns (y, part): `part` (or None when the shape is not
+    served) holds the statistics of y for the InstanceNorm that follows: instance_norm(y, ..., part=part)."""
+    if want_stats and CONV_STATS:
+        return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), True)
+    y = _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu))
+    return (y, None) if want_stats else y
 
 
 # ----------------------------------------------------------------------------------------------
@@ -526,15 +547,20 @@ def conv2d_cat(x, weight_a, bias_a, weight_b, bias_b):
 # ----------------------------------------------------------------------------------------------
 class _InstanceNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, relu, eps):
+    def forward(ctx, x, relu, eps, part=None):
         _dev(x)
         x = nhwc(x)
         N, C, H, W = x.shape
         L = _L()
         y = torch.empty_like(x, memory_format=CL)
         mr = torch.empty(N * C * 2, dtype=torch.float32, device=x.device)
-        ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
-        _lib.check(L.vqw_inorm_fwd(_p(x), _p(y), C, 0, _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, int(relu), _st()), "vqw_inorm_fwd")
+        if part is not None:        # statistics left by the producing convolution's epilogue
+            nparts = part.numel() // (N * C * 2)
+            _lib.check(L.vqw_inorm_fwd_parts(_p(x), _p(y), C, 0, _p(mr), _p(part), nparts, N, H * W, C, eps, int(relu), _st()),
+                       "vqw_inorm_fwd_parts")
+        else:
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+            _lib.check(L.vqw_inorm_fwd(_p(x), _p(y), C, 0, _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, int(relu), _st()), "vqw_inorm_fwd")
         ctx.save_for_backward(x, mr)
         ctx.relu = relu
         return y
@@ -549,11 +575,12 @@ class _InstanceNorm(torch.autograd.Function):
         ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
         _lib.check(L.vqw_inorm_bwd(_p(x), _p(mr), _p(gy), C, 0, _p(gx), _p(ws), ws.numel(), N, H * W, C, int(ctx.relu), _st()),
                    "vqw_inorm_bwd")
-        return gx, None, None
+        return gx, None, None, None
 
 
-def instance_norm(x, relu=False, eps=1e-5):
-    return _InstanceNorm.apply(x, bool(relu), float(eps))
+def instance_norm(x, relu=False, eps=1e-5, part=None):
+    """part: statistics partials from conv2d(..., want_stats=True) of the SAME tensor (skips the reduction pass)."""
+    return _InstanceNorm.apply(x, bool(relu), float(eps), part)
 
 
 class _InstanceNormCat(torch.autograd.Function):

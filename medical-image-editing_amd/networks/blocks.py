@@ -28,8 +28,8 @@ class Conv2d(nn.Conv2d):
         # OHWI storage (channels_last); logical shape / state_dict unchanged
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x, up2x=False, skip=None, relu=False):
-        return ops.conv2d(x, self.weight, self.bias, self.dilation[0], up2x=up2x, skip=skip, relu=relu)
+    def forward(self, x, up2x=False, skip=None, relu=False, want_stats=False):
+        return ops.conv2d(x, self.weight, self.bias, self.dilation[0], up2x=up2x, skip=skip, relu=relu, want_stats=want_stats)
 
 
 def conv3x3(in_channels, out_channels, stride=1, padding=1, bias=True):
@@ -43,8 +43,8 @@ class InstanceNorm2d(nn.Module):
         super().__init__()
         self.num_features, self.relu, self.eps = num_features, relu, eps
 
-    def forward(self, x):
-        return ops.instance_norm(x, relu=self.relu, eps=self.eps)
+    def forward(self, x, part=None):
+        return ops.instance_norm(x, relu=self.relu, eps=self.eps, part=part)
 
 
 class FusedReLU(nn.Identity):
@@ -93,9 +93,19 @@ class DoubleConv(nn.Module):
         self.double_conv = nn.Sequential(*layers)
 
     def forward(self, x, up2x=False, skip=None):
-        x = self.double_conv[0](x, up2x=up2x, skip=skip)
-        for layer in list(self.double_conv)[1:]:
-            x = layer(x)
+        # conv -> InstanceNorm pairs: the conv's epilogue leaves the norm's statistics (ops.conv2d want_stats)
+        layers = list(self.double_conv)
+        i = 0
+        while i < len(layers):
+            layer = layers[i]
+            kw = dict(up2x=up2x, skip=skip) if i == 0 else {}
+            if isinstance(layer, Conv2d) and i + 1 < len(layers) and isinstance(layers[i + 1], InstanceNorm2d):
+                x, part = layer(x, want_stats=True, **kw)
+                x = layers[i + 1](x, part=part)
+                i += 2
+            else:
+                x = layer(x, **kw)
+                i += 1
         return x
 
 
