@@ -111,6 +111,8 @@ int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int g
  * [sum, sumsq] partial totals via (sum_out) for cross-rank reduction: see vqw_bn_* below.  */
 int vqw_bn_partial_stats(const float* x, double* sums /*[C][2]*/, void* ws, size_t ws_bytes,
                          int N, int HW, int C, void* stream);
+/* sums[C][2] from the per-tile partials part[rows = N * parts][C][2] of the producing convolution (vqw_conv2d_fwd_stats) */
+int vqw_bn_stats_from_parts(const float* part, double* sums /*[C][2]*/, int rows, int C, void* stream);
 int vqw_bn_finalize(const double* sums /*[C][2]*/, double count, float* mean_rstd /*[C][2]*/,
                     float* running_mean, float* running_var, float momentum, float eps,
                     int C, void* stream);

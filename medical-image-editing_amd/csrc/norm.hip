@@ -446,6 +446,35 @@ __global__ void __launch_bounds__(256) k_channel_sum_finalize(const double* __re
     }
 }
 
+// the same from the per-tile float partials part[rows][C][2] a convolution's epilogue left (vqw_conv2d_fwd_stats)
+__global__ void __launch_bounds__(256) k_channel_sum_finalize_f(const float* __restrict__ part, double* __restrict__ sums, int C, int rows) {
+    __shared__ double sa[256], sb[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int r = t; r < rows; r += 256) {
+        const float* o = part + ((long)r * C + c) * 2;
+        a += (double)o[0];
+        b += (double)o[1];
+    }
+    sa[t] = a;
+    sb[t] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { sa[t] += sa[t + w]; sb[t] += sb[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        sums[2 * c] = sa[0];
+        sums[2 * c + 1] = sb[0];
+    }
+}
+extern "C" int vqw_bn_stats_from_parts(const float* part, double* sums, int rows, int C, void* stream) {
+    VQW_CHECK(part && sums && rows > 0 && C > 0, "vqw_bn_stats_from_parts: bad arguments");
+    k_channel_sum_finalize_f<<<C, 256, 0, (hipStream_t)stream>>>(part, sums, C, rows);
+    VQW_LAUNCH_CHECK("vqw_bn_stats_from_parts");
+    return VQW_OK;
+}
+
 extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size_t ws_bytes, int N, int HW, int C,
                                     void* stream) {
     VQW_CHECK(x && sums && ws && N > 0 && HW > 0 && C > 0, "vqw_bn_partial_stats: bad arguments");

@@ -642,7 +642,7 @@ def _dist_on():
 
 class _Spade(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt, res=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt, res=None, part=None):
         _dev(x, gamma, beta, res)
         x, gamma = nhwc(x), nhwc(gamma)
         N, C, H, W = x.shape
@@ -661,8 +661,11 @@ class _Spade(torch.autograd.Function):
         count = float(N * H * W)
         if training:
             sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
-            _lib.check(L.vqw_bn_partial_stats(_p(x), _p(sums), _p(ws), ws.numel(), N, H * W, C, _st()), "vqw_bn_partial_stats")
+            if part is not None:    # per-tile sums left by the producing convolution's epilogue
+                _lib.check(L.vqw_bn_stats_from_parts(_p(part), _p(sums), part.numel() // (2 * C), C, _st()), "vqw_bn_stats_from_parts")
+            else:
+                ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+                _lib.check(L.vqw_bn_partial_stats(_p(x), _p(sums), _p(ws), ws.numel(), N, H * W, C, _st()), "vqw_bn_partial_stats")
             if sync and _dist_on():
                 # SyncBatchNorm semantics (run_vqwnet.py:121): global-batch statistics, one small all-reduce.
                 # Every rank holds the same per-rank batch (weak scaling), so the count needs no exchange.
@@ -714,17 +717,18 @@ class _Spade(torch.autograd.Function):
             dist.all_reduce(sums)
         _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), gptr, bptr, gbs, _p(gy), _p(sums), count, _p(gx), N * H * W, C,
                                          int(relu), int(training), _st()), "vqw_spade_bwd_apply")
-        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None, (gy if ctx.has_res else None)
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None, (gy if ctx.has_res else None), None
 
 
 def spade_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, sync=True,
-               num_batches_tracked=None, residual=None):
-    """residual: added AFTER the activation (y = act(spade(x)) + residual); needs C % 4 == 0."""
+               num_batches_tracked=None, residual=None, part=None):
+    """residual: added AFTER the activation (y = act(spade(x)) + residual); needs C % 4 == 0.
+    part: statistics partials of x from conv2d(..., want_stats=True) (training mode skips its reduction pass)."""
     if residual is not None and (x.shape[1] & 3 or gamma.shape[1] & 3):
         return add(spade_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync,
-                              num_batches_tracked), residual)
+                              num_batches_tracked, part=part), residual)
     return _Spade.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu),
-                        bool(sync), num_batches_tracked, residual)
+                        bool(sync), num_batches_tracked, residual, part if training else None)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -134,12 +134,13 @@ class StyledDenorm(nn.Module):
             return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias), None
         return self.mlp_gamma(actv), self.mlp_beta(actv)
 
-    def forward(self, x, style, relu=False, maps=None, residual=None):
+    def forward(self, x, style, relu=False, maps=None, residual=None, part=None):
         bn = self.param_free_norm
         gamma, beta = maps if maps is not None else self.style_maps(style)
         return ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
                               momentum=bn.momentum, eps=bn.eps, relu=relu,
-                              num_batches_tracked=bn.num_batches_tracked if self.training else None, residual=residual)
+                              num_batches_tracked=bn.num_batches_tracked if self.training else None, residual=residual,
+                              part=part)
 
 
 class PixelShuffle(nn.Module):
@@ -199,5 +200,5 @@ class StyledResUpBlock(nn.Module):
         h = self.conv1(x, up2x=up)
         br.join(*m1, *m2)
         h = self.norm1(h, skip_input, relu=True, maps=m1)
-        h = self.conv2(h)
-        return self.norm2(h, skip_input, relu=self.use_output_act, maps=m2, residual=s)      # shortcut + main, in the kernel
+        h, part = self.conv2(h, want_stats=True)       # the epilogue leaves norm2's batch statistics
+        return self.norm2(h, skip_input, relu=self.use_output_act, maps=m2, residual=s, part=part)   # shortcut + main, in the kernel
