@@ -102,6 +102,9 @@ int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* me
 /* the same with the statistics taken from the producing convolution's partials (vqw_conv2d_fwd_stats) */
 int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, const float* part,
                         int nparts, int N, int HW, int C, float eps, int relu, void* stream);
+/* statistics only: mean_rstd[N][C][2] by reduction over x, or from a convolution's partials */
+int vqw_inorm_stats(const float* x, float* mean_rstd, void* ws, size_t ws_bytes, int N, int HW, int C, float eps, void* stream);
+int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_rstd, int N, int HW, int C, float eps, void* stream);
 int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
                   float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
 
@@ -146,6 +149,10 @@ int vqw_maxpool2_bwd(const float* x, const float* gy, const float* g_skip /*null
  * gx = [out > 0] * (g_out + g_pooled routed to each 2x2 window's arg-max) = d/da = d/db.  Either gradient may be
  * NULL (that output unused).  H, W even, C % 4 == 0, 16-byte aligned tensors.                                  */
 int vqw_res_tail_fwd(const float* a, const float* b, float* out, float* pooled, int N, int H, int W, int C, void* stream);
+/* the tail reading the RAW outputs of the block's two conv branches and their InstanceNorm statistics (mean, rstd per
+ * (n, c)): a = ReLU(IN(x2)), b = IN(xid), out = ReLU(a + b) — the two normalisation apply passes disappear.       */
+int vqw_res_tail_norm_fwd(const float* x2, const float* mr2, const float* xid, const float* mrid, float* out, float* pooled,
+                          int N, int H, int W, int C, void* stream);
 int vqw_res_tail_bwd(const float* out, const float* g_pooled /*nullable*/, const float* g_out /*nullable*/, float* gx,
                      int N, int H, int W, int C, void* stream);
 int vqw_tanh_fwd(const float* x, float* y, long n, void* stream);

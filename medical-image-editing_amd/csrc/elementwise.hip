@@ -211,6 +211,56 @@ extern "C" int vqw_res_tail_fwd(const float* a, const float* b, float* out, floa
     VQW_LAUNCH_CHECK("vqw_res_tail_fwd");
     return VQW_OK;
 }
+// The ResBlock tail reading the two RAW conv outputs and their InstanceNorm statistics (blocks.py:25-36):
+//   a = ReLU(IN(x2)), b = IN(xid), out = ReLU(a + b), pooled = MaxPool2d(2)(out)
+// -- the two normalisation apply passes (read + write of a full-resolution tensor each) are gone.
+__global__ void __launch_bounds__(256) k_res_tail_norm_fwd4(const float4* __restrict__ x2, const float* __restrict__ mr2,
+                                                            const float4* __restrict__ xid, const float* __restrict__ mrid,
+                                                            float4* __restrict__ out, float4* __restrict__ pooled, int N, int H,
+                                                            int W, int C4) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)N * Ho * Wo * C4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        long p = i / C4;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const long base = (((long)n * H + 2 * ho) * W + 2 * wo) * C4 + c;
+        const long idx[4] = {base, base + C4, base + (long)W * C4, base + (long)W * C4 + C4};
+        const float4* ma = (const float4*)(mr2 + 2 * ((long)n * C4 * 4 + c * 4));
+        const float4* mb = (const float4*)(mrid + 2 * ((long)n * C4 * 4 + c * 4));
+        const float4 a0 = ma[0], a1 = ma[1], b0 = mb[0], b1 = mb[1];       // (mean, rstd) pairs of channels 4c..4c+3
+        float4 m;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 x = x2[idx[k]], y = xid[idx[k]];
+            float4 u, v, o;
+            u.x = fmaxf((x.x - a0.x) * a0.y, 0.f); u.y = fmaxf((x.y - a0.z) * a0.w, 0.f);
+            u.z = fmaxf((x.z - a1.x) * a1.y, 0.f); u.w = fmaxf((x.w - a1.z) * a1.w, 0.f);
+            v.x = (y.x - b0.x) * b0.y; v.y = (y.y - b0.z) * b0.w; v.z = (y.z - b1.x) * b1.y; v.w = (y.w - b1.z) * b1.w;
+            o.x = fmaxf(u.x + v.x, 0.f); o.y = fmaxf(u.y + v.y, 0.f); o.z = fmaxf(u.z + v.z, 0.f); o.w = fmaxf(u.w + v.w, 0.f);
+            out[idx[k]] = o;
+            if (k == 0) m = o;
+            else { m.x = fmaxf(m.x, o.x); m.y = fmaxf(m.y, o.y); m.z = fmaxf(m.z, o.z); m.w = fmaxf(m.w, o.w); }
+        }
+        pooled[i] = m;
+    }
+}
+extern "C" int vqw_res_tail_norm_fwd(const float* x2, const float* mr2, const float* xid, const float* mrid, float* out,
+                                     float* pooled, int N, int H, int W, int C, void* stream) {
+    VQW_CHECK(x2 && mr2 && xid && mrid && out && pooled && N > 0 && C > 0, "vqw_res_tail_norm_fwd: bad arguments");
+    VQW_CHECK((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0 && H >= 2 && W >= 2, "vqw_res_tail_norm_fwd: needs even H, W and C %% 4 == 0");
+    VQW_CHECK(((((uintptr_t)x2 | (uintptr_t)xid | (uintptr_t)out | (uintptr_t)pooled | (uintptr_t)mr2 | (uintptr_t)mrid) & 15) == 0),
+              "vqw_res_tail_norm_fwd: 16-byte alignment");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 4);
+    k_res_tail_norm_fwd4<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>((const float4*)x2, mr2, (const float4*)xid, mrid,
+                                                                                    (float4*)out, (float4*)pooled, N, H, W, C / 4);
+    VQW_LAUNCH_CHECK("vqw_res_tail_norm_fwd");
+    return VQW_OK;
+}
 extern "C" int vqw_res_tail_bwd(const float* out, const float* g_pooled, const float* g_out, float* gx, int N, int H, int W,
                                 int C, void* stream) {
     VQW_CHECK(out && gx && (g_pooled || g_out) && N > 0 && C > 0, "vqw_res_tail_bwd: bad arguments");

@@ -303,6 +303,31 @@ extern "C" int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int 
     return VQW_OK;
 }
 
+// statistics only (mean, rstd per (n, c)): for consumers that normalise while they read (vqw_res_tail_norm_fwd)
+extern "C" int vqw_inorm_stats(const float* x, float* mean_rstd, void* ws, size_t ws_bytes, int N, int HW, int C, float eps,
+                               void* stream) {
+    VQW_CHECK(x && mean_rstd && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_stats: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_inorm_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    int splits = plane_splits(N, HW);
+    if ((C & 3) == 0 && al16(x)) {
+        FStats4 f{(const float4*)x};
+        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    } else {
+        FStats f{x};
+        k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+    }
+    k_inorm_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>((const double*)ws, mean_rstd, N * C, C, splits, 1.0 / (double)HW, eps);
+    VQW_LAUNCH_CHECK("vqw_inorm_stats");
+    return VQW_OK;
+}
+extern "C" int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_rstd, int N, int HW, int C, float eps, void* stream) {
+    VQW_CHECK(part && mean_rstd && nparts > 0 && N > 0 && HW > 0 && C > 0, "vqw_inorm_stats_parts: bad arguments");
+    k_inorm_finalize_parts<<<ceil_div((long)N * C, 4), 256, 0, (hipStream_t)stream>>>(part, mean_rstd, N * C, C, nparts, 1.0 / (double)HW, eps);
+    VQW_LAUNCH_CHECK("vqw_inorm_stats_parts");
+    return VQW_OK;
+}
+
 extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, void* ws,
                              size_t ws_bytes, int N, int HW, int C, float eps, int relu, void* stream) {
     VQW_CHECK(x && y && mean_rstd && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd: bad arguments");

@@ -43,6 +43,8 @@ SIGNATURES = {
     "vqw_plane_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "vqw_inorm_fwd": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_i, c_p]),
     "vqw_inorm_fwd_parts": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "vqw_inorm_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_p]),
+    "vqw_inorm_stats_parts": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqw_inorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_bn_partial_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_stats_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_p]),
@@ -57,6 +59,7 @@ SIGNATURES = {
     "vqw_maxpool2_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_maxpool2_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_res_tail_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_res_tail_norm_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_res_tail_bwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_tanh_fwd": (c_i, [c_p, c_p, c_l, c_p]),
     "vqw_tanh_bwd": (c_i, [c_p, c_p, c_p, c_l, c_p]),

@@ -818,6 +818,67 @@ class _ResTail(torch.autograd.Function):
         return gx, gx
 
 
+class _ResTailNorm(torch.autograd.Function):
+    """ResBlock tail on the RAW outputs of its two conv branches (blocks.py:25-36):
+    a = ReLU(InstanceNorm(x2)), b = InstanceNorm(xid), out = ReLU(a + b), pooled = MaxPool2d(2)(out).
+    The kernel normalises while it reads, so the two apply passes of the norms disappear; x2's statistics come from its
+    convolution's epilogue partials when available.  Backward = the tail's single kernel, then the two norms' backward."""
+
+    @staticmethod
+    def forward(ctx, x2, xid, eps, part2):
+        _dev(x2, xid)
+        x2, xid = nhwc(x2), nhwc(xid)
+        if x2.shape != xid.shape:
+            raise RuntimeError("res_tail_norm: shape mismatch %s vs %s" % (tuple(x2.shape), tuple(xid.shape)))
+        N, C, H, W = x2.shape
+        L = _L()
+        mr2 = torch.empty(N * C * 2, dtype=torch.float32, device=x2.device)
+        mrid = torch.empty(N * C * 2, dtype=torch.float32, device=x2.device)
+        if part2 is not None:
+            _lib.check(L.vqw_inorm_stats_parts(_p(part2), part2.numel() // (N * C * 2), _p(mr2), N, H * W, C, eps, _st()),
+                       "vqw_inorm_stats_parts")
+        else:
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x2)
+            _lib.check(L.vqw_inorm_stats(_p(x2), _p(mr2), _p(ws), ws.numel(), N, H * W, C, eps, _st()), "vqw_inorm_stats")
+        ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), xid)
+        _lib.check(L.vqw_inorm_stats(_p(xid), _p(mrid), _p(ws), ws.numel(), N, H * W, C, eps, _st()), "vqw_inorm_stats")
+        out = torch.empty_like(x2, memory_format=CL)
+        pooled = empty_nhwc(N, C, H // 2, W // 2, x2)
+        _lib.check(L.vqw_res_tail_norm_fwd(_p(x2), _p(mr2), _p(xid), _p(mrid), _p(out), _p(pooled), N, H, W, C, _st()),
+                   "vqw_res_tail_norm_fwd")
+        ctx.save_for_backward(x2, xid, mr2, mrid, out)
+        return pooled, out
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_out):
+        x2, xid, mr2, mrid, out = ctx.saved_tensors
+        N, C, H, W = out.shape
+        L = _L()
+        gp = nhwc(g_pooled) if g_pooled is not None else None
+        go = nhwc(g_out) if g_out is not None else None
+        g = torch.empty_like(out, memory_format=CL)
+        _lib.check(L.vqw_res_tail_bwd(_p(out), _p(gp), _p(go), _p(g), N, H, W, C, _st()), "vqw_res_tail_bwd")
+        gx2 = gxid = None
+        if ctx.needs_input_grad[0]:
+            gx2 = torch.empty_like(x2, memory_format=CL)
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x2)
+            _lib.check(L.vqw_inorm_bwd(_p(x2), _p(mr2), _p(g), C, 0, _p(gx2), _p(ws), ws.numel(), N, H * W, C, 1, _st()), "vqw_inorm_bwd")
+        if ctx.needs_input_grad[1]:
+            gxid = torch.empty_like(xid, memory_format=CL)
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), xid)
+            _lib.check(L.vqw_inorm_bwd(_p(xid), _p(mrid), _p(g), C, 0, _p(gxid), _p(ws), ws.numel(), N, H * W, C, 0, _st()), "vqw_inorm_bwd")
+        return gx2, gxid, None, None
+
+
+def res_tail_norm(x2, xid, eps=1e-5, part2=None):
+    """(pooled, out) of the ResBlock tail from the raw conv outputs x2 (main branch, norm + ReLU) and xid (1x1 branch,
+    norm only); None when the shape needs the separate operators (odd sizes / channel counts)."""
+    N, C, H, W = x2.shape
+    if (H | W) & 1 or C & 3:
+        return None
+    return _ResTailNorm.apply(x2, xid, float(eps), part2)
+
+
 def res_tail(a, b):
     """(MaxPool2d(2)(ReLU(a + b)), ReLU(a + b)); falls back to the separate operators for odd sizes / channel counts."""
     N, C, H, W = a.shape

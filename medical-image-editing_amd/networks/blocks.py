@@ -75,8 +75,16 @@ class ResBlock(nn.Module):
         self.relu = nn.ReLU()
 
     def forward(self, x):
-        identity = self.downsample(x)
-        return ops.res_tail(self.double_conv(x), identity)      # (pooled, out) with a single backward kernel
+        # both branches end in an InstanceNorm: the tail kernel normalises their raw conv outputs while it reads them
+        dc, ds = self.double_conv, self.downsample
+        if RES_TAIL_NORM and dc.ends_in_norm_relu() and ds[1].eps == dc.double_conv[4].eps and not ds[1].relu:
+            x2, part2 = dc(x, raw_tail=True)
+            xid = ds[0](x)
+            got = ops.res_tail_norm(x2, xid, eps=ds[1].eps, part2=part2)
+            if got is not None:
+                return got
+            return ops.res_tail(dc.double_conv[4](x2, part=part2), ds[1](xid))      # shape not served: separate norms
+        return ops.res_tail(dc(x), ds(x))      # (pooled, out) with a single backward kernel
 
 
 class DoubleConv(nn.Module):
@@ -92,9 +100,23 @@ class DoubleConv(nn.Module):
             layers += [InstanceNorm2d(out_channels, relu=True), FusedReLU()]
         self.double_conv = nn.Sequential(*layers)
 
-    def forward(self, x, up2x=False, skip=None):
+    def ends_in_norm_relu(self):
+        m = self.double_conv
+        return len(m) == 6 and isinstance(m[4], InstanceNorm2d) and m[4].relu
+
+    def forward(self, x, up2x=False, skip=None, raw_tail=False):
+        """raw_tail=True: stop before the last InstanceNorm(+ReLU) and return (raw conv output, its statistics partials or
+        None) for a consumer that normalises while it reads (ResBlock)."""
         # conv -> InstanceNorm pairs: the conv's epilogue leaves the norm's statistics (ops.conv2d want_stats)
         layers = list(self.double_conv)
+        if raw_tail:
+            layers = layers[:3]
+            x = DoubleConv._run(layers, x, up2x, skip)
+            return self.double_conv[3](x, want_stats=True)
+        return DoubleConv._run(layers, x, up2x, skip)
+
+    @staticmethod
+    def _run(layers, x, up2x, skip):
         i = 0
         while i < len(layers):
             layer = layers[i]
@@ -110,6 +132,7 @@ class DoubleConv(nn.Module):
 
 
 FUSE_GAMMA_BETA = os.environ.get("VQW_FUSE_GAMMA_BETA", "1") != "0"
+RES_TAIL_NORM = os.environ.get("VQW_RES_TAIL_NORM", "1") != "0"      # 0: ResBlock branches apply their norms themselves (A/B)
 
 
 class StyledDenorm(nn.Module):
