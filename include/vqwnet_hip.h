@@ -163,6 +163,10 @@ int vqw_mse_bwd(const float* a, const float* b, const float* gloss, float* ga, l
 size_t vqw_reduce_ws_bytes(long n);
 int vqw_weighted_sum(const float* const* terms_dev /*device array of ptrs*/, const float* weights_dev,
                      int n_terms, float* out, void* stream);
+/* the same with HOST arrays of (device) term pointers and weights, passed to the kernel by value: 1..16 terms, no
+ * host-to-device copy */
+int vqw_weighted_sum_host(const float* const* terms /*host array of device ptrs*/, const float* weights /*host*/,
+                          int n_terms, float* out, void* stream);
 
 /* ---- vector quantisation: networks/vq/vq_module.py:45-62,159-211; grad_approximation.py:7-29 */
 size_t vqw_vq_ws_bytes(long Npix, int D, int K);

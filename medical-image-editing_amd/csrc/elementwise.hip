@@ -424,6 +424,31 @@ extern "C" int vqw_weighted_sum(const float* const* terms_dev, const float* weig
     return VQW_OK;
 }
 
+// The same with the term pointers and weights as KERNEL ARGUMENTS (host arrays, at most 16 terms): no device-side table,
+// so no host-to-device copy per call (a pinned staging buffer per call made the host allocator — and now and then the
+// whole step — wait for the device).
+struct WsumArgs {
+    const float* t[16];
+    float w[16];
+    int n;
+};
+__global__ void k_weighted_sum_args(WsumArgs a, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < a.n; ++i) s += a.w[i] * a.t[i][0];
+        out[0] = s;
+    }
+}
+extern "C" int vqw_weighted_sum_host(const float* const* terms, const float* weights, int n_terms, float* out, void* stream) {
+    VQW_CHECK(terms && weights && out && n_terms > 0 && n_terms <= 16, "vqw_weighted_sum_host: 1..16 terms");
+    WsumArgs a;
+    for (int i = 0; i < 16; ++i) { a.t[i] = i < n_terms ? terms[i] : nullptr; a.w[i] = i < n_terms ? weights[i] : 0.f; }
+    a.n = n_terms;
+    k_weighted_sum_args<<<1, 64, 0, (hipStream_t)stream>>>(a, out);
+    VQW_LAUNCH_CHECK("vqw_weighted_sum_host");
+    return VQW_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Adam (torch.optim.Adam semantics: L2 decay folded into the gradient; eps added after the
 // bias-corrected sqrt).  28 B/param of HBM traffic: read p,g,m,v; write p,m,v.

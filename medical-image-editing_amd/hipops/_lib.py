@@ -68,6 +68,7 @@ SIGNATURES = {
     "vqw_mse_bwd": (c_i, [c_p, c_p, c_p, c_p, c_l, c_p]),
     "vqw_reduce_ws_bytes": (c_sz, [c_l]),
     "vqw_weighted_sum": (c_i, [c_p, c_p, c_i, c_p, c_p]),
+    "vqw_weighted_sum_host": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "vqw_vq_ws_bytes": (c_sz, [c_l, c_i, c_i]),
     "vqw_vq_fwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_sz, c_l, c_i, c_i, c_p]),
     "vqw_vq_ema_update": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_i, c_p]),

@@ -991,24 +991,24 @@ def window_mse_loss(a, b, dataset_window, target_window):
     return _WindowMse.apply(a, b.detach(), *window_map(dataset_window, target_window))
 
 
-_wsum_weights = {}
-
-
 class _WeightedSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weights, *terms):
         dev = terms[0].device
         _dev(*terms)
         terms = [t.reshape(()).contiguous() for t in terms]
-        # pinned staging + asynchronous copies: a blocking copy of pageable memory synchronises the stream, i.e. the host
-        # would wait here for the whole forward pass and only then start to enqueue the backward pass
-        ptrs = torch.tensor([t.data_ptr() for t in terms], dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
-        key = (tuple(weights), dev)
-        w = _wsum_weights.get(key)
-        if w is None:
-            w = _wsum_weights[key] = torch.tensor(list(weights), dtype=torch.float32).pin_memory().to(dev, non_blocking=True)
         out = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.check(_L().vqw_weighted_sum(_p(ptrs), _p(w), len(terms), _p(out), _st()), "vqw_weighted_sum")
+        if len(terms) <= 16:
+            # pointers and weights travel as kernel arguments: no device-side table, no host-to-device copy (a blocking
+            # copy synchronises the stream — the host would wait for the whole forward pass before it can enqueue the
+            # backward pass —, a pinned staging buffer per call makes the host allocator wait for the device now and then)
+            tp = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+            tw = (ctypes.c_float * len(terms))(*[float(x) for x in weights])
+            _lib.check(_L().vqw_weighted_sum_host(tp, tw, len(terms), _p(out), _st()), "vqw_weighted_sum_host")
+        else:
+            ptrs = torch.tensor([t.data_ptr() for t in terms], dtype=torch.int64).to(dev)
+            w = torch.tensor(list(weights), dtype=torch.float32).to(dev)
+            _lib.check(_L().vqw_weighted_sum(_p(ptrs), _p(w), len(terms), _p(out), _st()), "vqw_weighted_sum")
         ctx.weights = list(weights)
         ctx.keep = terms
         return out

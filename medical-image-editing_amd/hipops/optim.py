@@ -23,6 +23,7 @@ class Adam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._pin_rings = {}          # (group, table size) -> [[pinned int64 buffer, event of its last upload], ...]
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -92,7 +93,25 @@ class Adam(torch.optim.Optimizer):
             n = p.numel()
             for off in range(0, n, CHUNK):
                 rows.append((ptrs[0] + 4 * off, ptrs[1] + 4 * off, ptrs[2] + 4 * off, ptrs[3] + 4 * off, min(CHUNK, n - off)))
-        table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).pin_memory().to(dev, non_blocking=True)
+        # the pointer table goes up through a small ring of persistent pinned buffers (a fresh pinned allocation per
+        # step can make the host allocator wait for the device); a slot is reused only after its copy has run
+        arr = np.asarray(rows, dtype=np.int64)
+        ring = self._pin_rings.setdefault((id(group), arr.size), [])
+        slot = None
+        for cand in ring:
+            if cand[1].query():
+                slot = cand
+                break
+        if slot is None:
+            if len(ring) >= 8:
+                slot = ring[0]
+                slot[1].synchronize()
+            else:
+                slot = [torch.empty(arr.size, dtype=torch.int64).pin_memory(), torch.cuda.Event()]
+                ring.append(slot)
+        slot[0].numpy()[:] = arr.reshape(-1)
+        table = slot[0].to(dev, non_blocking=True).view(arr.shape)
+        slot[1].record(torch.cuda.current_stream())
         b1, b2 = group["betas"]
         _lib.check(L.vqw_adam_multi(ctypes.c_void_p(table.data_ptr()), len(rows), group["lr"], b1, b2, group["eps"],
                                     group["weight_decay"], 1.0 - b1 ** t, 1.0 - b2 ** t, st), "vqw_adam_multi")

@@ -225,6 +225,63 @@ def test_res_tail_matches_separate_ops_and_aten():
         assert torch.equal(grads[0][0], ar.grad) and torch.equal(grads[0][1], br.grad)
 
 
+STATS_CASES = [
+    # N, H, W, C0, C1, up, Cout        every halo-kernel template configuration, ragged rows, partial cout tile
+    (2, 32, 32, 32, 0, False, 32),     # one chunk, weights resident
+    (2, 32, 32, 32, 0, False, 64),     # 64-wide cout tile, 4-row tiles
+    (1, 20, 64, 64, 0, False, 32),     # streamed chunks, H not a multiple of the tile: rows below the image must not count
+    (2, 16, 32, 64, 0, False, 48),     # two cout tiles, the second one partial
+    (2, 16, 32, 16, 0, False, 16),     # 16-wide MFMA variant
+    (2, 32, 32, 32, 16, True, 16),     # up-sampled + concat source, 16 couts
+    (1, 32, 64, 64, 32, True, 32),     # two sources, 32 couts
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_epilogue_statistics(case):
+    """conv2d(..., want_stats=True): the per-tile (sum, sum of squares) partials of the halo kernel's epilogue add up to
+    the plane sums of the output, and the InstanceNorm fed with them equals the one that reduces itself."""
+    ops = _ops()
+    N, H, W, C0, C1, up, Cout = case
+    torch.manual_seed(sum(case))
+    x0 = torch.randn(N, C0, H // 2 if up else H, W // 2 if up else W, device=DEV)
+    x1 = torch.randn(N, C1, H, W, device=DEV) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 3, 3, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device=DEV)
+    y, part = ops.conv2d(x0, w, b, up2x=up, skip=x1, want_stats=True)
+    assert part is not None, "shape should be served by the halo kernel"
+    y_ref = ops.conv2d(x0, w, b, up2x=up, skip=x1)
+    assert torch.equal(y, y_ref)
+    p = part.view(N, -1, Cout, 2).double().sum(1).cpu()
+    yd = y.double().cpu()
+    assert_close(p[..., 0], yd.sum((2, 3)), 2e-6, "sum", atol=1e-4)
+    assert_close(p[..., 1], (yd * yd).sum((2, 3)), 2e-6, "sum of squares")
+    a = ops.instance_norm(y, relu=True, part=part)
+    r = ops.instance_norm(y, relu=True)
+    assert_close(a, r, 2e-6, "instance norm from conv partials")
+
+
+def test_res_tail_norm_matches_separate_ops():
+    """The ResBlock tail that normalises its raw inputs (res_tail_norm) against InstanceNorm + res_tail: values and both
+    input gradients (fp32 rounding of a fused multiply-add is the only difference)."""
+    ops = _ops()
+    torch.manual_seed(11)
+    x2 = torch.randn(2, 16, 16, 32, device=DEV) * 2 + 0.5
+    xid = torch.randn(2, 16, 16, 32, device=DEV)
+    rp, ro = torch.randn(2, 16, 8, 16, device=DEV), torch.randn(2, 16, 16, 32, device=DEV)
+    res = []
+    for fused in (True, False):
+        a, b = x2.clone().requires_grad_(True), xid.clone().requires_grad_(True)
+        if fused:
+            pooled, out = ops.res_tail_norm(a, b)
+        else:
+            pooled, out = ops.res_tail(ops.instance_norm(a, relu=True), ops.instance_norm(b))
+        ((pooled * rp).sum() + (out * ro).sum()).backward()
+        res.append((pooled.detach(), out.detach(), a.grad, b.grad))
+    for u, v, what in zip(res[0], res[1], ("pooled", "out", "d x2", "d xid")):
+        assert_close(u, v, 2e-6, what, atol=1e-7)
+
+
 # --------------------------------------------------------------------------------------------------
 # blocks against the reference's golden vectors
 # --------------------------------------------------------------------------------------------------
