@@ -83,7 +83,19 @@ __global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict_
         double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
         if (active && c4 < C4) {
             int p = p0 + tr;
-            for (; p + rows < p1; p += 2 * rows) {      // two independent loads in flight per lane
+            for (; p + 3 * rows < p1; p += 4 * rows) {  // four independent element loads in flight per lane
+                float va[4], vb[4], wa[4], wb[4], xa[4], xb[4], ya[4], yb[4];
+                f(((long)n * HW + p) * C4 + c4, n, c4 * 4, va, vb);
+                f(((long)n * HW + p + rows) * C4 + c4, n, c4 * 4, wa, wb);
+                f(((long)n * HW + p + 2 * rows) * C4 + c4, n, c4 * 4, xa, xb);
+                f(((long)n * HW + p + 3 * rows) * C4 + c4, n, c4 * 4, ya, yb);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a[k] += ((double)va[k] + (double)wa[k]) + ((double)xa[k] + (double)ya[k]);
+                    b[k] += ((double)vb[k] + (double)wb[k]) + ((double)xb[k] + (double)yb[k]);
+                }
+            }
+            for (; p + rows < p1; p += 2 * rows) {
                 float va[4], vb[4], wa[4], wb[4];
                 f(((long)n * HW + p) * C4 + c4, n, c4 * 4, va, vb);
                 f(((long)n * HW + p + rows) * C4 + c4, n, c4 * 4, wa, wb);
