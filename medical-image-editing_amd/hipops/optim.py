@@ -14,8 +14,18 @@ from . import _lib
 from . import ops as _ops
 
 
-MULTI_TENSOR = os.environ.get("VQW_ADAM_MULTI", "1") != "0"
+# One multi-tensor launch per parameter group (VQW_ADAM_MULTI=1) needs a pointer table uploaded every step (gradient
+# tensors are new every step).  Measured on the training step (same box, 8 runs of the default bench each): per-tensor
+# launches 223-224 images/s every run; multi-tensor 224 in half of the runs and 107-187 in the others — the
+# host-to-device table copy in the middle of the step stalls now and then — and no faster when it does not.  Off.
+MULTI_TENSOR = os.environ.get("VQW_ADAM_MULTI", "0") != "0"
 CHUNK = 1 << 16          # elements per workgroup of the multi-tensor launch
+
+
+def _same_layout(a, b):
+    """Same element order in memory: equal strides on every dimension of size > 1 (a size-1 dimension's stride is
+    arbitrary: a (16, 1, 3, 3) weight is 'channels_last' with NCHW strides, its freshly allocated gradient is not)."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
 
 
 class Adam(torch.optim.Optimizer):
@@ -51,10 +61,10 @@ class Adam(torch.optim.Optimizer):
                 state["step"] += 1
                 t = state["step"]
                 # element-wise update: any dense layout works as long as p, g, m, v share it
-                if g.stride() != p.stride():
+                if not _same_layout(g, p):
                     g = torch.empty_strided(p.size(), p.stride(), dtype=p.dtype, device=p.device).copy_(p.grad)
                 m, v = state["exp_avg"], state["exp_avg_sq"]
-                if m.stride() != p.stride() or v.stride() != p.stride():
+                if not (_same_layout(m, p) and _same_layout(v, p)):
                     raise RuntimeError("Adam state layout does not match the parameter layout")
                 _lib.check(L.vqw_adam_step(ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
                                            ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()), p.numel(),
@@ -72,14 +82,14 @@ class Adam(torch.optim.Optimizer):
         dev = params[0].device
         steps = set()
         for p in params:
-            if not p.is_cuda or p.device != dev or p.grad.stride() != p.stride():
+            if not p.is_cuda or p.device != dev or not _same_layout(p.grad, p):
                 return False
             state = self.state[p]
             if len(state) == 0:
                 state["step"] = 0
                 state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            if state["exp_avg"].stride() != p.stride() or state["exp_avg_sq"].stride() != p.stride():
+            if not (_same_layout(state["exp_avg"], p) and _same_layout(state["exp_avg_sq"], p)):
                 return False
             steps.add(state["step"])
         if len(steps) != 1:
