@@ -60,7 +60,8 @@ int vqw_pack_dgrad_weights(const float* w_ohwi, float* wt, int Cout, int Cin, in
 /* conv -> InstanceNorm (blocks.py:45-49): the convolution's epilogue also leaves the norm's statistics as per-tile
  * partial sums part[N][parts][Cout][2] (sum, sum of squares; fp32 over one tile, the norm sums tiles in double), so
  * the norm skips its reduction pass (vqw_inorm_fwd_parts).  ..._stats_parts() returns `parts` for a shape, 0 when
- * the shape is not served by the halo-tile kernel (then use vqw_conv2d_fwd + vqw_inorm_fwd).  No ReLU epilogue.   */
+ * the shape is not served (the halo-tile and the implicit-GEMM kernel are; then use vqw_conv2d_fwd + vqw_inorm_fwd).
+ * No ReLU epilogue.                                                                                              */
 int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H, int W, int Cout, int ksize, int dil);
 int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const float* src1, int C1,
                          const float* w_ohwi, const float* bias, float* y, float* part,
@@ -80,6 +81,10 @@ size_t vqw_conv3x3_up2_ws_bytes(int Cin, int Cout);
 int vqw_conv3x3_up2_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream);
 int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const float* bias, float* y, int N, int h, int w, int Cin,
                         int Cout, int relu, void* stream);
+/* forward that also leaves the following norm's statistics partials (see vqw_conv2d_fwd_stats); parts = 0: not served */
+int vqw_conv3x3_up2_fwd_stats_parts(int Cin, int Cout, int N, int h, int w);
+int vqw_conv3x3_up2_fwd_stats(const float* x_low, const void* ws, const float* bias, float* y, float* part, int N, int h, int w,
+                              int Cin, int Cout, void* stream);
 int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
                           void* stream);
 /* weight (and bias) gradient of the same layer on the low-resolution grid (needs w % 16 == 0) */

@@ -141,9 +141,10 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
 // ..._stats_parts() = partial (sum, sum of squares) pairs per (image, channel), 0 when the shape is not served.
 extern "C" int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H, int W, int Cout, int ksize, int dil) {
     ConvIn in{nullptr, nullptr, C0, C1, up0};
-    if (g_conv_backend != 0 || N <= 0 || !conv_mfma_fwd_ok(in, Cout, ksize) || !conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return 0;
+    if (g_conv_backend != 0 || N <= 0 || conv_stem_ok(in, Cout, ksize) || conv_head_ok(in, Cout, ksize) || !conv_mfma_fwd_ok(in, Cout, ksize)) return 0;
     if (conv_batch_group(N, H, W, C0 + C1, Cout) < N) return 0;
-    return conv_halo_stat_tiles(in, H, W, Cout);
+    if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_stat_tiles(in, H, W, Cout);
+    return conv_mfma_stat_tiles(in, N, H, W, Cout, dil);        // implicit-GEMM kernel: 1x1, dilated, ragged widths
 }
 extern "C" int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const float* src1, int C1, const float* w_ohwi,
                                     const float* bias, float* y, float* part, int N, int H, int W, int Cout, int ksize, int dil,
@@ -152,14 +153,15 @@ extern "C" int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const fl
     if (rc) return rc;
     VQW_CHECK(w_ohwi && y && part, "vqw_conv2d_fwd_stats: weights, output and partials must be set");
     VQW_CHECK(vqw_conv2d_fwd_stats_parts(C0, C1, up0, N, H, W, Cout, ksize, dil) > 0,
-              "vqw_conv2d_fwd_stats: shape not served by the halo-tile kernel (query vqw_conv2d_fwd_stats_parts)");
+              "vqw_conv2d_fwd_stats: shape not served (query vqw_conv2d_fwd_stats_parts)");
     ConvIn in{src0, src1, C0, C1, up0};
     hipStream_t st = (hipStream_t)stream;
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
     const double px = (double)N * H * W;
     const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
     ProfScope ps(0, flops, st, bytes);
-    return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, 0, st, part);
+    if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, 0, st, part);
+    return conv_mfma_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, 0, st, part);
 }
 
 extern "C" size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, int ksize) {
@@ -249,6 +251,19 @@ extern "C" int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const flo
     const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
     ProfScope ps(0, flops, (hipStream_t)stream, bytes);
     return conv_up2_fwd(x_low, (const float*)ws, bias, y, N, h, w, Cin, Cout, relu, (hipStream_t)stream);
+}
+extern "C" int vqw_conv3x3_up2_fwd_stats_parts(int Cin, int Cout, int N, int h, int w) {
+    if (g_conv_backend != 0 || !conv_up2_ok(Cin, Cout, (long)N * h * w)) return 0;
+    return conv_up2_stat_tiles(Cin, Cout, h, w);
+}
+extern "C" int vqw_conv3x3_up2_fwd_stats(const float* x_low, const void* ws, const float* bias, float* y, float* part, int N, int h,
+                                         int w, int Cin, int Cout, void* stream) {
+    VQW_CHECK(x_low && ws && y && part && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_fwd_stats: bad arguments");
+    VQW_CHECK(vqw_conv3x3_up2_fwd_stats_parts(Cin, Cout, N, h, w) > 0, "vqw_conv3x3_up2_fwd_stats: shape not served");
+    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
+    const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
+    ProfScope ps(0, flops, (hipStream_t)stream, bytes);
+    return conv_up2_fwd(x_low, (const float*)ws, bias, y, N, h, w, Cin, Cout, 0, (hipStream_t)stream, part);
 }
 extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
                                      void* stream) {

@@ -23,7 +23,9 @@ int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st,
 // MFMA implicit-GEMM kernels (conv_mfma.hip)
 bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks);
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
-                  int relu, hipStream_t st);
+                  int relu, hipStream_t st, float* stats = nullptr);
+int conv_mfma_stat_tiles(const ConvIn& in, int N, int H, int W, int Cout, int dil);     // partials per plane, 0 = not available
+int conv_up2_stat_tiles(int Cin, int Cout, int h, int w);
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
 // LDS-resident halo tiles for 3x3 layers with a narrow cout tile (conv_halo.hip)
 extern int g_halo_mode, g_wgrad_tile_mode;
@@ -40,7 +42,7 @@ bool conv_up2_ok(int Cin, int Cout, long Plow);
 size_t conv_up2_ws_floats(int Cin, int Cout);
 int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st);
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
-                 hipStream_t st);
+                 hipStream_t st, float* stats = nullptr);
 int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st);
 bool conv_up2_wgrad_ok(int Cin, int Cout, int N, int h, int w);
 size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w);

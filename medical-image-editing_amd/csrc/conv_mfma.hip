@@ -45,7 +45,7 @@ struct ConvGeom {
 template <int BM, int BN, int WM, int WN, int KC, bool DEEP>
 __global__ void __launch_bounds__(256, 2)
 k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y, int N, int H,
-                int W, int Cout, ConvGeom geo, int ntn, int relu, unsigned nb0, unsigned nb1, unsigned nbw) {
+                int W, int Cout, ConvGeom geo, int ntn, int relu, unsigned nb0, unsigned nb1, unsigned nbw, float* __restrict__ stats) {
     constexpr int LDK = KC + 4;           // padded row length (floats)
     constexpr int C4 = KC / 4;            // float4 per row
     constexpr int LA = BM * C4 / 256;     // A float4 loads per thread per chunk
@@ -235,6 +235,41 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
         }
     }
 
+    // Optional: statistics of the output for the InstanceNorm that follows (see k_conv_halo): per-tile (sum, sum of
+    // squares) per cout, the wave rows folded through LDS in a fixed order.  The host only asks for it when H*W is a
+    // multiple of BM (a tile never straddles two images).
+    if (stats) {           // uniform
+        constexpr int WAVES_M = BM / WM;
+        __syncthreads();                      // As is free now
+        float* R = &As[0][0];                 // [WAVES_M][BN][2]
+        const int wave_m = wv / WAVES_N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = co_base + wn0 + j * 32 + (lane & 31);
+            const float bv = (bias && co < Cout) ? bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r] + bv; s1 += v; s2 = fmaf(v, v, s2); }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) { R[(wave_m * BN + wn0 + j * 32 + lane) * 2] = s1; R[(wave_m * BN + wn0 + j * 32 + lane) * 2 + 1] = s2; }
+        }
+        __syncthreads();
+        if (tid < BN && co_base + tid < Cout) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < WAVES_M; ++m) { s1 += R[(m * BN + tid) * 2]; s2 += R[(m * BN + tid) * 2 + 1]; }
+            const int tpi = (H * W) / BM;                                   // tiles per image of the M grid
+            const int npar = geo.out_mode == 1 ? 4 : 1;
+            const int n = tile_m / tpi, t = tile_m - n * tpi;
+            const int part = (geo.out_mode == 1 ? (int)blockIdx.y * tpi : 0) + t;
+            float* o = stats + (((size_t)n * (tpi * npar) + part) * Cout + co_base + tid) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+    }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (cout), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -290,20 +325,29 @@ static ConvGeom plain_geom(int ks, int dil, int tap0 = -1) {
 
 template <int BM, int BN, int WM, int WN, int KC, bool DEEP>
 static int launch_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
-                      const ConvGeom& geo, int relu, hipStream_t st) {
+                      const ConvGeom& geo, int relu, hipStream_t st, float* stats = nullptr) {
+    if (stats && ((long)H * W) % BM != 0) { vqw_set_error("conv_mfma_fwd: statistics need H*W to be a multiple of the pixel tile"); return VQW_ERR_ARG; }
     long P = (long)N * H * W;
     int ntm = ceil_div(P, BM), ntn = ceil_div(Cout, BN);
     const long src_px = geo.src_mode == 2 ? 4 * P : (in.up0 ? P / 4 : P);
     const unsigned nb0 = (unsigned)(src_px * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
     const unsigned nbw = (unsigned)((long)Cout * geo.ntaps * (in.C0 + in.C1) * 4);
     k_conv_mfma_fwd<BM, BN, WM, WN, KC, DEEP><<<dim3(ntm * ntn, geo.out_mode == 1 ? 4 : 1), 256, 0, st>>>(
-        in, w, bias, y, N, H, W, Cout, geo, ntn, relu, nb0, nb1, nbw);
+        in, w, bias, y, N, H, W, Cout, geo, ntn, relu, nb0, nb1, nbw, stats);
     VQW_LAUNCH_CHECK("conv_mfma_fwd");
     return VQW_OK;
 }
 
+// pixel-tile height (BM) of the variant dispatch_fwd picks
+static int dispatch_bm(const ConvIn& in, int Cout) {
+    const int Cin = in.C0 + in.C1;
+    auto cost = [&](int bn, double eff) { return (double)ceil_div(Cout, bn) * bn / eff; };
+    const double c128 = cost(128, 1.0), c64 = cost(64, 0.82), c32 = cost(32, 0.70);
+    if ((c128 <= c64 && c128 <= c32) || c64 <= c32 || Cin % 32 == 0) return 128;
+    return 256;
+}
 static int dispatch_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout,
-                        const ConvGeom& geo, int relu, hipStream_t st) {
+                        const ConvGeom& geo, int relu, hipStream_t st, float* stats = nullptr) {
     const int Cin = in.C0 + in.C1;
     const bool k32 = (Cin % 32 == 0);
     // N tile: the one that pads Cout least, weighted by how well each tile runs (wider tiles reuse A fragments more)
@@ -316,23 +360,37 @@ static int dispatch_fwd(const ConvIn& in, const float* w, const float* bias, flo
     const long wg128 = (long)ceil_div((long)N * H * W, 128) * ceil_div(Cout, 128);
     const bool small_grid = wg128 <= 256 && Cout % 64 == 0 && k32;
     if (c128 <= c64 && c128 <= c32 && !small_grid) {
-        if (k32) return launch_fwd<128, 128, 64, 64, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
-        return launch_fwd<128, 128, 64, 64, 16, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+        if (k32) return launch_fwd<128, 128, 64, 64, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st, stats);
+        return launch_fwd<128, 128, 64, 64, 16, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st, stats);
     }
     if (c64 <= c32 || small_grid) {
-        if (k32 && deep) return launch_fwd<128, 64, 64, 32, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
-        if (k32) return launch_fwd<128, 64, 64, 32, 32, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
-        return launch_fwd<128, 64, 64, 32, 16, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+        if (k32 && deep) return launch_fwd<128, 64, 64, 32, 32, true>(in, w, bias, y, N, H, W, Cout, geo, relu, st, stats);
+        if (k32) return launch_fwd<128, 64, 64, 32, 32, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st, stats);
+        return launch_fwd<128, 64, 64, 32, 16, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st, stats);
     }
-    if (k32) return launch_fwd<128, 32, 32, 32, 32, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
-    return launch_fwd<256, 32, 64, 32, 16, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st);
+    if (k32) return launch_fwd<128, 32, 32, 32, 32, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st, stats);
+    return launch_fwd<256, 32, 64, 32, 16, false>(in, w, bias, y, N, H, W, Cout, geo, relu, st, stats);
 }
 
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
-                  int relu, hipStream_t st) {
+                  int relu, hipStream_t st, float* stats) {
     const int Cin = in.C0 + in.C1;
-    if (!fits_u32((long)N * H * W, Cin, Cout) || dil > 127) return conv_direct_fwd(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
-    return dispatch_fwd(in, w, bias, y, N, H, W, Cout, plain_geom(ks, dil), relu, st);
+    if (!fits_u32((long)N * H * W, Cin, Cout) || dil > 127) {
+        if (stats) { vqw_set_error("conv_mfma_fwd: statistics not available on the generic path"); return VQW_ERR_ARG; }
+        return conv_direct_fwd(in, w, bias, y, N, H, W, Cout, ks, dil, relu, st);
+    }
+    return dispatch_fwd(in, w, bias, y, N, H, W, Cout, plain_geom(ks, dil), relu, st, stats);
+}
+// statistics partials per plane of the implicit-GEMM forward (0: not available for the shape)
+int conv_mfma_stat_tiles(const ConvIn& in, int N, int H, int W, int Cout, int dil) {
+    if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout) || dil > 127) return 0;
+    const int bm = dispatch_bm(in, Cout);
+    return ((long)H * W) % bm == 0 ? (int)((long)H * W / bm) : 0;
+}
+int conv_up2_stat_tiles(int Cin, int Cout, int h, int w) {
+    ConvIn in{nullptr, nullptr, Cin, 0, 0};
+    const int bm = dispatch_bm(in, Cout);
+    return ((long)h * w) % bm == 0 ? 4 * (int)((long)h * w / bm) : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,12 +447,12 @@ int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t s
     return VQW_OK;
 }
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
-                 hipStream_t st) {
+                 hipStream_t st, float* stats) {
     ConvIn in{x_low, nullptr, Cin, 0, 0};
     ConvGeom g{};
     g.ntaps = 4;
     g.out_mode = 1;      // parity = blockIdx.y; tap offsets and the weight block are derived from it in the kernel
-    return dispatch_fwd(in, ws, bias, y, N, h, w, Cout, g, relu, st);
+    return dispatch_fwd(in, ws, bias, y, N, h, w, Cout, g, relu, st, stats);
 }
 int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st) {
     ConvIn in{dy, nullptr, Cout, 0, 0};

@@ -35,6 +35,8 @@ SIGNATURES = {
     "vqw_conv3x3_up2_ws_bytes": (c_sz, [c_i, c_i]),
     "vqw_conv3x3_up2_prepare": (c_i, [c_p, c_p, c_sz, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_conv3x3_up2_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "vqw_conv3x3_up2_fwd_stats": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_wgrad_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_up2_wgrad_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),

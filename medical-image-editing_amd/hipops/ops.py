@@ -334,8 +334,14 @@ class _Conv2d(torch.autograd.Function):
                 return buf
             up_ws = _cached(weight, "up2", _collapse)
             y = empty_nhwc(N, Cout, H, W, x0)
-            _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
-                       "vqw_conv3x3_up2_fwd")
+            nparts = L.vqw_conv3x3_up2_fwd_stats_parts(Cin, Cout, N, H // 2, W // 2) if (want_stats and not relu) else 0
+            if nparts > 0:
+                part = torch.empty(N * nparts * Cout * 2, dtype=torch.float32, device=x0.device)
+                _lib.check(L.vqw_conv3x3_up2_fwd_stats(_p(x0), _p(up_ws), _p(bias), _p(y), _p(part), N, H // 2, W // 2, Cin, Cout, _st()),
+                           "vqw_conv3x3_up2_fwd_stats")
+            else:
+                _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
+                           "vqw_conv3x3_up2_fwd")
         else:
             nparts = 0
             if want_stats and not relu:
@@ -588,7 +594,7 @@ class _InstanceNormCat(torch.autograd.Function):
     (the torch.cat of aspp.py:47 is never materialised as a separate pass)."""
 
     @staticmethod
-    def forward(ctx, relu, eps, *xs):
+    def forward(ctx, relu, eps, parts, *xs):
         _dev(*xs)
         xs = [nhwc(x) for x in xs]
         N, _, H, W = xs[0].shape
@@ -601,9 +607,14 @@ class _InstanceNormCat(torch.autograd.Function):
             if x.shape[0] != N or x.shape[2] != H or x.shape[3] != W:
                 raise RuntimeError("instance_norm_cat: shape mismatch")
             mr = torch.empty(N * C * 2, dtype=torch.float32, device=x.device)
-            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
-            _lib.check(L.vqw_inorm_fwd(_p(x), _p(y), Ct, off, _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, int(relu), _st()),
-                       "vqw_inorm_fwd")
+            part = parts[len(mrs)] if parts is not None else None
+            if part is not None:        # statistics left by the producing convolution's epilogue
+                _lib.check(L.vqw_inorm_fwd_parts(_p(x), _p(y), Ct, off, _p(mr), _p(part), part.numel() // (N * C * 2), N, H * W, C,
+                                                 eps, int(relu), _st()), "vqw_inorm_fwd_parts")
+            else:
+                ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+                _lib.check(L.vqw_inorm_fwd(_p(x), _p(y), Ct, off, _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, int(relu), _st()),
+                           "vqw_inorm_fwd")
             mrs.append(mr)
             off += C
         ctx.save_for_backward(*xs, *mrs)
@@ -626,11 +637,12 @@ class _InstanceNormCat(torch.autograd.Function):
                        "vqw_inorm_bwd")
             outs.append(gx)
             off += C
-        return (None, None, *outs)
+        return (None, None, None, *outs)
 
 
-def instance_norm_cat(xs, relu=True, eps=1e-5):
-    return _InstanceNormCat.apply(bool(relu), float(eps), *xs)
+def instance_norm_cat(xs, relu=True, eps=1e-5, parts=None):
+    """parts: per input, the statistics partials of conv2d(..., want_stats=True) or None."""
+    return _InstanceNormCat.apply(bool(relu), float(eps), tuple(parts) if parts is not None else None, *xs)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -825,7 +837,7 @@ class _ResTailNorm(torch.autograd.Function):
     convolution's epilogue partials when available.  Backward = the tail's single kernel, then the two norms' backward."""
 
     @staticmethod
-    def forward(ctx, x2, xid, eps, part2):
+    def forward(ctx, x2, xid, eps, part2, partid=None):
         _dev(x2, xid)
         x2, xid = nhwc(x2), nhwc(xid)
         if x2.shape != xid.shape:
@@ -840,8 +852,12 @@ class _ResTailNorm(torch.autograd.Function):
         else:
             ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x2)
             _lib.check(L.vqw_inorm_stats(_p(x2), _p(mr2), _p(ws), ws.numel(), N, H * W, C, eps, _st()), "vqw_inorm_stats")
-        ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), xid)
-        _lib.check(L.vqw_inorm_stats(_p(xid), _p(mrid), _p(ws), ws.numel(), N, H * W, C, eps, _st()), "vqw_inorm_stats")
+        if partid is not None:
+            _lib.check(L.vqw_inorm_stats_parts(_p(partid), partid.numel() // (N * C * 2), _p(mrid), N, H * W, C, eps, _st()),
+                       "vqw_inorm_stats_parts")
+        else:
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), xid)
+            _lib.check(L.vqw_inorm_stats(_p(xid), _p(mrid), _p(ws), ws.numel(), N, H * W, C, eps, _st()), "vqw_inorm_stats")
         out = torch.empty_like(x2, memory_format=CL)
         pooled = empty_nhwc(N, C, H // 2, W // 2, x2)
         _lib.check(L.vqw_res_tail_norm_fwd(_p(x2), _p(mr2), _p(xid), _p(mrid), _p(out), _p(pooled), N, H, W, C, _st()),
@@ -867,16 +883,16 @@ class _ResTailNorm(torch.autograd.Function):
             gxid = torch.empty_like(xid, memory_format=CL)
             ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), xid)
             _lib.check(L.vqw_inorm_bwd(_p(xid), _p(mrid), _p(g), C, 0, _p(gxid), _p(ws), ws.numel(), N, H * W, C, 0, _st()), "vqw_inorm_bwd")
-        return gx2, gxid, None, None
+        return gx2, gxid, None, None, None
 
 
-def res_tail_norm(x2, xid, eps=1e-5, part2=None):
+def res_tail_norm(x2, xid, eps=1e-5, part2=None, partid=None):
     """(pooled, out) of the ResBlock tail from the raw conv outputs x2 (main branch, norm + ReLU) and xid (1x1 branch,
     norm only); None when the shape needs the separate operators (odd sizes / channel counts)."""
     N, C, H, W = x2.shape
     if (H | W) & 1 or C & 3:
         return None
-    return _ResTailNorm.apply(x2, xid, float(eps), part2)
+    return _ResTailNorm.apply(x2, xid, float(eps), part2, partid)
 
 
 def res_tail(a, b):

@@ -27,5 +27,6 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         # every branch normalises straight into its channel slice of the concatenated output
-        raw = [stage.conv(x) for stage in self.stages.children()]
-        return ops.instance_norm_cat(raw, relu=True, eps=1e-5)
+        # (each conv's epilogue leaves the statistics of its branch's norm)
+        raw, parts = zip(*[stage.conv(x, want_stats=True) for stage in self.stages.children()])
+        return ops.instance_norm_cat(list(raw), relu=True, eps=1e-5, parts=parts)

@@ -79,12 +79,13 @@ class ResBlock(nn.Module):
         dc, ds = self.double_conv, self.downsample
         if RES_TAIL_NORM and dc.ends_in_norm_relu() and ds[1].eps == dc.double_conv[4].eps and not ds[1].relu:
             x2, part2 = dc(x, raw_tail=True)
-            xid = ds[0](x)
-            got = ops.res_tail_norm(x2, xid, eps=ds[1].eps, part2=part2)
+            xid, partid = ds[0](x, want_stats=True)
+            got = ops.res_tail_norm(x2, xid, eps=ds[1].eps, part2=part2, partid=partid)
             if got is not None:
                 return got
-            return ops.res_tail(dc.double_conv[4](x2, part=part2), ds[1](xid))      # shape not served: separate norms
-        return ops.res_tail(dc(x), ds(x))      # (pooled, out) with a single backward kernel
+            return ops.res_tail(dc.double_conv[4](x2, part=part2), ds[1](xid, part=partid))      # shape not served: separate norms
+        xid, partid = ds[0](x, want_stats=True)
+        return ops.res_tail(dc(x), ds[1](xid, part=partid))      # (pooled, out) with a single backward kernel
 
 
 class DoubleConv(nn.Module):
@@ -219,7 +220,8 @@ class StyledResUpBlock(nn.Module):
             x, up = self.up_sample(down_input), False
         else:
             x, up = down_input, True
-        s = self.conv[1](self.conv[0](x, up2x=up))
+        s, part = self.conv[0](x, up2x=up, want_stats=True)      # the shortcut conv's epilogue leaves its norm's statistics
+        s = self.conv[1](s, part=part)
         h = self.conv1(x, up2x=up)
         br.join(*m1, *m2)
         h = self.norm1(h, skip_input, relu=True, maps=m1)

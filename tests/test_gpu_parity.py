@@ -235,6 +235,33 @@ STATS_CASES = [
     (2, 32, 32, 32, 16, True, 16),     # up-sampled + concat source, 16 couts
     (1, 32, 64, 64, 32, True, 32),     # two sources, 32 couts
 ]
+STATS_CASES_GEMM = [
+    # N, H, W, Cin, Cout, ks, dil, up     implicit-GEMM kernel (1x1, dilated) and the collapsed up-sampled form
+    (2, 32, 32, 16, 32, 1, 1, False),
+    (2, 16, 16, 64, 128, 1, 1, False),
+    (1, 32, 32, 32, 32, 3, 6, False),
+    (2, 16, 16, 32, 160, 3, 2, False),
+    (2, 32, 32, 64, 32, 3, 1, True),      # collapsed: four parity launches, each a quarter of every plane
+    (1, 32, 64, 128, 64, 3, 1, True),
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES_GEMM)
+def test_conv_epilogue_statistics_implicit_gemm(case):
+    ops = _ops()
+    N, H, W, Cin, Cout, ks, dil, up = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(N, Cin, H // 2 if up else H, W // 2 if up else W, device=DEV)
+    w = (torch.randn(Cout, Cin, ks, ks, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device=DEV)
+    y, part = ops.conv2d(x, w, b, dilation=dil, up2x=up, want_stats=True)
+    assert part is not None, "shape should be served"
+    assert torch.equal(y, ops.conv2d(x, w, b, dilation=dil, up2x=up))
+    p = part.view(N, -1, Cout, 2).double().sum(1).cpu()
+    yd = y.double().cpu()
+    assert_close(p[..., 0], yd.sum((2, 3)), 2e-6, "sum", atol=1e-4)
+    assert_close(p[..., 1], (yd * yd).sum((2, 3)), 2e-6, "sum of squares")
+    assert_close(ops.instance_norm(y, relu=True, part=part), ops.instance_norm(y, relu=True), 2e-6, "instance norm from conv partials")
 
 
 @pytest.mark.parametrize("case", STATS_CASES)
