@@ -222,8 +222,8 @@ class StyledResUpBlock(nn.Module):
             x, up = down_input, True
         s, part = self.conv[0](x, up2x=up, want_stats=True)      # the shortcut conv's epilogue leaves its norm's statistics
         s = self.conv[1](s, part=part)
-        h = self.conv1(x, up2x=up)
+        h, part1 = self.conv1(x, up2x=up, want_stats=True)      # ... and norm1's batch statistics
         br.join(*m1, *m2)
-        h = self.norm1(h, skip_input, relu=True, maps=m1)
+        h = self.norm1(h, skip_input, relu=True, maps=m1, part=part1)
         h, part = self.conv2(h, want_stats=True)       # the epilogue leaves norm2's batch statistics
         return self.norm2(h, skip_input, relu=self.use_output_act, maps=m2, residual=s, part=part)   # shortcut + main, in the kernel
