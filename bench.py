@@ -137,10 +137,9 @@ def main():
             return tr.training_step({"image": img}, noise=noise)
 
     for i in range(args.warmup):
-        step(i)
-        torch.cuda.synchronize()
-        if rank == 0:
-            print("[bench] warm-up step %d done" % i, file=sys.stderr, flush=True)
+        step(i)                 # not synchronised one by one: the warm-up also fills the allocator's pool for the number
+        if rank == 0:           # of steps the trainer keeps in flight
+            print("[bench] warm-up step %d enqueued" % i, file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -148,6 +147,7 @@ def main():
     timing = not args.no_kernel_timing
     if timing:
         _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
@@ -157,7 +157,10 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
-        print("[bench] %d timed steps: %.1f ms/step" % (args.steps, dt / args.steps * 1e3), file=sys.stderr, flush=True)
+        ms1 = torch.cuda.memory_stats(dev)
+        print("[bench] %d timed steps: %.1f ms/step; device segments allocated inside the timed region: %d (+%.2f GB reserved)"
+              % (args.steps, dt / args.steps * 1e3, ms1["segment.all.allocated"] - ms0["segment.all.allocated"],
+                 (ms1["reserved_bytes.all.current"] - ms0["reserved_bytes.all.current"]) / 2**30), file=sys.stderr, flush=True)
     prof = (ctypes.c_double * 16)()
     if timing:
         _lib.check(L.vqw_profile_end(prof), "vqw_profile_end")

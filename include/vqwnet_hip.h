@@ -112,6 +112,10 @@ int vqw_inorm_stats(const float* x, float* mean_rstd, void* ws, size_t ws_bytes,
 int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_rstd, int N, int HW, int C, float eps, void* stream);
 int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
                   float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
+/* backward of two InstanceNorms fed with the SAME gradient (the two branches in front of a ResBlock tail; a: norm + ReLU,
+ * b: norm): the common gradient is read once per pass.  ws: 2 x vqw_plane_ws_bytes(N, C, HW).  C % 4 == 0.          */
+int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float* xb, const float* mrb, const float* gy,
+                       float* gxa, float* gxb, void* ws, size_t ws_bytes, int N, int HW, int C, void* stream);
 
 /* ---- StyledDenorm = BatchNorm2d(affine=False)(x)*(1+gamma)+beta [+ReLU]: blocks.py:82-90,126-132.
  * training=1: batch statistics, running stats updated in place (momentum, unbiased var);

@@ -458,6 +458,131 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// Backward of TWO InstanceNorms that receive the SAME gradient (the two branches in front of a ResBlock tail: a with
+// its ReLU, b without): one reduction and one apply kernel read the common gradient once instead of twice each.
+// Arithmetic per element is that of vqw_inorm_bwd.
+__global__ void __launch_bounds__(256) k_inorm_bwd_pair_reduce4(const float4* __restrict__ xa, const float* __restrict__ mra,
+                                                                const float4* __restrict__ xb, const float* __restrict__ mrb,
+                                                                const float4* __restrict__ gy, double* __restrict__ parta,
+                                                                double* __restrict__ partb, int HW, int C, int splits) {
+    __shared__ double sq[4][4][256];        // [quantity: a.sum, a.dot, b.sum, b.dot][channel of the quad][thread]
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int C4 = C >> 2;
+    const int tcn = C4 < 256 ? C4 : 256;
+    const int rows = 256 / tcn;
+    const int t = threadIdx.x;
+    const int tc = t % tcn, tr = t / tcn;
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = s * per;
+    const int p1 = (p0 + per < HW) ? p0 + per : HW;
+    const bool active = tr < rows;
+    for (int cb = 0; cb < C4; cb += tcn) {
+        const int c4 = cb + tc;
+        double acc[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[q][k] = 0.0;
+        if (active && c4 < C4) {
+            const float4* ma = (const float4*)(mra + 2 * ((long)n * C + c4 * 4));
+            const float4* mb = (const float4*)(mrb + 2 * ((long)n * C + c4 * 4));
+            const float4 a0 = ma[0], a1 = ma[1], b0 = mb[0], b1 = mb[1];
+            for (int p = p0 + tr; p < p1; p += rows) {
+                const long i4 = ((long)n * HW + p) * C4 + c4;
+                const float4 va = xa[i4], vb = xb[i4], g = gy[i4];
+                const float xha[4] = {(va.x - a0.x) * a0.y, (va.y - a0.z) * a0.w, (va.z - a1.x) * a1.y, (va.w - a1.z) * a1.w};
+                const float xhb[4] = {(vb.x - b0.x) * b0.y, (vb.y - b0.z) * b0.w, (vb.z - b1.x) * b1.y, (vb.w - b1.z) * b1.w};
+                const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float qa = !(xha[k] > 0.f) ? 0.f : gg[k];        // branch a: ReLU after the norm
+                    acc[0][k] += (double)qa;
+                    acc[1][k] += (double)(qa * xha[k]);
+                    acc[2][k] += (double)gg[k];
+                    acc[3][k] += (double)(gg[k] * xhb[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sq[q][k][t] = acc[q][k];
+        __syncthreads();
+        if (tr == 0 && c4 < C4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double tq[4] = {acc[0][k], acc[1][k], acc[2][k], acc[3][k]};
+                for (int r = 1; r < rows; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tq[q] += sq[q][k][r * tcn + tc];
+                double* oa = parta + (((long)n * splits + s) * C + c4 * 4 + k) * 2;
+                double* ob = partb + (((long)n * splits + s) * C + c4 * 4 + k) * 2;
+                oa[0] = tq[0]; oa[1] = tq[1];
+                ob[0] = tq[2]; ob[1] = tq[3];
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_inorm_bwd_pair_apply4(const float4* __restrict__ xa, const float* __restrict__ mra, const float* __restrict__ ea,
+                                        const float4* __restrict__ xb, const float* __restrict__ mrb, const float* __restrict__ eb,
+                                        const float4* __restrict__ gy, float4* __restrict__ gxa, float4* __restrict__ gxb,
+                                        long total4, int HW, int C4) {
+    long stride = (long)gridDim.x * blockDim.x;
+    long plane4 = (long)HW * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const int c = (int)(i % C4) * 4;
+        const int n = (int)(i / plane4);
+        const long k = 2 * ((long)n * C4 * 4 + c);
+        const float4* m = (const float4*)(mra + k);
+        const float4* e = (const float4*)(ea + k);
+        float4 m0 = m[0], m1 = m[1], e0 = e[0], e1 = e[1];
+        const float4 g = gy[i];
+        float4 v = xa[i], o;
+        float xh, gg;
+        xh = (v.x - m0.x) * m0.y; gg = !(xh > 0.f) ? 0.f : g.x; o.x = m0.y * (gg - e0.x - xh * e0.y);
+        xh = (v.y - m0.z) * m0.w; gg = !(xh > 0.f) ? 0.f : g.y; o.y = m0.w * (gg - e0.z - xh * e0.w);
+        xh = (v.z - m1.x) * m1.y; gg = !(xh > 0.f) ? 0.f : g.z; o.z = m1.y * (gg - e1.x - xh * e1.y);
+        xh = (v.w - m1.z) * m1.w; gg = !(xh > 0.f) ? 0.f : g.w; o.w = m1.w * (gg - e1.z - xh * e1.w);
+        gxa[i] = o;
+        m = (const float4*)(mrb + k);
+        e = (const float4*)(eb + k);
+        m0 = m[0]; m1 = m[1]; e0 = e[0]; e1 = e[1];
+        v = xb[i];
+        xh = (v.x - m0.x) * m0.y; o.x = m0.y * (g.x - e0.x - xh * e0.y);
+        xh = (v.y - m0.z) * m0.w; o.y = m0.w * (g.y - e0.z - xh * e0.w);
+        xh = (v.z - m1.x) * m1.y; o.z = m1.y * (g.z - e1.x - xh * e1.y);
+        xh = (v.w - m1.z) * m1.w; o.w = m1.w * (g.w - e1.z - xh * e1.w);
+        gxb[i] = o;
+    }
+}
+// a: InstanceNorm + ReLU, b: InstanceNorm; both get gy.  ws: 2 x vqw_plane_ws_bytes(N, C, HW).
+extern "C" int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float* xb, const float* mrb, const float* gy, float* gxa,
+                                  float* gxb, void* ws, size_t ws_bytes, int N, int HW, int C, void* stream) {
+    VQW_CHECK(xa && mra && xb && mrb && gy && gxa && gxb && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_bwd_pair: bad arguments");
+    VQW_CHECK((C & 3) == 0, "vqw_inorm_bwd_pair: C %% 4 == 0");
+    VQW_CHECK(((((uintptr_t)xa | (uintptr_t)xb | (uintptr_t)gy | (uintptr_t)gxa | (uintptr_t)gxb | (uintptr_t)mra | (uintptr_t)mrb) & 15) == 0),
+              "vqw_inorm_bwd_pair: 16-byte alignment");
+    const size_t one = vqw_plane_ws_bytes(N, C, HW);
+    VQW_CHECK(ws_bytes >= 2 * one && (one & 15) == 0, "vqw_inorm_bwd_pair: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = plane_splits(N, HW);
+    double* parta = (double*)ws;
+    float* ea = (float*)((char*)ws + plane_part_bytes(N, C));
+    double* partb = (double*)((char*)ws + one);
+    float* eb = (float*)((char*)ws + one + plane_part_bytes(N, C));
+    k_inorm_bwd_pair_reduce4<<<dim3(splits, N), 256, 0, st>>>((const float4*)xa, mra, (const float4*)xb, mrb, (const float4*)gy, parta,
+                                                               partb, HW, C, splits);
+    k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(parta, ea, N * C, C, splits, 1.0 / (double)HW);
+    k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(partb, eb, N * C, C, splits, 1.0 / (double)HW);
+    const long t4 = (long)N * HW * C / 4;
+    k_inorm_bwd_pair_apply4<<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)xa, mra, ea, (const float4*)xb, mrb, eb,
+                                                                  (const float4*)gy, (float4*)gxa, (float4*)gxb, t4, HW, C / 4);
+    VQW_LAUNCH_CHECK("vqw_inorm_bwd_pair");
+    return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // BatchNorm statistics (per channel over N*H*W) -> double sums[C][2] so ranks can be summed (SyncBN).
 // sums[c] = sum over `rows` partial rows; one workgroup per channel: 256 threads take the rows round-robin, then a
 // fixed-order tree through LDS -> deterministic (16 row groups per channel walked 128 rows each one load after the other)

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vqw_inorm_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_p]),
     "vqw_inorm_stats_parts": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqw_inorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_inorm_bwd_pair": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_partial_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_stats_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_p]),
     "vqw_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_f, c_f, c_i, c_p]),

@@ -830,6 +830,9 @@ class _ResTail(torch.autograd.Function):
         return gx, gx
 
 
+IN_BWD_PAIR = os.environ.get("VQW_IN_BWD_PAIR", "1") != "0"      # 0: two separate InstanceNorm backward calls (A/B timing)
+
+
 class _ResTailNorm(torch.autograd.Function):
     """ResBlock tail on the RAW outputs of its two conv branches (blocks.py:25-36):
     a = ReLU(InstanceNorm(x2)), b = InstanceNorm(xid), out = ReLU(a + b), pooled = MaxPool2d(2)(out).
@@ -875,6 +878,13 @@ class _ResTailNorm(torch.autograd.Function):
         g = torch.empty_like(out, memory_format=CL)
         _lib.check(L.vqw_res_tail_bwd(_p(out), _p(gp), _p(go), _p(g), N, H, W, C, _st()), "vqw_res_tail_bwd")
         gx2 = gxid = None
+        if IN_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:      # both norms' backward, common gradient read once
+            gx2 = torch.empty_like(x2, memory_format=CL)
+            gxid = torch.empty_like(xid, memory_format=CL)
+            ws = _ws(2 * L.vqw_plane_ws_bytes(N, C, H * W), x2)
+            _lib.check(L.vqw_inorm_bwd_pair(_p(x2), _p(mr2), _p(xid), _p(mrid), _p(g), _p(gx2), _p(gxid), _p(ws), ws.numel(),
+                                            N, H * W, C, _st()), "vqw_inorm_bwd_pair")
+            return gx2, gxid, None, None, None
         if ctx.needs_input_grad[0]:
             gx2 = torch.empty_like(x2, memory_format=CL)
             ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x2)

@@ -15,9 +15,9 @@ from . import ops as _ops
 
 
 # One multi-tensor launch per parameter group (VQW_ADAM_MULTI=1) needs a pointer table uploaded every step (gradient
-# tensors are new every step).  Measured on the training step (same box, 8 runs of the default bench each): per-tensor
-# launches 223-224 images/s every run; multi-tensor 224 in half of the runs and 107-187 in the others — the
-# host-to-device table copy in the middle of the step stalls now and then — and no faster when it does not.  Off.
+# tensors are new every step).  With the host throttled to two steps in flight (trainers.StepThrottle) it measures +0.2 %
+# (225.8 vs 225.3 images/s, five default bench runs each); off by default: 147 launches of ~5 us behind the last weight
+# gradients cost next to nothing and need no host-to-device copy in the step.
 MULTI_TENSOR = os.environ.get("VQW_ADAM_MULTI", "0") != "0"
 CHUNK = 1 << 16          # elements per workgroup of the multi-tensor launch
 

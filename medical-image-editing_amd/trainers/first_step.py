@@ -20,6 +20,33 @@ from .data_parallel import GradientAllReducer
 LossWeights = namedtuple("LossWeights", "commit cross dist reg recon freq perceptual", defaults=(1.0,) * 5 + (0.0, 0.0))
 
 
+class StepThrottle:
+    """At most `max_inflight` training steps enqueued ahead of the GPU (VQW_MAX_INFLIGHT, default 2).
+
+    The host enqueues a step five times faster than the GPU runs it.  Unthrottled it gets many steps ahead, and every
+    tensor that was handed to another stream (record_stream: conv inputs / gradients used by the weight-gradient lanes,
+    the second view) cannot be reused by the caching allocator until the GPU has passed its last use: the allocator
+    then hipMallocs a fresh working set for every step in flight (+10 GB of reserved memory per step measured, with
+    sporadic stalls of 0.3-1 s in those calls).  Two steps in flight keep the GPU fed and the pool bounded."""
+
+    def __init__(self, device):
+        import collections
+        import os
+        self.cuda = torch.device(device).type == "cuda"
+        self.events = collections.deque()
+        self.max_inflight = max(1, int(os.environ.get("VQW_MAX_INFLIGHT", "2")))
+
+    def begin(self):
+        while len(self.events) >= self.max_inflight:
+            self.events.popleft().synchronize()
+
+    def end(self):
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.events.append(ev)
+
+
 class FlipViews:
     """view 1 = identity, view 2 = horizontal flip; noise (if given) only on the noised copy of view 2.
     `cross_ids(ids, which)` maps a view's id map into the other view's frame (flip), zeroing a border."""
@@ -95,6 +122,7 @@ class FirstStepTrainer:
             concurrent_views = os.environ.get("VQW_CONCURRENT_VIEWS", "1") != "0"
         self.concurrent_views = bool(concurrent_views) and self.device.type == "cuda"
         self._s2 = None
+        self.throttle = StepThrottle(self.device)
         self.reducer = None
         self._params = list(self.encoder.parameters()) + list(self.decoder.parameters())
         if data_parallel:
@@ -190,6 +218,7 @@ class FirstStepTrainer:
 
     def training_step(self, batch, noise=None):
         image = batch['image'] if isinstance(batch, dict) else batch
+        self.throttle.begin()
         if self.reducer is not None:
             ops.reset_pending(self._params)
         out = self.forward_losses(image, noise)
@@ -205,6 +234,7 @@ class FirstStepTrainer:
             self.reducer.finish()
         self.enc_optim.step()
         self.dec_optim.step()
+        self.throttle.end()
         return out
 
     @staticmethod

@@ -20,6 +20,8 @@ class SecondStepTrainer:
     def __init__(self, encoder, decoder, dis=None, loss_weight=None, n_inner_loops=1, lr=1e-4, betas=(0.5, 0.999),
                  weight_decay=0.0, device="cuda", data_parallel=False):
         self.device = torch.device(device)
+        from .first_step import StepThrottle
+        self.throttle = StepThrottle(self.device)      # at most two steps enqueued ahead of the GPU
         self.encoder = encoder.to(self.device)
         self.decoder = decoder.to(self.device).train()
         self.dis = (dis if dis is not None else NLayerDiscriminator()).to(self.device).train()
@@ -41,6 +43,7 @@ class SecondStepTrainer:
     def training_step(self, batch):
         image = batch['image'] if isinstance(batch, dict) else batch
         w = self.w
+        self.throttle.begin()
         if self.dec_reducer is not None:
             ops.reset_pending(self.dec_optim.param_groups[0]["params"])
         self.encoder.eval()
@@ -80,4 +83,5 @@ class SecondStepTrainer:
             if self.dis_reducer is not None:
                 self.dis_reducer.finish()
             self.dis_optim.step()
+        self.throttle.end()
         return dict(gen_total=l_gen_total, recon=l_recon, gen=l_gen, dis_total=l_dis_total, ids=ids, recon_image=recon)
