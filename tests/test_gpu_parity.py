@@ -1088,6 +1088,30 @@ def test_multi_window_recon_loss():
     tr.training_step(img)
 
 
+def test_host_throttle_bounds_steps_in_flight_and_allocator_pool():
+    """trainers.StepThrottle: never more than two steps enqueued ahead of the GPU, and in steady state a step allocates
+    (almost) no new device segments — unthrottled, every step in flight needed a fresh working set because tensors that
+    were record_stream'ed to the weight-gradient lanes / the second view cannot be reused before the GPU has passed them."""
+    import bench
+    from trainers import FirstStepTrainer
+    torch.manual_seed(0)
+    tr = FirstStepTrainer(device=DEV)
+    assert tr.throttle.max_inflight == 2
+    img, noise = bench.synthetic_batch(8, 128, 3, torch.device(DEV))
+    for _ in range(4):                          # fills the pool for two steps in flight
+        tr.training_step({"image": img}, noise=noise)
+        assert len(tr.throttle.events) <= 2
+    torch.cuda.synchronize()
+    s0 = torch.cuda.memory_stats()
+    for _ in range(8):
+        tr.training_step({"image": img}, noise=noise)
+        assert len(tr.throttle.events) <= 2
+    torch.cuda.synchronize()
+    s1 = torch.cuda.memory_stats()
+    grown = s1["reserved_bytes.all.current"] - s0["reserved_bytes.all.current"]
+    assert grown <= 0.25 * s0["reserved_bytes.all.current"], "allocator pool grew by %.1f MB over 8 steady-state steps" % (grown / 2**20)
+
+
 def test_training_step_is_bit_deterministic():
     """Two runs of the same seeded training (fresh modules, three steps, two views on two streams, weight gradients on
     the side stream) end in bit-identical parameters, codebook and losses: no result depends on kernel scheduling
