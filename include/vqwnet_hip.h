@@ -179,6 +179,9 @@ int vqw_weighted_sum_host(const float* const* terms /*host array of device ptrs*
 
 /* ---- vector quantisation: networks/vq/vq_module.py:45-62,159-211; grad_approximation.py:7-29 */
 size_t vqw_vq_ws_bytes(long Npix, int D, int K);
+/* which search / statistics route (D, K) takes: 0 = codebook in LDS + matrix-core statistics, 1 = codebook in LDS +
+ * sorted statistics, 2 = fused MFMA score GEMM / arg-max + sorted statistics, 3 = generic scalar + sorted statistics */
+int vqw_vq_plan(int D, int K);
 /* x [Npix][D] (NHWC rows), embed [K][D].  Outputs: ids int64 [Npix], q [Npix][D],
  * commit = mean((x-q)^2); when stats != NULL also counts[K] and embed_sum[D][K]
  * (layout of the reference's embed_avg) as double in `stats` = [K + D*K].

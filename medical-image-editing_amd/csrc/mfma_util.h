@@ -29,6 +29,12 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned byt
     return f;
 }
 
+__device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 f) {
+    u32x4 v;
+    v[0] = __float_as_uint(f.x); v[1] = __float_as_uint(f.y); v[2] = __float_as_uint(f.z); v[3] = __float_as_uint(f.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 0);
+}
+
 // A select between two values that are both evaluated.  Written as `c ? f(x) : k` the address arithmetic of f lands in
 // an exec-masked block of its own; basic-block boundaries inside an MFMA loop keep the scheduler from spreading the
 // prefetch / store instructions between the MFMAs (they end up in one run during which the matrix pipe idles).

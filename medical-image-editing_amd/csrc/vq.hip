@@ -2,57 +2,112 @@
 // Replaces networks/vq/vq_module.py:45-62 (_torch_knn), :168-202 (_quantize), :204-207 (lookup) and
 // networks/vq/grad_approximation.py:7-29 of the reference.  Rows are NHWC pixels: x[Npix][D].
 //
-// Score (same association order as the reference): s_k = ((2 * (e_k . x)) - |e_k|^2) - |x|^2, fp32 FMA
-// chain over d ascending; arg-max over k with ties to the LOWEST index.  The K x N score matrix, the N x K
-// one-hot and the D x N x K "embed_sum" GEMM of the reference are never materialised.
+// Score (same association order as the reference): s_k = ((2 * (e_k . x)) - |e_k|^2) - |x|^2 in fp32; arg-max over k
+// with ties to the LOWEST index.  The K x N score matrix, the N x K one-hot and the D x N x K "embed_sum" GEMM of the
+// reference are never materialised.
+//
+// Three search routes (vq_plan):
+//   SMALL   codebook (+ norms) resident in LDS, query row in registers, scalar FMA chains over d ascending.  EMA
+//           statistics  X^T . onehot  (vq_module.py:186) on the matrix cores: per wave a 64-pixel tile of X goes through
+//           LDS as the A operand of v_mfma_f32_16x16x4_f32, the one-hot of the wave's ids is built in registers as B;
+//           counts come from a row of ones appended to X.  Exact fp32, fixed order.
+//   MFMA    any codebook that does not fit LDS (BASELINE config 4: K = 1024, D = 256): the score GEMM runs on
+//           v_mfma_f32_32x32x2_f32 with codes on the M axis and pixels on the N axis, so one lane owns one pixel and
+//           keeps its running (max, arg-max) in two registers across all code tiles; S never exists.
+//   GENERIC odd D / very wide D: scalar kernel, codebook from LDS or global.
+// EMA statistics of the MFMA / GENERIC routes: deterministic counting sort of the pixels by code (wave-private
+// histograms, stable ranks) + segmented row sums in sorted order.  No float atomics anywhere.
 #include "common.h"
-#include "conv_common.h"
+#include "mfma_util.h"
 #include "../../include/vqwnet_hip.h"
 
 #define VQ_BLOCK 256
-#define VQ_LDS_FLOATS 15360  // 60 KiB of LDS for codebook + norms (+ privatised stats)
+#define VQ_LDS_FLOATS 15360  // 60 KiB of LDS for codebook + norms
+#define VQ_MAX_D 1024
 
 static inline int vq_blocks(long Npix) { return (int)imin(2048, ceil_div(Npix, VQ_BLOCK)); }
-
 static inline bool vq_lds_codebook(int D, int K) { return (long)K * D + K <= VQ_LDS_FLOATS; }
-static inline bool vq_lds_stats(int D, int K) { return (long)K * D + K + 4L * K * (D + 1) <= VQ_LDS_FLOATS; }   // one statistics slab per wave
-
-// ---- large codebooks (BASELINE config 4: K = 1024, D = 256): score GEMM on the matrix cores + wave-per-pixel select
-#define VQ_GEMM_CHUNK 65536L          // pixels per score chunk (the K x N matrix is never held whole)
-static inline bool vq_use_gemm(int D, int K) { return !vq_lds_codebook(D, K) && K >= 64 && (K % 4 == 0) && (D % 4 == 0) && D >= 8; }
-static inline long vq_gemm_chunk(long Npix) { return Npix < VQ_GEMM_CHUNK ? Npix : VQ_GEMM_CHUNK; }
-static inline size_t vq_gemm_ws_bytes(long Npix, int D, int K) {
-    size_t cpart = (((size_t)(Npix + 3) / 4) * sizeof(double) + 255) / 256 * 256;
-    size_t accum = ((size_t)K * (D + 1) + K) * sizeof(float) + 256;
-    return cpart + accum + (size_t)vq_gemm_chunk(Npix) * K * sizeof(float) + 256;
+static inline int vq_pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+// matrix-core statistics in the small kernel: (D/16 + 1) x NT accumulator tiles of 16 x 16, NT = pow2 >= ceil(K/16)
+static inline int vq_small_nt(int D, int K) {
+    if (!(D == 16 || D == 32 || D == 64) || !vq_lds_codebook(D, K)) return 0;
+    int nt = vq_pow2_ge(ceil_div(K, 16));
+    return (D / 16 + 1) * nt <= 16 ? nt : 0;
 }
+static inline int vq_mfma_dt(int D) { return D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : 256; }
+static inline bool vq_use_mfma(int D, int K) { return (D % 4 == 0) && D >= 8 && D <= 256 && K >= 32; }
 
-extern "C" size_t vqw_vq_ws_bytes(long Npix, int D, int K) {
-    if (vq_use_gemm(D, K)) return vq_gemm_ws_bytes(Npix, D, K);
-    size_t nb = (size_t)vq_blocks(Npix);
-    // per-block commit partial (double) + per-block stats partials (float) or ONE global float accumulator
-    size_t rows = vq_lds_stats(D, K) ? nb : 1;
-    return ((nb * sizeof(double) + 255) / 256) * 256 + rows * (size_t)K * (D + 1) * sizeof(float) + 256;
+enum { VQ_PLAN_SMALL_MFMA_STATS = 0, VQ_PLAN_SMALL_SORTED = 1, VQ_PLAN_MFMA = 2, VQ_PLAN_GENERIC = 3 };
+static inline int vq_plan(int D, int K) {
+    if (vq_small_nt(D, K) > 0) return VQ_PLAN_SMALL_MFMA_STATS;
+    if (vq_lds_codebook(D, K) && (D == 16 || D == 32 || D == 64)) return VQ_PLAN_SMALL_SORTED;
+    if (vq_use_mfma(D, K)) return VQ_PLAN_MFMA;
+    return VQ_PLAN_GENERIC;
 }
+extern "C" int vqw_vq_plan(int D, int K) { return vq_plan(D, K); }
 
+// ---- workspace layout ------------------------------------------------------------------------------------------------
+#define VQ_SB 2048          // pixels per sort block (one wave each)
+#define VQ_CH 128           // sorted rows per segment-sum work item
+static inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+struct VqWs {
+    double* cpart;      // commit partials, one per workgroup
+    float* enorm;       // |e_k|^2 (+inf padding) for the MFMA route
+    float* spart;       // per-workgroup statistics rows of the SMALL route
+    int *hist, *total, *base, *cstart, *lrank, *perm;
+    float* partial;
+    size_t bytes;
+};
+static inline long vq_ncpart(long Npix, int plan) { return plan == VQ_PLAN_MFMA ? (Npix + 127) / 128 : vq_blocks(Npix); }
+static VqWs vq_carve(void* ws, long Npix, int D, int K) {
+    const int plan = vq_plan(D, K);
+    VqWs w;
+    char* p = (char*)ws;
+    size_t o = 0;
+    w.cpart = (double*)(p + o); o += al256((size_t)vq_ncpart(Npix, plan) * sizeof(double));
+    w.enorm = (float*)(p + o); o += al256(((size_t)K + 512) * sizeof(float));
+    w.spart = (float*)(p + o);
+    if (plan == VQ_PLAN_SMALL_MFMA_STATS) o += al256((size_t)vq_blocks(Npix) * K * (D + 1) * sizeof(float));
+    const long nsb = (Npix + VQ_SB - 1) / VQ_SB;
+    const long tmax = (Npix + VQ_CH - 1) / VQ_CH + K;
+    w.hist = (int*)(p + o);
+    if (plan != VQ_PLAN_SMALL_MFMA_STATS) {
+        o += al256((size_t)nsb * K * sizeof(int));
+        w.total = (int*)(p + o); o += al256((size_t)(K + 1) * sizeof(int));
+        w.base = (int*)(p + o); o += al256((size_t)(K + 1) * sizeof(int));
+        w.cstart = (int*)(p + o); o += al256((size_t)(K + 1) * sizeof(int));
+        w.lrank = (int*)(p + o); o += al256((size_t)Npix * sizeof(int));
+        w.perm = (int*)(p + o); o += al256((size_t)Npix * sizeof(int));
+        w.partial = (float*)(p + o); o += al256((size_t)tmax * D * sizeof(float));
+    } else {
+        w.total = w.base = w.cstart = w.lrank = w.perm = nullptr;
+        w.partial = nullptr;
+    }
+    w.bytes = o + 256;
+    return w;
+}
+extern "C" size_t vqw_vq_ws_bytes(long Npix, int D, int K) { return vq_carve(nullptr, Npix, D, K).bytes; }
+
+// ======================================================================================================================
+// SMALL / GENERIC route
+// ======================================================================================================================
 // DT > 0: query row held in DT registers.  DT == 0: generic D (row re-read from global/L1).
-// LDS_CB: codebook + norms staged in LDS.  LDS_ST: EMA statistics privatised in LDS (per-block partials).
-template <int DT, bool LDS_CB, bool LDS_ST>
+// LDS_CB: codebook staged in LDS.  NT > 0: EMA statistics on the matrix cores (DT > 0 only), NT column tiles of 16 codes.
+template <int DT, bool LDS_CB, int NT>
 __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x, const float* __restrict__ embed,
                                                      int64_t* __restrict__ ids, float* __restrict__ q,
                                                      double* __restrict__ commit_part, float* __restrict__ stat_part,
-                                                     float* __restrict__ stat_global, long Npix, int D, int K, int want_stats,
-                                                     int id_base) {
+                                                     long Npix, int D, int K, int want_stats, int id_base) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_cb = smem;                                   // [K][D] if LDS_CB
     float* s_nrm = smem + (LDS_CB ? K * D : 0);           // [K]
-    float* s_st = s_nrm + K;                              // [waves][K*(D+1)] if LDS_ST: counts[K] then sum[d][k], one slab per wave
+    float* s_x = s_nrm + ((K + 3) & ~3);                  // NT > 0: [waves][64][DT + 4] X tiles, later [waves][K*(D+1)] slabs
     __shared__ double s_red[VQ_BLOCK / 64];
-    const int t = threadIdx.x;
+    constexpr int MT = NT > 0 ? DT / 16 + 1 : 1;
+    constexpr int XS = DT + 4;                            // padded tile row: conflict-free b128 stores, 2-way worst b32 reads
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (LDS_CB)
         for (int i = t; i < K * D; i += VQ_BLOCK) s_cb[i] = embed[i];
-    if (LDS_ST && want_stats)
-        for (int i = t; i < (VQ_BLOCK / 64) * K * (D + 1); i += VQ_BLOCK) s_st[i] = 0.f;
     for (int k = t; k < K; k += VQ_BLOCK) {
         float n2 = 0.f;
         for (int d = 0; d < D; ++d) { float e = embed[k * D + d]; n2 = fmaf(e, e, n2); }
@@ -60,9 +115,14 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
     }
     __syncthreads();
     const float* cb = LDS_CB ? s_cb : embed;
+    f32x4 acc[MT][NT > 0 ? NT : 1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < (NT > 0 ? NT : 1); ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     double csum = 0.0;
-    // wave-uniform trip count: the statistics below are reduced with wave shuffles, so every lane stays in the loop
-    // (lanes past the end compute on the last pixel and contribute nothing)
+    // wave-uniform trip count (the statistics tile is a wave-wide operation); lanes past the end compute on the last pixel
+    // and contribute nothing
     for (long base = (long)blockIdx.x * VQ_BLOCK; base < Npix; base += (long)gridDim.x * VQ_BLOCK) {
         const bool active = base + t < Npix;
         const long p = active ? base + t : Npix - 1;
@@ -111,71 +171,85 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
             for (int d = 0; d < D; ++d) { float ev = e[d]; if (active) qr[d] = ev; float a = xr[d] - ev; c = fmaf(a, a, c); }
         }
         if (active) csum += (double)c;
-        if (want_stats && LDS_ST) {
-            // deterministic: per code, a fixed-order wave butterfly of the member lanes' values, added by ONE lane into
-            // the wave's own LDS slab (no atomics: the summation order never depends on scheduling)
-            float* slab = s_st + (t >> 6) * K * (D + 1);
-            const int code = active ? bi : -1;
-            for (int k = 0; k < K; ++k) {
-                const unsigned long long members = __ballot(code == k);
-                if (members == 0ull) continue;
-                const bool mine = code == k;
-                if ((t & 63) == 0) slab[k] += (float)__popcll(members);
-                if (DT > 0) {
+        if constexpr (NT > 0 && DT > 0) if (want_stats) {
+            // sums[d][k] += sum_p X[p][d] * [id_p == k]  as  A (16 rows of d x 4 pixels) . B (4 pixels x 16 codes), 16 steps of
+            // 4 pixels per 64-pixel tile; row d == D of A is all ones -> counts.  One accumulation chain per tile, in pixel order.
+            float* xt = s_x + wv * 64 * XS;
 #pragma unroll
-                    for (int d = 0; d < DT; ++d) {
-                        float v = wave_sum_f(mine ? xv[d] : 0.f);
-                        if ((t & 63) == 0) slab[K + d * K + k] += v;
-                    }
-                } else {
-                    for (int d = 0; d < D; ++d) {
-                        float v = wave_sum_f(mine ? xr[d] : 0.f);
-                        if ((t & 63) == 0) slab[K + d * K + k] += v;
-                    }
+            for (int d4 = 0; d4 < DT / 4; ++d4)
+                *(float4*)(xt + lane * XS + 4 * d4) = float4{xv[4 * d4], xv[4 * d4 + 1], xv[4 * d4 + 2], xv[4 * d4 + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int code = active ? bi : -1;
+            const int lm = lane & 15, lg = lane >> 4;
+            const float ones = lm == 0 ? 1.f : 0.f;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const int pid = __shfl(code, 4 * s + lg, 64);
+                float bm[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bm[j] = pid == j * 16 + lm ? 1.f : 0.f;
+                const float* ar = xt + (4 * s + lg) * XS + lm;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float a = i < MT - 1 ? ar[i * 16] : ones;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(a, bm[j], acc[i][j]);
                 }
             }
-        } else if (want_stats && active) {
-            atomicAdd(stat_global + bi, 1.f);
-            if (DT > 0) {
-#pragma unroll
-                for (int d = 0; d < DT; ++d) atomicAdd(stat_global + K + d * K + bi, xv[d]);
-            } else {
-                for (int d = 0; d < D; ++d) atomicAdd(stat_global + K + d * K + bi, xr[d]);
-            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     csum = wave_sum_d(csum);
-    if ((t & 63) == 0) s_red[t >> 6] = csum;
+    if (lane == 0) s_red[wv] = csum;
     __syncthreads();
     if (t == 0) {
         double a = 0.0;
         for (int w = 0; w < VQ_BLOCK / 64; ++w) a += s_red[w];
         commit_part[blockIdx.x] = a;
     }
-    if (LDS_ST && want_stats) {          // fold the wave slabs in wave order
-        float* o = stat_part + (long)blockIdx.x * K * (D + 1);
+    if constexpr (NT > 0) if (want_stats) {
+        // accumulator tile (i, j), register r: row m = 16 i + 4 (lane / 16) + r, column n = 16 j + lane % 16
         const int KD1 = K * (D + 1);
-        for (int i = t; i < KD1; i += VQ_BLOCK) {
-            float a = s_st[i];
-            for (int w = 1; w < VQ_BLOCK / 64; ++w) a += s_st[w * KD1 + i];
+        float* slab = s_x + wv * KD1;          // layout of `stats`: counts[K] then sums[d][k]
+        const int lm = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * i + 4 * lg + r, n = 16 * j + lm;
+                    if (n < K) {
+                        if (m < D) slab[K + m * K + n] = acc[i][j][r];
+                        else if (m == D) slab[n] = acc[i][j][r];
+                    }
+                }
+        __syncthreads();
+        float* o = stat_part + (long)blockIdx.x * KD1;
+        for (int i = t; i < KD1; i += VQ_BLOCK) {      // fold the wave slabs in wave order
+            float a = s_x[i];
+            for (int w = 1; w < VQ_BLOCK / 64; ++w) a += s_x[w * KD1 + i];
             o[i] = a;
         }
     }
 }
 
-__global__ void k_vq_finalize(const double* __restrict__ commit_part, const float* __restrict__ stat_part, int nblocks,
+// commit = sum(commit_part) / numel; stats (SMALL route) = column sums of the per-workgroup rows, in double, fixed order
+__global__ void k_vq_finalize(const double* __restrict__ commit_part, const float* __restrict__ stat_part, long nblocks,
                               int nstat_rows, float* __restrict__ commit, double* __restrict__ stats, int KD1, double inv_numel) {
     __shared__ double s_red[4];
     const int t = threadIdx.x;
     if (blockIdx.x == 0) {
         double a = 0.0;
-        for (int i = t; i < nblocks; i += blockDim.x) a += commit_part[i];
+        for (long i = t; i < nblocks; i += blockDim.x) a += commit_part[i];
         a = wave_sum_d(a);
         if ((t & 63) == 0) s_red[t >> 6] = a;
         __syncthreads();
         if (t == 0) commit[0] = (float)((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_numel);
     }
-    if (stats) {      // column sums of the per-block partial rows: 16 columns x 16 row groups per workgroup, fixed order
+    if (stats) {      // 16 columns x 16 row groups per workgroup
         __shared__ double sm[16][17];
         const int cx = t & 15, g = t >> 4;
         for (int base = blockIdx.x * 16; base < KD1; base += gridDim.x * 16) {
@@ -195,135 +269,364 @@ __global__ void k_vq_finalize(const double* __restrict__ commit_part, const floa
     }
 }
 
-__global__ void k_vq_enorm(const float* __restrict__ embed, float* __restrict__ enorm, int D, int K) {
+// ======================================================================================================================
+// MFMA route: fused score GEMM + running arg-max
+// ======================================================================================================================
+__global__ void k_vq_enorm(const float* __restrict__ embed, float* __restrict__ enorm, int D, int K, int Kpad) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
-    float n2 = 0.f;
-    for (int d = 0; d < D; ++d) { float e = embed[(long)k * D + d]; n2 = fmaf(e, e, n2); }
+    if (k >= Kpad) return;
+    float n2 = INFINITY;            // padding rows can never win: (2*0 - inf) - |x|^2 = -inf
+    if (k < K) {
+        n2 = 0.f;
+        for (int d = 0; d < D; ++d) { float e = embed[(long)k * D + d]; n2 = fmaf(e, e, n2); }
+    }
     enorm[k] = n2;
 }
 
-// One wave per pixel: final scores ((2*dot - |e|^2) - |x|^2), arg-max with ties to the lowest index, gather, commitment
-// partial, EMA statistics by float atomics into a [counts K | sums K x D] accumulator (contiguous 4*D bytes per code).
-__global__ void __launch_bounds__(256) k_vq_select(const float* __restrict__ scores, const float* __restrict__ x,
-                                                   const float* __restrict__ embed, const float* __restrict__ enorm,
-                                                   int64_t* __restrict__ ids, float* __restrict__ q, double* __restrict__ cpart,
-                                                   float* __restrict__ accum, long p0, long pn, int D, int K, int id_base) {
-    __shared__ float s_c[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long pl = (long)blockIdx.x * 4 + wv;          // pixel inside the chunk
-    float csum = 0.f;
-    if (pl < pn) {
-        const long p = p0 + pl;
-        const float* xr = x + p * D;
-        float x2 = 0.f;
-        for (int d = lane * 4; d < D; d += 256) {
-            float4 v = *(const float4*)(xr + d);
-            x2 = fmaf(v.x, v.x, x2); x2 = fmaf(v.y, v.y, x2); x2 = fmaf(v.z, v.z, x2); x2 = fmaf(v.w, v.w, x2);
-        }
-        x2 = wave_sum(x2);
-        const float* sr = scores + pl * K;
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int k = lane * 4; k < K; k += 256) {
-            float4 sv = *(const float4*)(sr + k);
-            float4 en = *(const float4*)(enorm + k);
-            float c0 = (2.f * sv.x - en.x) - x2, c1 = (2.f * sv.y - en.y) - x2, c2 = (2.f * sv.z - en.z) - x2, c3 = (2.f * sv.w - en.w) - x2;
-            if (c0 > best) { best = c0; bi = k; }
-            if (c1 > best) { best = c1; bi = k + 1; }
-            if (c2 > best) { best = c2; bi = k + 2; }
-            if (c3 > best) { best = c3; bi = k + 3; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            float ob = __shfl_xor(best, o, 64);
-            int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (lane == 0) ids[p] = (int64_t)(bi + id_base);
-        const float* e = embed + (long)bi * D;
-        float* qr = q + p * D;
-        float c = 0.f;
-        for (int d = lane * 4; d < D; d += 256) {
-            float4 ev = *(const float4*)(e + d), xv = *(const float4*)(xr + d);
-            *(float4*)(qr + d) = ev;
-            float a0 = xv.x - ev.x, a1 = xv.y - ev.y, a2 = xv.z - ev.z, a3 = xv.w - ev.w;
-            c = fmaf(a0, a0, c); c = fmaf(a1, a1, c); c = fmaf(a2, a2, c); c = fmaf(a3, a3, c);
-            if (accum) {
-                float* ar = accum + K + (long)bi * D + d;
-                atomicAdd(ar, xv.x); atomicAdd(ar + 1, xv.y); atomicAdd(ar + 2, xv.z); atomicAdd(ar + 3, xv.w);
-            }
-        }
-        if (accum && lane == 0) atomicAdd(accum + bi, 1.f);
-        csum = wave_sum(c);
-    }
-    if (lane == 0) s_c[wv] = csum;
-    __syncthreads();
-    if (threadIdx.x == 0) cpart[p0 / 4 + blockIdx.x] = (double)s_c[0] + (double)s_c[1] + (double)s_c[2] + (double)s_c[3];
-}
-
-// commit = sum(cpart)/numel; stats[k] = counts, stats[K + d*K + k] = sums[k][d]  (the reference's embed_avg layout)
-__global__ void k_vq_gemm_finalize(const double* __restrict__ cpart, long ncp, const float* __restrict__ accum, float* __restrict__ commit,
-                                   double* __restrict__ stats, int D, int K, double inv_numel) {
+// One workgroup = 4 waves x 32 pixels.  A lane (n = lane % 32, h = lane / 32) keeps half of pixel n's row in DT/2
+// registers: MFMA step 4j+i contracts the channel pair {8j+i (h=0), 8j+4+i (h=1)}, so both operands are float4 loads.
+// Code tiles of TR = 32 * (256 / DT) rows stream through a double-buffered LDS stage (next tile prefetched into
+// registers under the MFMAs, one barrier per stage).  Accumulator register r of a 32-code block holds code row
+// 8 (r/4) + 4 h + r%4 for the lane's pixel: the arg-max is 16 compare/selects per 128 MFMAs, in ascending code order.
+// FULL: D == DT (no channel padding: the per-chunk range predicates compile away).
+template <int DT, bool FULL>
+__global__ void __launch_bounds__(256, 2) k_vq_mfma(const float* __restrict__ x, const float* __restrict__ embed,
+                                                    const float* __restrict__ enorm, int64_t* __restrict__ ids,
+                                                    float* __restrict__ q, double* __restrict__ cpart, unsigned Npix, int D, int K,
+                                                    int id_base) {
+    constexpr int NBLK = 256 / DT, TR = 32 * NBLK, LS = DT + 4, STAGE = TR * LS + TR, C4 = DT / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ double s_red[4];
-    const int t = threadIdx.x;
-    if (blockIdx.x == 0) {
-        double a = 0.0;
-        for (long i = t; i < ncp; i += blockDim.x) a += cpart[i];
-        a = wave_sum_d(a);
-        if ((t & 63) == 0) s_red[t >> 6] = a;
-        __syncthreads();
-        if (t == 0) commit[0] = (float)((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_numel);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
+    const unsigned p = blockIdx.x * 128u + wv * 32u + n;
+    const bool pvalid = p < Npix;
+    const unsigned OOB = 0xffffff00u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, Npix * (unsigned)D * 4u);
+    const __amdgpu_buffer_rsrc_t re = make_rsrc(embed, (unsigned)K * (unsigned)D * 4u);
+    float xr[DT / 2];
+    float x2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < DT / 8; ++j) {
+        const unsigned d0 = 8 * j + 4 * h;
+        const float4 v = buf_ld4(rx, sel_u32(pvalid & (FULL || d0 < (unsigned)D), (p * (unsigned)D + d0) * 4u, OOB));
+        xr[4 * j] = v.x; xr[4 * j + 1] = v.y; xr[4 * j + 2] = v.z; xr[4 * j + 3] = v.w;
     }
-    if (stats) {
-        const long n = (long)K * (D + 1);
-        for (long i = (long)blockIdx.x * blockDim.x + t; i < n; i += (long)gridDim.x * blockDim.x) {
-            if (i < K) stats[i] = (double)accum[i];
-            else {
-                long r = i - K;
-                int d = (int)(r / K), k = (int)(r % K);
-                stats[i] = (double)accum[K + (long)k * D + d];
+#pragma unroll
+    for (int i = 0; i < DT / 2; ++i) x2 = fmaf(xr[i], xr[i], x2);
+    x2 += __shfl_xor(x2, 32, 64);
+
+    // stage loader: 2048 float4 per tile, 8 per thread (thread -> column chunk c4 of rows r0 + i * RSTEP); rows past K and
+    // columns past D read as zero (buffer range check)
+    constexpr int RSTEP = 256 / C4;
+    const int r0 = tid / C4, c4 = tid % C4;
+    const bool cvalid = FULL || 4 * c4 < D;
+    const unsigned goff0 = ((unsigned)r0 * (unsigned)D + 4u * c4) * 4u, gstep = (unsigned)RSTEP * (unsigned)D * 4u;
+    const int loff0 = r0 * LS + 4 * c4;
+    const int nstage = (K + TR - 1) / TR;
+    const unsigned stage_bytes = (unsigned)TR * (unsigned)D * 4u;
+    float4 pf[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pf[i] = buf_ld4(re, sel_u32(cvalid, goff0 + i * gstep, OOB));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(float4*)(smem + loff0 + i * RSTEP * LS) = pf[i];
+    if (tid < TR) smem[TR * LS + tid] = enorm[tid];
+    __syncthreads();
+
+    float best = -INFINITY;
+    int bi = 0;
+    for (int s = 0; s < nstage; ++s) {
+        const float* buf = smem + (s & 1) * STAGE;
+        float* nbuf = smem + ((s + 1) & 1) * STAGE;
+        const bool more = s + 1 < nstage;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pf[i] = buf_ld4(re, sel_u32(cvalid, goff0 + i * gstep + (unsigned)(s + 1) * stage_bytes, OOB));
+        }
+        const float en_next = (more && tid < TR) ? enorm[(s + 1) * TR + tid] : 0.f;
+#pragma unroll 1
+        for (int b = 0; b < NBLK; ++b) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* arow = buf + (b * 32 + n) * LS + 4 * h;
+#pragma unroll
+            for (int j = 0; j < DT / 8; ++j) {
+                const float4 a = *(const float4*)(arow + 8 * j);
+                acc = MFMA32(a.x, xr[4 * j], acc);
+                acc = MFMA32(a.y, xr[4 * j + 1], acc);
+                acc = MFMA32(a.z, xr[4 * j + 2], acc);
+                acc = MFMA32(a.w, xr[4 * j + 3], acc);
+            }
+            const float* en = buf + TR * LS + b * 32 + 4 * h;
+            const int code0 = s * TR + b * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 e4 = *(const float4*)(en + 8 * g);
+                const float s0 = (2.f * acc[4 * g] - e4.x) - x2, s1 = (2.f * acc[4 * g + 1] - e4.y) - x2;
+                const float s2 = (2.f * acc[4 * g + 2] - e4.z) - x2, s3 = (2.f * acc[4 * g + 3] - e4.w) - x2;
+                if (s0 > best) { best = s0; bi = code0 + 8 * g; }
+                if (s1 > best) { best = s1; bi = code0 + 8 * g + 1; }
+                if (s2 > best) { best = s2; bi = code0 + 8 * g + 2; }
+                if (s3 > best) { best = s3; bi = code0 + 8 * g + 3; }
             }
         }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(float4*)(nbuf + loff0 + i * RSTEP * LS) = pf[i];
+            if (tid < TR) nbuf[TR * LS + tid] = en_next;
+        }
+        __syncthreads();
+    }
+    {   // the two halves of a pixel hold disjoint code rows: keep the larger score, ties to the lower code
+        const float ob = __shfl_xor(best, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (pvalid && h == 0) ids[p] = (int64_t)(bi + id_base);
+    float c = 0.f;
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q, Npix * (unsigned)D * 4u);
+#pragma unroll
+    for (int j = 0; j < DT / 8; ++j) {
+        const unsigned d0 = 8 * j + 4 * h;
+        const bool dv = FULL || d0 < (unsigned)D;
+        const float4 ev = buf_ld4(re, sel_u32(dv, ((unsigned)bi * (unsigned)D + d0) * 4u, OOB));
+        buf_st4(rq, sel_u32(pvalid & dv, (p * (unsigned)D + d0) * 4u, OOB), ev);      // out-of-range offsets are dropped
+        const float a0 = xr[4 * j] - ev.x, a1 = xr[4 * j + 1] - ev.y, a2 = xr[4 * j + 2] - ev.z, a3 = xr[4 * j + 3] - ev.w;
+        c = fmaf(a0, a0, c); c = fmaf(a1, a1, c); c = fmaf(a2, a2, c); c = fmaf(a3, a3, c);
+    }
+    double cs = wave_sum_d(pvalid ? (double)c : 0.0);
+    if (lane == 0) s_red[wv] = cs;
+    __syncthreads();
+    if (tid == 0) cpart[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ======================================================================================================================
+// deterministic EMA statistics for the MFMA / GENERIC routes: counting sort by code + segmented sums in sorted order
+// ======================================================================================================================
+// One wave per sort block of VQ_SB pixels: rank of every pixel among the pixels of its code inside the block (in pixel
+// order) and the block's histogram.  Peers of a lane = lanes of the round with the same code (one ballot per code bit).
+__global__ void __launch_bounds__(64) k_vq_rank(const int64_t* __restrict__ ids, int id_base, int* __restrict__ lrank,
+                                                int* __restrict__ hist, long Npix, int K, int nbits) {
+    extern __shared__ int s_cnt[];
+    const int lane = threadIdx.x;
+    for (int k = lane; k < K; k += 64) s_cnt[k] = 0;
+    __syncthreads();
+    const long p0 = (long)blockIdx.x * VQ_SB;
+    const long pend = p0 + VQ_SB < Npix ? p0 + VQ_SB : Npix;
+    for (long pb = p0; pb < pend; pb += 64) {
+        const long p = pb + lane;
+        const bool valid = p < pend;
+        int code = valid ? (int)(ids[p] - id_base) : 0;
+        code = code < 0 ? 0 : (code >= K ? K - 1 : code);
+        unsigned long long peers = __ballot(valid);
+        for (int b = 0; b < nbits; ++b) {
+            const bool bit = (code >> b) & 1;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const int rin = __popcll(peers & ((1ull << lane) - 1ull));
+        const int basec = s_cnt[code];
+        __syncthreads();
+        if (valid && rin == 0) s_cnt[code] = basec + __popcll(peers);
+        __syncthreads();
+        if (valid) lrank[p] = basec + rin;
+    }
+    for (int k = lane; k < K; k += 64) hist[(long)blockIdx.x * K + k] = s_cnt[k];
+}
+
+// per code: exclusive scan of the block histograms over the sort blocks (in place) and the code's total
+__global__ void __launch_bounds__(256) k_vq_hscan(int* __restrict__ hist, int* __restrict__ total, int nsb, int K) {
+    __shared__ int s_sum[4][64];
+    const int t = threadIdx.x, kk = blockIdx.x * 64 + (t & 63), sl = t >> 6;
+    const int lo = (int)((long)nsb * sl / 4), hi = (int)((long)nsb * (sl + 1) / 4);
+    int sum = 0;
+    if (kk < K)
+        for (int sb = lo; sb < hi; ++sb) sum += hist[(long)sb * K + kk];
+    s_sum[sl][t & 63] = sum;
+    __syncthreads();
+    int run = 0, tot = 0;
+    for (int s = 0; s < 4; ++s) { const int v = s_sum[s][t & 63]; if (s < sl) run += v; tot += v; }
+    if (kk < K) {
+        for (int sb = lo; sb < hi; ++sb) { const long i = (long)sb * K + kk; const int v = hist[i]; hist[i] = run; run += v; }
+        if (sl == 0) total[kk] = tot;
     }
 }
 
-static int vq_fwd_gemm(const float* x, const float* embed, int64_t* ids, int id_base, float* q, float* commit, double* stats,
-                       void* ws, long Npix, int D, int K, hipStream_t st) {
-    const size_t cp_bytes = (((size_t)(Npix + 3) / 4) * sizeof(double) + 255) / 256 * 256;
-    double* cpart = (double*)ws;
-    float* accum = (float*)((char*)ws + cp_bytes);                       // [K] counts, [K][D] sums, then [K] code norms
-    float* enorm = accum + (size_t)K * (D + 1);
-    float* scores = (float*)((char*)accum + (((size_t)K * (D + 1) + K) * sizeof(float) + 255) / 256 * 256);
-    if (stats && hipMemsetAsync(accum, 0, (size_t)K * (D + 1) * sizeof(float), st) != hipSuccess) {
-        vqw_set_error("vqw_vq_fwd: memset failed");
-        return VQW_ERR_HIP;
+// base[k] = first sorted position of code k; cstart[k] = first segment-sum work item of code k; counts -> stats[0..K)
+__global__ void __launch_bounds__(1024) k_vq_bases(const int* __restrict__ total, int* __restrict__ base, int* __restrict__ cstart,
+                                                   double* __restrict__ stats, int K) {
+    __shared__ int s_a[1024], s_b[1024];
+    const int t = threadIdx.x, it = (K + 1023) / 1024;
+    int la = 0, lb = 0;
+    for (int i = 0; i < it; ++i) { const int k = t * it + i; if (k < K) { la += total[k]; lb += (total[k] + VQ_CH - 1) / VQ_CH; } }
+    s_a[t] = la; s_b[t] = lb;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {      // Hillis-Steele inclusive scan
+        const int va = t >= o ? s_a[t - o] : 0, vb = t >= o ? s_b[t - o] : 0;
+        __syncthreads();
+        s_a[t] += va; s_b[t] += vb;
+        __syncthreads();
     }
-    k_vq_enorm<<<ceil_div(K, 256), 256, 0, st>>>(embed, enorm, D, K);
-    const long PC = vq_gemm_chunk(Npix);
-    for (long p0 = 0; p0 < Npix; p0 += PC) {
-        const long pn = Npix - p0 < PC ? Npix - p0 : PC;
-        // scores[p][k] = x_p . e_k  == a 1x1 convolution with Cout = K over the pixel chunk (fp32 MFMA implicit GEMM)
-        ConvIn in{x + p0 * D, nullptr, D, 0, 0};
-        int rc = conv_mfma_fwd(in, embed, nullptr, scores, 1, 1, (int)pn, K, 1, 1, 0, st);
-        if (rc) return rc;
-        k_vq_select<<<(unsigned)((pn + 3) / 4), 256, 0, st>>>(scores, x, embed, enorm, ids, q, cpart, stats ? accum : nullptr, p0, pn, D,
-                                                              K, id_base);
+    int ra = s_a[t] - la, rb = s_b[t] - lb;
+    for (int i = 0; i < it; ++i) {
+        const int k = t * it + i;
+        if (k < K) {
+            base[k] = ra; cstart[k] = rb;
+            stats[k] = (double)total[k];
+            ra += total[k]; rb += (total[k] + VQ_CH - 1) / VQ_CH;
+        }
     }
-    VQW_LAUNCH_CHECK("vqw_vq_fwd(gemm)");
-    k_vq_gemm_finalize<<<stats ? 256 : 1, 256, 0, st>>>(cpart, (Npix + 3) / 4, accum, commit, stats, D, K, 1.0 / ((double)Npix * D));
-    VQW_LAUNCH_CHECK("vqw_vq_gemm_finalize");
+    if (t == 1023) { base[K] = s_a[1023]; cstart[K] = s_b[1023]; }
+}
+
+__global__ void k_vq_scatter(const int64_t* __restrict__ ids, int id_base, const int* __restrict__ lrank,
+                             const int* __restrict__ hist, const int* __restrict__ base, int* __restrict__ perm, long Npix, int K) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < Npix; p += stride) {
+        int code = (int)(ids[p] - id_base);
+        code = code < 0 ? 0 : (code >= K ? K - 1 : code);
+        perm[base[code] + hist[(p / VQ_SB) * K + code] + lrank[p]] = (int)p;
+    }
+}
+
+// One wave per work item: the sum, in sorted order, of up to VQ_CH member rows of one code.  V4: D % 4 == 0.
+template <bool V4>
+__global__ void __launch_bounds__(256) k_vq_segsum(const float* __restrict__ x, const int* __restrict__ perm,
+                                                   const int* __restrict__ total, const int* __restrict__ base,
+                                                   const int* __restrict__ cstart, float* __restrict__ partial, int D, int K) {
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= cstart[K]) return;
+    int lo = 0, hi = K;                       // largest k with cstart[k] <= w and a non-empty range
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cstart[mid] <= w) lo = mid; else hi = mid; }
+    const int k = lo, j = w - cstart[k];
+    const int r0 = base[k] + j * VQ_CH;
+    const int cnt = min(VQ_CH, base[k] + total[k] - r0);
+    constexpr int NA = V4 ? VQ_MAX_D / 256 : VQ_MAX_D / 64;
+    float4 a4[V4 ? NA : 1];
+    float a1[V4 ? 1 : NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { if constexpr (V4) a4[i] = float4{0.f, 0.f, 0.f, 0.f}; else a1[i] = 0.f; }
+    for (int rb = 0; rb < cnt; rb += 64) {
+        const int mine = rb + lane < cnt ? perm[r0 + rb + lane] : 0;
+        const int nr = min(64, cnt - rb);
+        int r = 0;
+        for (; r + 4 <= nr; r += 4) {          // four rows in flight, added in sorted order
+            const float* row[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) row[u] = x + (size_t)__shfl(mine, r + u, 64) * D;
+            if constexpr (V4) {
+                float4 v[4][NA];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const int d = 4 * (lane + 64 * i);
+                        v[u][i] = d < D ? *(const float4*)(row[u] + d) : float4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) { a4[i].x += v[u][i].x; a4[i].y += v[u][i].y; a4[i].z += v[u][i].z; a4[i].w += v[u][i].w; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) { const int d = lane + 64 * i; if (d < D) a1[i] += row[u][d]; }
+            }
+        }
+        for (; r < nr; ++r) {
+            const float* row = x + (size_t)__shfl(mine, r, 64) * D;
+            if constexpr (V4) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int d = 4 * (lane + 64 * i);
+                    if (d < D) { const float4 v = *(const float4*)(row + d); a4[i].x += v.x; a4[i].y += v.y; a4[i].z += v.z; a4[i].w += v.w; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) { const int d = lane + 64 * i; if (d < D) a1[i] += row[d]; }
+            }
+        }
+    }
+    float* o = partial + (size_t)w * D;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        if constexpr (V4) { const int d = 4 * (lane + 64 * i); if (d < D) *(float4*)(o + d) = a4[i]; }
+        else { const int d = lane + 64 * i; if (d < D) o[d] = a1[i]; }
+    }
+}
+
+// One workgroup per code: its work-item partials summed in order (16 waves take contiguous sixteenths, folded in wave
+// order) -> stats[K + d*K + k] (the reference's embed_sum layout, as double)
+__global__ void __launch_bounds__(1024) k_vq_segfinal(const float* __restrict__ partial, const int* __restrict__ cstart,
+                                                      double* __restrict__ stats, int D, int K) {
+    extern __shared__ float s_p[];           // [16][D]
+    const int k = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c0 = cstart[k], np = cstart[k + 1] - c0;
+    const int lo = (int)((long)np * wv / 16), hi = (int)((long)np * (wv + 1) / 16);
+    for (int d = lane; d < D; d += 64) {
+        float a = 0.f;
+#pragma unroll 4
+        for (int j = lo; j < hi; ++j) a += partial[(size_t)(c0 + j) * D + d];
+        s_p[wv * D + d] = a;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 1024) {
+        float a = s_p[d];
+        for (int w = 1; w < 16; ++w) a += s_p[w * D + d];
+        stats[K + (size_t)d * K + k] = (double)a;
+    }
+}
+
+static int vq_sorted_stats(const float* x, const int64_t* ids, int id_base, double* stats, const VqWs& w, long Npix, int D, int K,
+                           hipStream_t st) {
+    const int nsb = (int)((Npix + VQ_SB - 1) / VQ_SB);
+    int nbits = 0;
+    while ((1 << nbits) < K) ++nbits;
+    k_vq_rank<<<nsb, 64, (size_t)K * sizeof(int), st>>>(ids, id_base, w.lrank, w.hist, Npix, K, nbits);
+    k_vq_hscan<<<ceil_div(K, 64), 256, 0, st>>>(w.hist, w.total, nsb, K);
+    k_vq_bases<<<1, 1024, 0, st>>>(w.total, w.base, w.cstart, stats, K);
+    k_vq_scatter<<<stream_grid(Npix, 256), 256, 0, st>>>(ids, id_base, w.lrank, w.hist, w.base, w.perm, Npix, K);
+    const long tmax = (Npix + VQ_CH - 1) / VQ_CH + K;
+    if (D % 4 == 0) k_vq_segsum<true><<<(unsigned)((tmax + 3) / 4), 256, 0, st>>>(x, w.perm, w.total, w.base, w.cstart, w.partial, D, K);
+    else k_vq_segsum<false><<<(unsigned)((tmax + 3) / 4), 256, 0, st>>>(x, w.perm, w.total, w.base, w.cstart, w.partial, D, K);
+    k_vq_segfinal<<<K, 1024, (size_t)16 * D * sizeof(float), st>>>(w.partial, w.cstart, stats, D, K);
+    VQW_LAUNCH_CHECK("vqw_vq_fwd(sorted statistics)");
     return VQW_OK;
 }
 
-template <int DT>
-static int launch_vq(const float* x, const float* embed, int64_t* ids, float* q, double* cpart, float* spart, float* sglob,
-                     long Npix, int D, int K, int want, int id_base, bool lds_cb, bool lds_st, int nb, size_t lds_bytes,
-                     hipStream_t st) {
-    if (lds_cb && lds_st) k_vq_fwd<DT, true, true><<<nb, VQ_BLOCK, lds_bytes, st>>>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base);
-    else if (lds_cb) k_vq_fwd<DT, true, false><<<nb, VQ_BLOCK, lds_bytes, st>>>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base);
-    else k_vq_fwd<DT, false, false><<<nb, VQ_BLOCK, lds_bytes, st>>>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base);
-    return 0;
+template <int DT, bool FULL>
+static int launch_vq_mfma(const float* x, const float* embed, const float* enorm, int64_t* ids, float* q, double* cpart, long Npix,
+                          int D, int K, int id_base, hipStream_t st) {
+    constexpr int NBLK = 256 / DT, TR = 32 * NBLK, LS = DT + 4, STAGE = TR * LS + TR;
+    const size_t lds = 2 * (size_t)STAGE * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)k_vq_mfma<DT, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            vqw_set_error("vqw_vq_fwd: cannot reserve %zu bytes of LDS", lds);
+            return VQW_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    // 32-bit buffer offsets: pixel chunks whose rows stay below 4 GiB (a multiple of the 128-pixel workgroup tile)
+    const long pch = (long)((0xfffffe00ull / ((unsigned long long)D * 4ull)) / 128ull) * 128;
+    for (long p0 = 0; p0 < Npix; p0 += pch) {
+        const long pn = Npix - p0 < pch ? Npix - p0 : pch;
+        k_vq_mfma<DT, FULL><<<(unsigned)((pn + 127) / 128), 256, lds, st>>>(x + p0 * D, embed, enorm, ids + p0, q + p0 * D, cpart + p0 / 128,
+                                                                      (unsigned)pn, D, K, id_base);
+    }
+    return VQW_OK;
+}
+
+template <int DT, bool LDS_CB>
+static void launch_vq_small(int nt, int nb, size_t lds, hipStream_t st, const float* x, const float* embed, int64_t* ids, float* q,
+                            double* cpart, float* spart, long Npix, int D, int K, int want, int id_base) {
+    if (DT > 0 && nt == 1) k_vq_fwd<DT, LDS_CB, (DT > 0 ? 1 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
+    else if (DT > 0 && nt == 2) k_vq_fwd<DT, LDS_CB, (DT > 0 ? 2 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
+    else if (DT > 0 && DT <= 32 && nt == 4) k_vq_fwd<DT, LDS_CB, (DT > 0 && DT <= 32 ? 4 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
+    else if (DT == 16 && nt == 8) k_vq_fwd<DT, LDS_CB, (DT == 16 ? 8 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
+    else k_vq_fwd<DT, LDS_CB, 0><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
 }
 
 extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int id_base, float* q, float* commit, double* stats,
@@ -331,32 +634,53 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
     VQW_CHECK(x && embed && ids && q && commit && ws && Npix > 0 && D > 0 && K > 0, "vqw_vq_fwd: bad arguments");
     VQW_CHECK(ws_bytes >= vqw_vq_ws_bytes(Npix, D, K), "vqw_vq_fwd: workspace too small");
     VQW_CHECK(K <= 8192, "vqw_vq_fwd: dict_size %d exceeds the supported 8192", K);
+    VQW_CHECK(D <= VQ_MAX_D, "vqw_vq_fwd: emb_dim %d exceeds the supported %d", D, VQ_MAX_D);
+    VQW_CHECK(Npix < (1L << 31), "vqw_vq_fwd: %ld pixels per call exceed the supported 2^31", Npix);
     hipStream_t st = (hipStream_t)stream;
-    VQW_CHECK((((uintptr_t)x | (uintptr_t)q) & 15) == 0, "vqw_vq_fwd: x and q must be 16-byte aligned");
-    if (vq_use_gemm(D, K)) return vq_fwd_gemm(x, embed, ids, id_base, q, commit, stats, ws, Npix, D, K, st);
+    VQW_CHECK((((uintptr_t)x | (uintptr_t)q | (uintptr_t)embed) & 15) == 0, "vqw_vq_fwd: x, q and embed must be 16-byte aligned");
+    const int plan = vq_plan(D, K);
+    const VqWs w = vq_carve(ws, Npix, D, K);
+    const int want = stats != nullptr;
+    const double inv_numel = 1.0 / ((double)Npix * D);
+    if (plan == VQ_PLAN_MFMA) {
+        const int dt = vq_mfma_dt(D);
+        const int tr = 32 * (256 / dt);
+        const int kpad = (K + tr - 1) / tr * tr;
+        k_vq_enorm<<<ceil_div(kpad, 256), 256, 0, st>>>(embed, w.enorm, D, K, kpad);
+        int rc;
+#define VQ_MFMA_CASE(DT_) (D == DT_ ? launch_vq_mfma<DT_, true>(x, embed, w.enorm, ids, q, w.cpart, Npix, D, K, id_base, st) \
+                                    : launch_vq_mfma<DT_, false>(x, embed, w.enorm, ids, q, w.cpart, Npix, D, K, id_base, st))
+        if (dt == 32) rc = VQ_MFMA_CASE(32);
+        else if (dt == 64) rc = VQ_MFMA_CASE(64);
+        else if (dt == 128) rc = VQ_MFMA_CASE(128);
+        else rc = VQ_MFMA_CASE(256);
+#undef VQ_MFMA_CASE
+        if (rc) return rc;
+        VQW_LAUNCH_CHECK("vqw_vq_fwd(mfma)");
+        if (want) { rc = vq_sorted_stats(x, ids, id_base, stats, w, Npix, D, K, st); if (rc) return rc; }
+        k_vq_finalize<<<1, 256, 0, st>>>(w.cpart, nullptr, vq_ncpart(Npix, plan), 0, commit, nullptr, 0, inv_numel);
+        VQW_LAUNCH_CHECK("vqw_vq_finalize");
+        return VQW_OK;
+    }
     const int nb = vq_blocks(Npix);
     const int KD1 = K * (D + 1);
-    double* cpart = (double*)ws;
-    float* spart = (float*)((char*)ws + (((size_t)nb * sizeof(double) + 255) / 256) * 256);
-    VQW_CHECK((((uintptr_t)x | (uintptr_t)q) & 15) == 0, "vqw_vq_fwd: x and q must be 16-byte aligned");
-    bool lds_cb = vq_lds_codebook(D, K);
-    bool lds_st = vq_lds_stats(D, K);
-    size_t lds_floats = (size_t)K + (lds_cb ? (size_t)K * D : 0) + (lds_st ? (size_t)(VQ_BLOCK / 64) * KD1 : 0);
-    int want = stats != nullptr;
-    float* sglob = spart;  // global accumulator (row 0) when not privatised
-    if (want && !lds_st) {
-        hipError_t e = hipMemsetAsync(sglob, 0, (size_t)KD1 * sizeof(float), st);
-        if (e != hipSuccess) { vqw_set_error("vqw_vq_fwd: memset failed"); return VQW_ERR_HIP; }
+    const bool lds_cb = vq_lds_codebook(D, K);
+    const int nt = plan == VQ_PLAN_SMALL_MFMA_STATS ? vq_small_nt(D, K) : 0;
+    size_t lds_floats = (size_t)((K + 3) & ~3) + (lds_cb ? (size_t)K * D : 0);
+    if (nt > 0) {
+        const size_t tiles = (size_t)(VQ_BLOCK / 64) * 64 * (D + 4), slabs = (size_t)(VQ_BLOCK / 64) * KD1;
+        lds_floats += tiles > slabs ? tiles : slabs;
     }
-    size_t lb = lds_floats * sizeof(float);
-    if (D == 16) launch_vq<16>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
-    else if (D == 32) launch_vq<32>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
-    else if (D == 64) launch_vq<64>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
-    else launch_vq<0>(x, embed, ids, q, cpart, spart, sglob, Npix, D, K, want, id_base, lds_cb, lds_st, nb, lb, st);
+    const size_t lb = lds_floats * sizeof(float);
+    if (D == 16 && lds_cb) launch_vq_small<16, true>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
+    else if (D == 32 && lds_cb) launch_vq_small<32, true>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
+    else if (D == 64 && lds_cb) launch_vq_small<64, true>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
+    else if (lds_cb) launch_vq_small<0, true>(0, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
+    else launch_vq_small<0, false>(0, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
     VQW_LAUNCH_CHECK("vqw_vq_fwd");
-    k_vq_finalize<<<imax(1, imin(256, ceil_div(KD1, 16))), 256, 0, st>>>(cpart, spart, nb, lds_st ? nb : 1, commit,
-                                                                         want ? stats : nullptr, KD1,
-                                                                         1.0 / ((double)Npix * D));
+    if (want && nt == 0) { int rc = vq_sorted_stats(x, ids, id_base, stats, w, Npix, D, K, st); if (rc) return rc; }
+    k_vq_finalize<<<(want && nt > 0) ? imax(1, imin(256, ceil_div(KD1, 16))) : 1, 256, 0, st>>>(
+        w.cpart, w.spart, nb, nb, commit, (want && nt > 0) ? stats : nullptr, KD1, inv_numel);
     VQW_LAUNCH_CHECK("vqw_vq_finalize");
     return VQW_OK;
 }

@@ -73,6 +73,7 @@ SIGNATURES = {
     "vqw_weighted_sum": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "vqw_weighted_sum_host": (c_i, [c_p, c_p, c_i, c_p, c_p]),
     "vqw_vq_ws_bytes": (c_sz, [c_l, c_i, c_i]),
+    "vqw_vq_plan": (c_i, [c_i, c_i]),
     "vqw_vq_fwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_sz, c_l, c_i, c_i, c_p]),
     "vqw_vq_ema_update": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_i, c_p]),
     "vqw_vq_lookup": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p]),
@@ -117,7 +118,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def load():

@@ -453,6 +453,81 @@ def test_vq_large_codebook_vs_oracle():
         assert_close(e, V["embed"], 2e-5, "embed")
 
 
+VQ_ROUTES = [        # (K, D, B, S, expected plan): 0 LDS + matrix-core statistics, 1 LDS + sorted, 2 fused MFMA, 3 generic
+    (10, 16, 3, 40, 0), (64, 32, 2, 24, 0), (32, 64, 1, 30, 0), (128, 16, 2, 20, 0),
+    (180, 16, 2, 24, 1), (100, 32, 1, 20, 1),
+    (1024, 256, 1, 34, 2), (1024, 64, 2, 20, 2), (96, 40, 1, 23, 2), (3000, 12, 1, 18, 2), (160, 128, 1, 17, 2), (40, 200, 1, 13, 2),
+    (20, 20, 2, 12, 3), (50, 7, 1, 21, 3), (700, 30, 1, 16, 3),
+]
+
+
+@pytest.mark.parametrize("K,D,B,S,plan", VQ_ROUTES)
+def test_vq_routes_vs_oracle(K, D, B, S, plan):
+    """Every search / statistics route of vq.hip against the CPU oracle: ids bit-exact off ties, q / commit / gradient,
+    the three EMA buffers after the update; then the same call again must give the same bits (no float atomics)."""
+    from oracle import vqwnet_ref as O
+    from hipops import _lib
+    ops = _ops()
+    assert _lib.load().vqw_vq_plan(D, K) == plan
+    g = torch.Generator().manual_seed(K * 1000 + D)
+    embed = torch.randn(K, D, generator=g)
+    x = (torch.randn(B, D, S, S, generator=g) * 1.1).requires_grad_(True)
+    V = dict(embed=embed.clone(), cluster_size=torch.full((K,), 3.0), embed_avg=(embed * 3.0).t().contiguous())
+    q, commit, ids, gap = O.vq_forward(V, x, True, 0.9)
+    r = torch.randn(B, D, S, S, generator=g)
+    ((q * r).sum() + commit).backward()
+    outs = []
+    for rep in range(2):
+        dx = x.detach().to(DEV).requires_grad_(True)
+        e = embed.to(DEV).clone(); cs = torch.full((K,), 3.0, device=DEV); ea = (embed * 3.0).t().contiguous().to(DEV)
+        dq, dc, dids = ops.vq_quantize(dx, e, cs, ea, True, 0.9, 1e-5)
+        ((dq * r.to(DEV)).sum() + dc).backward()
+        outs.append((dq.detach().clone(), dc.detach().clone(), dids.clone(), e, cs, ea, dx.grad.clone()))
+    dq, dc, dids, e, cs, ea, gx = outs[0]
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), "VQ is not bit-deterministic"
+    gp = gap.numpy()
+    clear = gp > 1e-4 * (1 + np.abs(gp))
+    assert clear.mean() > 0.97
+    assert np.array_equal(dids.cpu().numpy()[clear], ids.numpy()[clear])
+    assert_close(dc, commit, 1e-5, "commit")
+    assert_close(gx, x.grad, 1e-5, "gx")
+    assert abs(float(cs.sum()) - float(V["cluster_size"].sum())) < 1e-4 * float(V["cluster_size"].sum())
+    if bool((dids.cpu() == ids).all()):
+        assert_close(dq, q.detach(), 1e-6, "q")
+        assert_close(cs, V["cluster_size"], 1e-6, "cluster_size")
+        assert_close(ea, V["embed_avg"], 2e-5, "embed_avg")
+        assert_close(e, V["embed"], 2e-5, "embed")
+
+
+@pytest.mark.parametrize("K,D", [(1024, 256), (10, 16), (180, 16), (50, 7)])
+def test_vq_statistics_skewed_and_exact(K, D):
+    """EMA statistics on integer-valued inputs are exact whatever the summation order: one code owning (almost) every
+    pixel (the cold-start case: thousands of segment partials of one code), empty codes, a ragged pixel count."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    embed = torch.randint(-3, 4, (K, D), generator=g).float() * 8.0
+    embed[0] = 0.0
+    n = 3 * 61 * 61
+    x = torch.randint(-2, 3, (3, D, 61, 61), generator=g).float()         # every pixel is nearest to code 0 ...
+    pick = torch.randperm(n, generator=g)[:97]
+    xf = x.permute(0, 2, 3, 1).reshape(n, D)
+    xf[pick] = embed[torch.randint(1, K, (97,), generator=g)]           # ... except 97 that sit exactly on other codes
+    x = xf.reshape(3, 61, 61, D).permute(0, 3, 1, 2).contiguous()
+    e = embed.to(DEV).clone(); cs = torch.zeros(K, device=DEV); ea = torch.zeros(D, K, device=DEV)
+    q, commit, ids = ops.vq_quantize(x.to(DEV), e, cs, ea, True, 0.0, 1e-5)       # momentum 0: buffers = raw statistics
+    d2 = ((xf[:, None, :] - embed[None, :, :]) ** 2).sum(-1) if K * n * D < 5e8 else None
+    ids_ref = d2.argmin(1) if d2 is not None else None
+    idf = ids.reshape(-1).cpu()
+    if ids_ref is not None:
+        assert torch.equal(idf, ids_ref)
+    counts = torch.bincount(idf, minlength=K).float()
+    sums = torch.zeros(K, D).index_add_(0, idf, xf)
+    assert torch.equal(cs.cpu(), counts)
+    assert torch.equal(ea.cpu(), sums.t())
+    assert int(counts[0]) >= n - 97 and int((counts == 0).sum()) >= K - 98 - 1
+
+
 def test_vq_conservation_and_ties():
     """Properties: sum of counts == N pixels; all-equal scores resolve to the lowest index; ids in range."""
     ops = _ops()

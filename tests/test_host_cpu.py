@@ -23,7 +23,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvqwnet_hip.so does not export " + name
     L = _lib.load()
-    assert L.vqw_abi_version() == 2
+    assert L.vqw_abi_version() == _lib.ABI_VERSION
     # argument validation happens before any device work: callable without a GPU
     assert L.vqw_add(None, None, None, 0, 0, None) != 0
     assert b"vqw_add" in L.vqw_last_error()
