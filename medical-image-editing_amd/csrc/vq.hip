@@ -22,10 +22,13 @@
 #include "../../include/vqwnet_hip.h"
 
 #define VQ_BLOCK 256
+#ifndef VQ_EXP
+#define VQ_EXP 0       // timing-only A/B builds (tools/vq_ab.sh): 1 = no arg-max epilogue, 2 = no stage refill / barrier, 4 = one MFMA chain per two blocks
+#endif
 #define VQ_LDS_FLOATS 15360  // 60 KiB of LDS for codebook + norms
 #define VQ_MAX_D 1024
 
-static inline int vq_blocks(long Npix) { return (int)imin(2048, ceil_div(Npix, VQ_BLOCK)); }
+static inline int vq_blocks(long Npix) { return (int)imin(1024, ceil_div(Npix, VQ_BLOCK)); }   // one resident round (4 per CU)
 static inline bool vq_lds_codebook(int D, int K) { return (long)K * D + K <= VQ_LDS_FLOATS; }
 static inline int vq_pow2_ge(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 // matrix-core statistics in the small kernel: (D/16 + 1) x NT accumulator tiles of 16 x 16, NT = pow2 >= ceil(K/16)
@@ -54,6 +57,7 @@ struct VqWs {
     double* cpart;      // commit partials, one per workgroup
     float* enorm;       // |e_k|^2 (+inf padding) for the MFMA route
     float* spart;       // per-workgroup statistics rows of the SMALL route
+    double* spart2;     // stage-one column sums (32 rows each)
     int *hist, *total, *base, *cstart, *lrank, *perm;
     float* partial;
     size_t bytes;
@@ -68,6 +72,8 @@ static VqWs vq_carve(void* ws, long Npix, int D, int K) {
     w.enorm = (float*)(p + o); o += al256(((size_t)K + 512) * sizeof(float));
     w.spart = (float*)(p + o);
     if (plan == VQ_PLAN_SMALL_MFMA_STATS) o += al256((size_t)vq_blocks(Npix) * K * (D + 1) * sizeof(float));
+    w.spart2 = (double*)(p + o);
+    if (plan == VQ_PLAN_SMALL_MFMA_STATS) o += al256((size_t)ceil_div(vq_blocks(Npix), 32) * K * (D + 1) * sizeof(double));
     const long nsb = (Npix + VQ_SB - 1) / VQ_SB;
     const long tmax = (Npix + VQ_CH - 1) / VQ_CH + K;
     w.hist = (int*)(p + o);
@@ -123,6 +129,12 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
     double csum = 0.0;
     // wave-uniform trip count (the statistics tile is a wave-wide operation); lanes past the end compute on the last pixel
     // and contribute nothing
+    float4 nxt[DT > 0 ? DT / 4 : 1];         // the next iteration's row is in flight while this one is scored
+    if (DT > 0) {
+        const long p0 = (long)blockIdx.x * VQ_BLOCK + t < Npix ? (long)blockIdx.x * VQ_BLOCK + t : Npix - 1;
+#pragma unroll
+        for (int d4 = 0; d4 < DT / 4; ++d4) nxt[d4] = ((const float4*)(x + p0 * D))[d4];
+    }
     for (long base = (long)blockIdx.x * VQ_BLOCK; base < Npix; base += (long)gridDim.x * VQ_BLOCK) {
         const bool active = base + t < Npix;
         const long p = active ? base + t : Npix - 1;
@@ -132,8 +144,14 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
         if (DT > 0) {
 #pragma unroll
             for (int d4 = 0; d4 < DT / 4; ++d4) {
-                float4 v = ((const float4*)xr)[d4];
+                const float4 v = nxt[d4];
                 xv[4 * d4] = v.x; xv[4 * d4 + 1] = v.y; xv[4 * d4 + 2] = v.z; xv[4 * d4 + 3] = v.w;
+            }
+            const long nb_ = base + (long)gridDim.x * VQ_BLOCK;
+            if (nb_ < Npix) {
+                const long pn = nb_ + t < Npix ? nb_ + t : Npix - 1;
+#pragma unroll
+                for (int d4 = 0; d4 < DT / 4; ++d4) nxt[d4] = ((const float4*)(x + pn * D))[d4];
             }
 #pragma unroll
             for (int d = 0; d < DT; ++d) x2 = fmaf(xv[d], xv[d], x2);
@@ -236,51 +254,47 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
     }
 }
 
-// commit = sum(commit_part) / numel; stats (SMALL route) = column sums of the per-workgroup rows, in double, fixed order
-__global__ void k_vq_finalize(const double* __restrict__ commit_part, const float* __restrict__ stat_part, long nblocks,
-                              int nstat_rows, float* __restrict__ commit, double* __restrict__ stats, int KD1, double inv_numel) {
+// commit = sum(commit_part) / numel
+__global__ void k_vq_finalize(const double* __restrict__ commit_part, long nblocks, float* __restrict__ commit, double inv_numel) {
     __shared__ double s_red[4];
     const int t = threadIdx.x;
-    if (blockIdx.x == 0) {
+    double a = 0.0;
+    for (long i = t; i < nblocks; i += blockDim.x) a += commit_part[i];
+    a = wave_sum_d(a);
+    if ((t & 63) == 0) s_red[t >> 6] = a;
+    __syncthreads();
+    if (t == 0) commit[0] = (float)((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_numel);
+}
+// stats (SMALL route) = column sums of the per-workgroup rows, in double, fixed order, two stages: 32 rows per
+// workgroup (a thread per column, coalesced), then the <= 32 stage-one rows
+__global__ void __launch_bounds__(256) k_vq_stat_rows(const float* __restrict__ stat_part, int nrows, double* __restrict__ part2, int KD1) {
+    const int r0 = blockIdx.x * 32, r1 = min(r0 + 32, nrows);
+    for (int i = threadIdx.x; i < KD1; i += 256) {
         double a = 0.0;
-        for (long i = t; i < nblocks; i += blockDim.x) a += commit_part[i];
-        a = wave_sum_d(a);
-        if ((t & 63) == 0) s_red[t >> 6] = a;
-        __syncthreads();
-        if (t == 0) commit[0] = (float)((s_red[0] + s_red[1] + s_red[2] + s_red[3]) * inv_numel);
+        for (int r = r0; r < r1; ++r) a += (double)stat_part[(long)r * KD1 + i];
+        part2[(long)blockIdx.x * KD1 + i] = a;
     }
-    if (stats) {      // 16 columns x 16 row groups per workgroup
-        __shared__ double sm[16][17];
-        const int cx = t & 15, g = t >> 4;
-        for (int base = blockIdx.x * 16; base < KD1; base += gridDim.x * 16) {
-            const int i = base + cx;
-            double a = 0.0;
-            if (i < KD1)
-                for (int b = g; b < nstat_rows; b += 16) a += (double)stat_part[(long)b * KD1 + i];
-            sm[g][cx] = a;
-            __syncthreads();
-            if (g == 0 && i < KD1) {
-                double s2 = 0.0;
-                for (int k = 0; k < 16; ++k) s2 += sm[k][cx];
-                stats[i] = s2;
-            }
-            __syncthreads();
-        }
-    }
+}
+__global__ void __launch_bounds__(256) k_vq_stat_final(const double* __restrict__ part2, int nrows2, double* __restrict__ stats, int KD1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= KD1) return;
+    double a = 0.0;
+    for (int r = 0; r < nrows2; ++r) a += part2[(long)r * KD1 + i];
+    stats[i] = a;
 }
 
 // ======================================================================================================================
 // MFMA route: fused score GEMM + running arg-max
 // ======================================================================================================================
-__global__ void k_vq_enorm(const float* __restrict__ embed, float* __restrict__ enorm, int D, int K, int Kpad) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per code: |e_k|^2 (fixed butterfly order); padding rows get +inf and can never win: (2*0 - inf) - |x|^2 = -inf
+__global__ void __launch_bounds__(256) k_vq_enorm(const float* __restrict__ embed, float* __restrict__ enorm, int D, int K, int Kpad) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= Kpad) return;
-    float n2 = INFINITY;            // padding rows can never win: (2*0 - inf) - |x|^2 = -inf
-    if (k < K) {
-        n2 = 0.f;
-        for (int d = 0; d < D; ++d) { float e = embed[(long)k * D + d]; n2 = fmaf(e, e, n2); }
-    }
-    enorm[k] = n2;
+    float n2 = 0.f;
+    if (k < K)
+        for (int d = lane; d < D; d += 64) { const float e = embed[(long)k * D + d]; n2 = fmaf(e, e, n2); }
+    n2 = wave_sum_f(n2);
+    if (lane == 0) enorm[k] = k < K ? n2 : INFINITY;
 }
 
 // One workgroup = 4 waves x 32 pixels.  A lane (n = lane % 32, h = lane / 32) keeps half of pixel n's row in DT/2
@@ -335,10 +349,10 @@ __global__ void __launch_bounds__(256, 2) k_vq_mfma(const float* __restrict__ x,
     float best = -INFINITY;
     int bi = 0;
     for (int s = 0; s < nstage; ++s) {
-        const float* buf = smem + (s & 1) * STAGE;
+        const float* buf = smem + ((VQ_EXP & 2) ? 0 : (s & 1)) * STAGE;
         float* nbuf = smem + ((s + 1) & 1) * STAGE;
         const bool more = s + 1 < nstage;
-        if (more) {
+        if (more && !(VQ_EXP & 2)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) pf[i] = buf_ld4(re, sel_u32(cvalid, goff0 + i * gstep + (unsigned)(s + 1) * stage_bytes, OOB));
         }
@@ -349,18 +363,29 @@ __global__ void __launch_bounds__(256, 2) k_vq_mfma(const float* __restrict__ x,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float* arow = buf + (b * 32 + n) * LS + 4 * h;
+            // two fragment register sets: the LDS read of group j+1 is issued before the four MFMAs of group j
+            float4 a0 = *(const float4*)arow, a1;
 #pragma unroll
-            for (int j = 0; j < DT / 8; ++j) {
-                const float4 a = *(const float4*)(arow + 8 * j);
-                acc = MFMA32(a.x, xr[4 * j], acc);
-                acc = MFMA32(a.y, xr[4 * j + 1], acc);
-                acc = MFMA32(a.z, xr[4 * j + 2], acc);
-                acc = MFMA32(a.w, xr[4 * j + 3], acc);
+            for (int j = 0; j < DT / 8; j += 2) {
+                a1 = *(const float4*)(arow + 8 * (j + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc = MFMA32(a0.x, xr[4 * j], acc);
+                acc = MFMA32(a0.y, xr[4 * j + 1], acc);
+                acc = MFMA32(a0.z, xr[4 * j + 2], acc);
+                acc = MFMA32(a0.w, xr[4 * j + 3], acc);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 2 < DT / 8) a0 = *(const float4*)(arow + 8 * (j + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                acc = MFMA32(a1.x, xr[4 * j + 4], acc);
+                acc = MFMA32(a1.y, xr[4 * j + 5], acc);
+                acc = MFMA32(a1.z, xr[4 * j + 6], acc);
+                acc = MFMA32(a1.w, xr[4 * j + 7], acc);
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float* en = buf + TR * LS + b * 32 + 4 * h;
             const int code0 = s * TR + b * 32 + 4 * h;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int g = 0; g < ((VQ_EXP & 1) ? 1 : 4); ++g) {
                 const float4 e4 = *(const float4*)(en + 8 * g);
                 const float s0 = (2.f * acc[4 * g] - e4.x) - x2, s1 = (2.f * acc[4 * g + 1] - e4.y) - x2;
                 const float s2 = (2.f * acc[4 * g + 2] - e4.z) - x2, s3 = (2.f * acc[4 * g + 3] - e4.w) - x2;
@@ -370,12 +395,12 @@ __global__ void __launch_bounds__(256, 2) k_vq_mfma(const float* __restrict__ x,
                 if (s3 > best) { best = s3; bi = code0 + 8 * g + 3; }
             }
         }
-        if (more) {
+        if (more && !(VQ_EXP & 2)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) *(float4*)(nbuf + loff0 + i * RSTEP * LS) = pf[i];
             if (tid < TR) nbuf[TR * LS + tid] = en_next;
         }
-        __syncthreads();
+        if (!(VQ_EXP & 2)) __syncthreads();
     }
     {   // the two halves of a pixel hold disjoint code rows: keep the larger score, ties to the lower code
         const float ob = __shfl_xor(best, 32, 64);
@@ -646,7 +671,7 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
         const int dt = vq_mfma_dt(D);
         const int tr = 32 * (256 / dt);
         const int kpad = (K + tr - 1) / tr * tr;
-        k_vq_enorm<<<ceil_div(kpad, 256), 256, 0, st>>>(embed, w.enorm, D, K, kpad);
+        k_vq_enorm<<<ceil_div(kpad, 4), 256, 0, st>>>(embed, w.enorm, D, K, kpad);
         int rc;
 #define VQ_MFMA_CASE(DT_) (D == DT_ ? launch_vq_mfma<DT_, true>(x, embed, w.enorm, ids, q, w.cpart, Npix, D, K, id_base, st) \
                                     : launch_vq_mfma<DT_, false>(x, embed, w.enorm, ids, q, w.cpart, Npix, D, K, id_base, st))
@@ -658,7 +683,7 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
         if (rc) return rc;
         VQW_LAUNCH_CHECK("vqw_vq_fwd(mfma)");
         if (want) { rc = vq_sorted_stats(x, ids, id_base, stats, w, Npix, D, K, st); if (rc) return rc; }
-        k_vq_finalize<<<1, 256, 0, st>>>(w.cpart, nullptr, vq_ncpart(Npix, plan), 0, commit, nullptr, 0, inv_numel);
+        k_vq_finalize<<<1, 256, 0, st>>>(w.cpart, vq_ncpart(Npix, plan), commit, inv_numel);
         VQW_LAUNCH_CHECK("vqw_vq_finalize");
         return VQW_OK;
     }
@@ -679,42 +704,66 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
     else launch_vq_small<0, false>(0, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
     VQW_LAUNCH_CHECK("vqw_vq_fwd");
     if (want && nt == 0) { int rc = vq_sorted_stats(x, ids, id_base, stats, w, Npix, D, K, st); if (rc) return rc; }
-    k_vq_finalize<<<(want && nt > 0) ? imax(1, imin(256, ceil_div(KD1, 16))) : 1, 256, 0, st>>>(
-        w.cpart, w.spart, nb, nb, commit, (want && nt > 0) ? stats : nullptr, KD1, inv_numel);
+    k_vq_finalize<<<1, 256, 0, st>>>(w.cpart, nb, commit, inv_numel);
+    if (want && nt > 0) {
+        const int nr2 = ceil_div(nb, 32);
+        k_vq_stat_rows<<<nr2, 256, 0, st>>>(w.spart, nb, w.spart2, KD1);
+        k_vq_stat_final<<<ceil_div(KD1, 256), 256, 0, st>>>(w.spart2, nr2, stats, KD1);
+    }
     VQW_LAUNCH_CHECK("vqw_vq_finalize");
     return VQW_OK;
 }
 
-// EMA (vq_module.py:132-136,195-196) + Laplace-smoothed renormalisation (:198-200); single small block.
-__global__ void k_vq_ema(const double* __restrict__ stats, float* __restrict__ embed, float* __restrict__ cs,
-                         float* __restrict__ ea, float m, float eps, float sum_scale, int D, int K) {
+// EMA (vq_module.py:132-136,195-196) + Laplace-smoothed renormalisation (:198-200).  One workgroup per 32 (d) x 32 (k)
+// tile of embed_avg; every workgroup derives n = sum_k cluster_size_new[k] itself from the OLD cluster sizes and the
+// counts (same order everywhere), k_vq_ema_cs then writes the new cluster sizes.
+__global__ void __launch_bounds__(256) k_vq_ema(const double* __restrict__ stats, float* __restrict__ embed, const float* __restrict__ cs,
+                                                float* __restrict__ ea, float m, float eps, float sum_scale, int D, int K) {
     __shared__ double s_red[4];
     __shared__ float s_n;
+    __shared__ float s_t[32][33];
     const int t = threadIdx.x;
     const float om = 1.f - m;
     double part = 0.0;
-    for (int k = t; k < K; k += blockDim.x) {
-        float c = cs[k] * m + om * (float)stats[k];
-        cs[k] = c;
-        part += (double)c;
-    }
-    for (int i = t; i < D * K; i += blockDim.x) ea[i] = ea[i] * m + om * ((float)stats[K + i] * sum_scale);
+    for (int k = t; k < K; k += 256) part += (double)(cs[k] * m + om * (float)stats[k]);
     part = wave_sum_d(part);
     if ((t & 63) == 0) s_red[t >> 6] = part;
     __syncthreads();
     if (t == 0) s_n = (float)(s_red[0] + s_red[1] + s_red[2] + s_red[3]);
     __syncthreads();
     const float n = s_n;
-    for (int i = t; i < D * K; i += blockDim.x) {
-        int k = i / D, d = i % D;
-        float csn = n * (cs[k] + eps) / (n + (float)K * eps);
-        embed[i] = ea[d * K + k] / csn;
+    const int tk = (K + 31) / 32;
+    const int d0 = (blockIdx.x / tk) * 32, k0 = (blockIdx.x % tk) * 32;
+    const int tx = t & 31, ty = t >> 5;              // 32 x 8 threads, 4 rows each
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int d = d0 + ty + 8 * r, k = k0 + tx;
+        if (d < D && k < K) {
+            const long i = (long)d * K + k;
+            const float a = ea[i] * m + om * ((float)stats[K + i] * sum_scale);
+            ea[i] = a;
+            const float c = cs[k] * m + om * (float)stats[k];
+            const float csn = n * (c + eps) / (n + (float)K * eps);
+            s_t[ty + 8 * r][tx] = a / csn;
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + ty + 8 * r, d = d0 + tx;
+        if (d < D && k < K) embed[(long)k * D + d] = s_t[tx][ty + 8 * r];
+    }
+}
+__global__ void k_vq_ema_cs(const double* __restrict__ stats, float* __restrict__ cs, float m, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) cs[k] = cs[k] * m + (1.f - m) * (float)stats[k];
 }
 extern "C" int vqw_vq_ema_update(const double* stats, float* embed, float* cluster_size, float* embed_avg, float momentum,
                                  float eps, float sum_scale, int D, int K, void* stream) {
     VQW_CHECK(stats && embed && cluster_size && embed_avg && D > 0 && K > 0, "vqw_vq_ema_update: bad arguments");
-    k_vq_ema<<<1, 256, 0, (hipStream_t)stream>>>(stats, embed, cluster_size, embed_avg, momentum, eps, sum_scale, D, K);
+    hipStream_t st = (hipStream_t)stream;
+    k_vq_ema<<<ceil_div(D, 32) * ceil_div(K, 32), 256, 0, st>>>(stats, embed, cluster_size, embed_avg, momentum, eps, sum_scale, D, K);
+    k_vq_ema_cs<<<ceil_div(K, 256), 256, 0, st>>>(stats, cluster_size, momentum, K);
     VQW_LAUNCH_CHECK("vqw_vq_ema_update");
     return VQW_OK;
 }
