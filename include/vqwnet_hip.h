@@ -58,7 +58,8 @@ int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* src1, int C1
  * relu=1 fuses nn.ReLU into the epilogue (blocks.py:75-77 mlp_shared).             */
 int vqw_pack_dgrad_weights(const float* w_ohwi, float* wt, int Cout, int Cin, int ksize, void* stream);
 /* conv -> InstanceNorm (blocks.py:45-49): the convolution's epilogue also leaves the norm's statistics as per-tile
- * partial sums part[N][parts][Cout][2] (sum, sum of squares; fp32 over one tile, the norm sums tiles in double), so
+ * partials part[N][parts][Cout][2] = (sum, M2 = sum (x - tile mean)^2) of one equal-sized tile each (fp32, merged pairwise
+ * inside the tile; the norm combines tiles in double: no fp32 value ever holds a sum of squares), so
  * the norm skips its reduction pass (vqw_inorm_fwd_parts).  ..._stats_parts() returns `parts` for a shape, 0 when
  * the shape is not served (the halo-tile and the implicit-GEMM kernel are; then use vqw_conv2d_fwd + vqw_inorm_fwd).
  * No ReLU epilogue.                                                                                              */
@@ -123,8 +124,9 @@ int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float* xb, const
  * [sum, sumsq] partial totals via (sum_out) for cross-rank reduction: see vqw_bn_* below.  */
 int vqw_bn_partial_stats(const float* x, double* sums /*[C][2]*/, void* ws, size_t ws_bytes,
                          int N, int HW, int C, void* stream);
-/* sums[C][2] from the per-tile partials part[rows = N * parts][C][2] of the producing convolution (vqw_conv2d_fwd_stats) */
-int vqw_bn_stats_from_parts(const float* part, double* sums /*[C][2]*/, int rows, int C, void* stream);
+/* sums[C][2] from the per-tile partials part[rows = N * parts][C][2] of the producing convolution (vqw_conv2d_fwd_stats):
+ * each partial is (sum, M2 = sum (x - tile mean)^2) of one tile of `tile_count` = N*HW / rows pixels */
+int vqw_bn_stats_from_parts(const float* part, double* sums /*[C][2]*/, int rows, int C, double tile_count, void* stream);
 int vqw_bn_finalize(const double* sums /*[C][2]*/, double count, float* mean_rstd /*[C][2]*/,
                     float* running_mean, float* running_var, float momentum, float eps,
                     int C, void* stream);

@@ -138,7 +138,7 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
 
 // Convolution that also leaves the InstanceNorm statistics of its output (per-tile partial sums from the epilogue of the
 // halo-tile kernel): the norm that follows (blocks.py:45-49: conv -> InstanceNorm -> ReLU) skips its own reduction pass.
-// ..._stats_parts() = partial (sum, sum of squares) pairs per (image, channel), 0 when the shape is not served.
+// ..._stats_parts() = partial (sum, M2 about the tile mean) pairs per (image, channel), 0 when the shape is not served.
 extern "C" int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H, int W, int Cout, int ksize, int dil) {
     ConvIn in{nullptr, nullptr, C0, C1, up0};
     if (g_conv_backend != 0 || N <= 0 || conv_stem_ok(in, Cout, ksize) || conv_head_ok(in, Cout, ksize) || !conv_mfma_fwd_ok(in, Cout, ksize)) return 0;

@@ -47,7 +47,7 @@ struct HaloArgs {
     int kt;                    // consecutive spatial tiles per workgroup
     int relu;
     unsigned nb0, nb1, nbw, nby;
-    float* stats;              // optional [N][tilesY*tilesX][Cout][2]: per-tile (sum, sum of squares) of the output
+    float* stats;              // optional [N][tilesY*tilesX][Cout][2]: per-tile (sum, M2 about the tile mean) of the output
 };
 
 template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC>
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     float* Hs = smem;                              // [2][HBUF]
     float* Ws = smem + 2 * HBUF;                   // [WPERSIST ? 1 : 2][WBUF]
     // InstanceNorm statistics of the output, fused: every wave leaves the column sums of its tile rows here, after the
-    // item's barrier BN threads fold the TH rows in a fixed order and write one (sum, sum of squares) pair per cout and
+    // item's barrier BN threads merge the TH rows in a fixed order and write one (sum, M2 about the tile mean) pair per cout and
     // tile; the norm's finalize sums the tiles of a plane in double.  Two buffers: a fold reads while the next tile's
     // rows may already be written (the fold of tile k and the row sums of tile k+1 are one barrier apart).
     float* Rs = smem + 2 * HBUF + (WPERSIST ? 1 : 2) * WBUF;      // [2][TH][BN][2]
@@ -280,9 +280,9 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         if (fold_t < 0) return;        // uniform
         if (tid < BN && co_base + tid < Cout) {
             const float* R = Rs + spar * (TH * BN * 2) + tid * 2;
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = R[0], s2 = R[1];          // rows of 32 pixels, merged in row order
 #pragma unroll
-            for (int r = 0; r < TH; ++r) { s1 += R[r * BN * 2]; s2 += R[r * BN * 2 + 1]; }
+            for (int r = 1; r < TH; ++r) stat_merge(s1, s2, (float)(32 * r), R[r * BN * 2], R[r * BN * 2 + 1], 32.f);
             float* o = a.stats + ((size_t)fold_t * Cout + co_base + tid) * 2;
             o[0] = s1;
             o[1] = s2;
@@ -413,26 +413,27 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
             if (a.stats) {             // uniform
                 float* R = Rs + spar * (TH * BN * 2);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float rv = (cty * TH + wr * TM + i) < H ? 1.f : 0.f;       // rows below the image do not count
+                for (int i = 0; i < TM; ++i) {       // H % TH == 0 whenever statistics are requested: every row counts
                     if constexpr (M16) {      // lane: cout = lane&15, pixels blk*16 + 4*(lane>>4) + r
-                        float s1 = 0.f, s2 = 0.f;
+                        float vals[8], s1, s2;
 #pragma unroll
                         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { const float v = done4[i][blk][r]; s1 += v; s2 = fmaf(v, v, s2); }
-                        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-                        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                        if (lane < 16) { R[((wr * TM + i) * BN + lane) * 2] = s1 * rv; R[((wr * TM + i) * BN + lane) * 2 + 1] = s2 * rv; }
+                            for (int r = 0; r < 4; ++r) vals[blk * 4 + r] = done4[i][blk][r];
+                        lane_stats<8>(vals, s1, s2);
+                        stat_merge_eq(s1, s2, __shfl_xor(s1, 16, 64), __shfl_xor(s2, 16, 64), 1.f / 16.f);
+                        stat_merge_eq(s1, s2, __shfl_xor(s1, 32, 64), __shfl_xor(s2, 32, 64), 1.f / 32.f);
+                        if (lane < 16) { R[((wr * TM + i) * BN + lane) * 2] = s1; R[((wr * TM + i) * BN + lane) * 2 + 1] = s2; }
                     } else {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {    // lane: cout = lane&31, 16 of the row's 32 pixels; the other half in lane^32
-                            float s1 = 0.f, s2 = 0.f;
+                            float vals[16], s1, s2;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) { const float v = done[i][j][r]; s1 += v; s2 = fmaf(v, v, s2); }
-                            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                            for (int r = 0; r < 16; ++r) vals[r] = done[i][j][r];
+                            lane_stats<16>(vals, s1, s2);
+                            stat_merge_eq(s1, s2, __shfl_xor(s1, 32, 64), __shfl_xor(s2, 32, 64), 1.f / 32.f);
                             const int col = (wc * TN + j) * 32 + (lane & 31);
-                            if (lane < 32) { R[((wr * TM + i) * BN + col) * 2] = s1 * rv; R[((wr * TM + i) * BN + col) * 2 + 1] = s2 * rv; }
+                            if (lane < 32) { R[((wr * TM + i) * BN + col) * 2] = s1; R[((wr * TM + i) * BN + col) * 2 + 1] = s2; }
                         }
                     }
                 }
@@ -510,7 +511,10 @@ static int halo_tile_rows(const ConvIn& in, int Cout) {
     if (Cin == 32 && in.C1 == 0 && Cout > 32) return 4;
     return 8;
 }
-int conv_halo_stat_tiles(const ConvIn& in, int H, int W, int Cout) { return ceil_div(H, halo_tile_rows(in, Cout)) * (W / 32); }
+int conv_halo_stat_tiles(const ConvIn& in, int H, int W, int Cout) {     // equal, full tiles only: the partials carry no count
+    const int th = halo_tile_rows(in, Cout);
+    return H % th == 0 ? (H / th) * (W / 32) : 0;
+}
 
 int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
                   hipStream_t st, float* stats) {

@@ -235,8 +235,8 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
         }
     }
 
-    // Optional: statistics of the output for the InstanceNorm that follows (see k_conv_halo): per-tile (sum, sum of
-    // squares) per cout, the wave rows folded through LDS in a fixed order.  The host only asks for it when H*W is a
+    // Optional: statistics of the output for the InstanceNorm that follows (see k_conv_halo): per-tile (sum, M2
+    // about the tile mean) per cout, the wave rows merged through LDS in a fixed order (mfma_util.h: stat_merge).  The host only asks for it when H*W is a
     // multiple of BM (a tile never straddles two images).
     if (stats) {           // uniform
         constexpr int WAVES_M = BM / WM;
@@ -247,20 +247,21 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
         for (int j = 0; j < TN; ++j) {
             const int co = co_base + wn0 + j * 32 + (lane & 31);
             const float bv = (bias && co < Cout) ? bias[co] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
+            float vals[TM * 16];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r] + bv; s1 += v; s2 = fmaf(v, v, s2); }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
+                for (int r = 0; r < 16; ++r) vals[i * 16 + r] = acc[i][j][r] + bv;
+            float s1, s2;                     // (sum, M2) of this lane's TM*16 rows, then of the wave's WM rows
+            lane_stats<TM * 16>(vals, s1, s2);
+            stat_merge_eq(s1, s2, __shfl_xor(s1, 32, 64), __shfl_xor(s2, 32, 64), 1.f / (2 * TM * 16));
             if (lane < 32) { R[(wave_m * BN + wn0 + j * 32 + lane) * 2] = s1; R[(wave_m * BN + wn0 + j * 32 + lane) * 2 + 1] = s2; }
         }
         __syncthreads();
         if (tid < BN && co_base + tid < Cout) {
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = R[tid * 2], s2 = R[tid * 2 + 1];
 #pragma unroll
-            for (int m = 0; m < WAVES_M; ++m) { s1 += R[(m * BN + tid) * 2]; s2 += R[(m * BN + tid) * 2 + 1]; }
+            for (int m = 1; m < WAVES_M; ++m) stat_merge(s1, s2, (float)(m * WM), R[(m * BN + tid) * 2], R[(m * BN + tid) * 2 + 1], (float)WM);
             const int tpi = (H * W) / BM;                                   // tiles per image of the M grid
             const int npar = geo.out_mode == 1 ? 4 : 1;
             const int n = tile_m / tpi, t = tile_m - n * tpi;

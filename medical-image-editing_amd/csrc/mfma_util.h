@@ -39,3 +39,29 @@ __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, unsigned byte_
 // an exec-masked block of its own; basic-block boundaries inside an MFMA loop keep the scheduler from spreading the
 // prefetch / store instructions between the MFMAs (they end up in one run during which the matrix pipe idles).
 __device__ __forceinline__ unsigned sel_u32(bool c, unsigned a, unsigned b) { return c ? a : b; }
+
+// Per-tile statistics the conv epilogues leave for the following normalisation: (sum, M2) with M2 = sum (x - tile mean)^2,
+// merged pairwise (Chan et al.) so that no fp32 quantity ever holds sum(x^2): var = E[x^2] - mean^2 from fp32 sums loses
+// (mean / sigma)^2 * 6e-8 - 3e-4 of the output on a plane that sits 60 sigma off zero (profiles/r02_stats_precision.txt).
+// lane_stats: m values held by one lane.  stat_merge_eq: two groups of n elements EACH (inv2n = 1 / (2 n)).
+// stat_merge: groups of na and nb elements.
+template <int M>
+__device__ __forceinline__ void lane_stats(const float* v, float& s, float& m2) {
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) s += v[i];
+    const float mean = s * (1.f / M);
+    m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) { const float d = v[i] - mean; m2 = fmaf(d, d, m2); }
+}
+__device__ __forceinline__ void stat_merge_eq(float& s, float& m2, float so, float m2o, float inv2n) {
+    const float d = so - s;
+    m2 = (m2 + m2o) + d * d * inv2n;
+    s += so;
+}
+__device__ __forceinline__ void stat_merge(float& s, float& m2, float na, float so, float m2o, float nb) {
+    const float d = so / nb - s / na;
+    m2 = (m2 + m2o) + d * d * (na * nb / (na + nb));
+    s += so;
+}

@@ -279,15 +279,16 @@ __global__ void k_inorm_bwd_apply4(const float4* __restrict__ x, const float* __
 // statistics from per-tile float partials part[n][nparts][C][2] (written by the conv that produced x): one wave per
 // (n, c), lanes take the tiles round-robin and sum in double, fixed butterfly
 __global__ void __launch_bounds__(256) k_inorm_finalize_parts(const float* __restrict__ part, float* __restrict__ mr, int NC, int C,
-                                                              int nparts, double inv_hw, float eps) {
+                                                              int nparts, double inv_hw, float eps, double inv_tile) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;
     if (i >= NC) return;              // wave-uniform
     const int n = i / C, c = i % C;
     double a = 0.0, b = 0.0;
     for (int t = s; t < nparts; t += 64) {
-        const float* o = part + (((long)n * nparts + t) * C + c) * 2;
-        a += (double)o[0];
-        b += (double)o[1];
+        const float* o = part + (((long)n * nparts + t) * C + c) * 2;     // (sum, M2 about the tile mean) of one tile
+        const double st = (double)o[0];
+        a += st;
+        b += (double)o[1] + st * st * inv_tile;                           // -> sum of squares, in double
     }
     a = wave_sum_d(a);
     b = wave_sum_d(b);
@@ -303,7 +304,7 @@ extern "C" int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int 
     VQW_CHECK(x && y && mean_rstd && part && nparts > 0 && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd_parts: bad arguments");
     VQW_CHECK(y_coff >= 0 && y_coff + C <= y_cstride, "vqw_inorm_fwd_parts: output channel slice [%d,%d) outside stride %d", y_coff, y_coff + C, y_cstride);
     hipStream_t st = (hipStream_t)stream;
-    k_inorm_finalize_parts<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, mean_rstd, N * C, C, nparts, 1.0 / (double)HW, eps);
+    k_inorm_finalize_parts<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, mean_rstd, N * C, C, nparts, 1.0 / (double)HW, eps, (double)nparts / (double)HW);
     long total = (long)N * HW * C;
     if ((C & 3) == 0 && (y_cstride & 3) == 0 && (y_coff & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
         long t4 = total / 4;
@@ -335,7 +336,7 @@ extern "C" int vqw_inorm_stats(const float* x, float* mean_rstd, void* ws, size_
 }
 extern "C" int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_rstd, int N, int HW, int C, float eps, void* stream) {
     VQW_CHECK(part && mean_rstd && nparts > 0 && N > 0 && HW > 0 && C > 0, "vqw_inorm_stats_parts: bad arguments");
-    k_inorm_finalize_parts<<<ceil_div((long)N * C, 4), 256, 0, (hipStream_t)stream>>>(part, mean_rstd, N * C, C, nparts, 1.0 / (double)HW, eps);
+    k_inorm_finalize_parts<<<ceil_div((long)N * C, 4), 256, 0, (hipStream_t)stream>>>(part, mean_rstd, N * C, C, nparts, 1.0 / (double)HW, eps, (double)nparts / (double)HW);
     VQW_LAUNCH_CHECK("vqw_inorm_stats_parts");
     return VQW_OK;
 }
@@ -609,14 +610,16 @@ __global__ void __launch_bounds__(256) k_channel_sum_finalize(const double* __re
 }
 
 // the same from the per-tile float partials part[rows][C][2] a convolution's epilogue left (vqw_conv2d_fwd_stats)
-__global__ void __launch_bounds__(256) k_channel_sum_finalize_f(const float* __restrict__ part, double* __restrict__ sums, int C, int rows) {
+__global__ void __launch_bounds__(256) k_channel_sum_finalize_f(const float* __restrict__ part, double* __restrict__ sums, int C, int rows,
+                                                                double inv_tile) {
     __shared__ double sa[256], sb[256];
     const int c = blockIdx.x, t = threadIdx.x;
     double a = 0.0, b = 0.0;
     for (int r = t; r < rows; r += 256) {
-        const float* o = part + ((long)r * C + c) * 2;
-        a += (double)o[0];
-        b += (double)o[1];
+        const float* o = part + ((long)r * C + c) * 2;          // (sum, M2 about the tile mean)
+        const double st = (double)o[0];
+        a += st;
+        b += (double)o[1] + st * st * inv_tile;
     }
     sa[t] = a;
     sb[t] = b;
@@ -630,9 +633,9 @@ __global__ void __launch_bounds__(256) k_channel_sum_finalize_f(const float* __r
         sums[2 * c + 1] = sb[0];
     }
 }
-extern "C" int vqw_bn_stats_from_parts(const float* part, double* sums, int rows, int C, void* stream) {
-    VQW_CHECK(part && sums && rows > 0 && C > 0, "vqw_bn_stats_from_parts: bad arguments");
-    k_channel_sum_finalize_f<<<C, 256, 0, (hipStream_t)stream>>>(part, sums, C, rows);
+extern "C" int vqw_bn_stats_from_parts(const float* part, double* sums, int rows, int C, double tile_count, void* stream) {
+    VQW_CHECK(part && sums && rows > 0 && C > 0 && tile_count >= 1.0, "vqw_bn_stats_from_parts: bad arguments");
+    k_channel_sum_finalize_f<<<C, 256, 0, (hipStream_t)stream>>>(part, sums, C, rows, 1.0 / tile_count);
     VQW_LAUNCH_CHECK("vqw_bn_stats_from_parts");
     return VQW_OK;
 }

@@ -674,7 +674,8 @@ class _Spade(torch.autograd.Function):
         if training:
             sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
             if part is not None:    # per-tile sums left by the producing convolution's epilogue
-                _lib.check(L.vqw_bn_stats_from_parts(_p(part), _p(sums), part.numel() // (2 * C), C, _st()), "vqw_bn_stats_from_parts")
+                rows = part.numel() // (2 * C)
+                _lib.check(L.vqw_bn_stats_from_parts(_p(part), _p(sums), rows, C, count / rows, _st()), "vqw_bn_stats_from_parts")
             else:
                 ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
                 _lib.check(L.vqw_bn_partial_stats(_p(x), _p(sums), _p(ws), ws.numel(), N, H * W, C, _st()), "vqw_bn_partial_stats")

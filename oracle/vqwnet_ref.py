@@ -51,10 +51,12 @@ def conv(P, key, x, dilation=1):
 
 
 def inorm(x):
-    """InstanceNorm2d(affine=False, no running stats): per (n,c) plane, biased var."""
-    mu = x.mean(dim=(2, 3), keepdim=True)
-    var = x.var(dim=(2, 3), unbiased=False, keepdim=True)
-    return (x - mu) / torch.sqrt(var + IN_EPS)
+    """InstanceNorm2d(affine=False, no running stats): per (n,c) plane (x - mean) / sqrt(biased var + eps).
+
+    Evaluated by ATen's instance-norm kernel (what nn.InstanceNorm2d runs in the reference): its backward keeps the
+    plane reductions in the accumulation type.  The composite formula's autograd backward cancels in fp32 and is up to
+    ~100x further from the fp64 gradient on the 160->32 layer behind the ASPP (measured with the fp64 fixtures)."""
+    return F.instance_norm(x, eps=IN_EPS)
 
 
 def double_conv(P, key, x):
@@ -88,18 +90,11 @@ def batch_norm(P, key, x, training):
     Mutates P[key+'.running_mean'|'.running_var'|'.num_batches_tracked'].
     """
     rm, rv = P[key + ".running_mean"], P[key + ".running_var"]
-    if training:
-        n = x.numel() // x.shape[1]
-        mu = x.mean(dim=(0, 2, 3))
-        var = x.var(dim=(0, 2, 3), unbiased=False)
+    if training and key + ".num_batches_tracked" in P:
         with torch.no_grad():
-            rm.mul_(1 - BN_MOMENTUM).add_(mu.detach(), alpha=BN_MOMENTUM)
-            rv.mul_(1 - BN_MOMENTUM).add_(var.detach() * (n / max(n - 1, 1)), alpha=BN_MOMENTUM)
-            if key + ".num_batches_tracked" in P:
-                P[key + ".num_batches_tracked"] += 1
-    else:
-        mu, var = rm, rv
-    return (x - mu[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + BN_EPS)
+            P[key + ".num_batches_tracked"] += 1
+    # ATen's batch-norm kernel, as nn.BatchNorm2d runs it in the reference (same reasoning as inorm above)
+    return F.batch_norm(x, rm, rv, None, None, training, BN_MOMENTUM, BN_EPS)
 
 
 def styled_denorm(P, key, x, style, training):

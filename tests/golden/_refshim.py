@@ -85,3 +85,30 @@ def load_reference():
         OneHotEncoder=fn.onehot.OneHotEncoder,
         SoftDiceLoss=fn.seg_loss.SoftDiceLoss, FocalLoss=fn.seg_loss.FocalLoss,
     )
+
+
+def load_reference_utils():
+    """utils/__init__.py of the reference (CT windows, norm / denorm, load_json).  Its imports of nibabel, matplotlib,
+    Lightning-based `.logger` and `.init_seed` are never touched by those functions and are given as inert stubs; the
+    module is loaded under the name `refutils` so that the `utils` stub above stays in place."""
+    import importlib.machinery
+    for name in ("nibabel",):
+        if importlib.util.find_spec(name) is None and name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, mpl.pyplot
+    for sub, names in (("logger", ("ModelSaver", "Logger")), ("init_seed", ("InitSeedAndSaveConfig",))):
+        m = types.ModuleType("refutils." + sub)
+        for n in names:
+            setattr(m, n, type(n, (), {}))
+        sys.modules["refutils." + sub] = m
+    path = os.path.join(REF_SRC, "utils", "__init__.py")
+    spec = importlib.util.spec_from_file_location("refutils", path, submodule_search_locations=[])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["refutils"] = mod
+    spec.loader.exec_module(mod)
+    return mod

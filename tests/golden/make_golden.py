@@ -204,11 +204,13 @@ def ref_first_step(enc, dec, eopt, dopt, image, noise, cfg):
     l_commit = lc1 + lc2
     total = (w["commit"] * l_commit + w["cross"] * l_cross + w["dist"] * l_dist
              + w["reg"] * l_reg + w["recon"] * l_recon)
-    eopt.zero_grad(); dopt.zero_grad()
+    if eopt is not None:
+        eopt.zero_grad(); dopt.zero_grad()
     total.backward()
     grads = {"enc." + k: p.grad.clone() for k, p in enc.named_parameters()}
     grads.update({"dec." + k: p.grad.clone() for k, p in dec.named_parameters()})
-    eopt.step(); dopt.step()
+    if eopt is not None:
+        eopt.step(); dopt.step()
     return dict(total=total, commit=l_commit, cross=l_cross, dist=l_dist, reg=l_reg, recon=l_recon,
                 ids_1=ids1, ids_2=ids2, recon_1=rec1, recon_2=rec2, embed_1=e1, embed_2=e2), grads
 
@@ -216,6 +218,15 @@ def ref_first_step(enc, dec, eopt, dopt, image, noise, cfg):
 def sample_idx(numel, n=64, seed=0):
     g = torch.Generator().manual_seed(seed)
     return torch.randint(0, numel, (min(n, numel),), generator=g)
+
+
+def ref_grads_fp64(enc, dec, image, noise, cfg):
+    """The same first step on `.double()` copies of the reference modules (same weights, buffers and inputs): the
+    gradients every fp32 implementation - the reference's own included - is an approximation of."""
+    import copy
+    enc64, dec64 = copy.deepcopy(enc).double(), copy.deepcopy(dec).double()
+    out, grads = ref_first_step(enc64, dec64, None, None, image.double(), noise.double(), cfg)
+    return out, grads
 
 
 def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, momentum=0.999, warm=False):
@@ -268,7 +279,31 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
     for s in range(n_steps):
         image, noise = O.synthetic_slices(batch, size, 1234 + s)
         d["step%d/image" % s], d["step%d/noise" % s] = npy(image), npy(noise)
+        if s == 0:
+            import copy
+            out64, grads64 = ref_grads_fp64(enc, dec, image, noise, cfg)
+            # the reference's own fp32 spread: the same step evaluated in mathematically equivalent ways that change
+            # only the association order of its fp32 reductions - batch order reversed, one thread instead of eight
+            variants = []
+            for flip, threads in ((True, 8), (False, 1), (True, 1)):
+                torch.set_num_threads(threads)
+                img_v, noi_v = (image.flip(0), noise.flip(0)) if flip else (image, noise)
+                variants.append(ref_first_step(copy.deepcopy(enc), copy.deepcopy(dec), None, None, img_v, noi_v, cfg)[1])
+            torch.set_num_threads(8)
         out, grads = ref_first_step(enc, dec, eopt, dopt, image, noise, cfg)
+        if s == 0:
+            # principled gradient gate (tests/helpers.py::check_grads_vs_fp64): 256 sampled entries of the fp64 gradient and
+            # of each fp32 evaluation of the reference at the same positions, the fp64 norm, whole-tensor fp32 errors
+            for v in ("1", "2"):
+                d["step0/ids64_agree_" + v] = np.array(float((out64["ids_" + v] == out["ids_" + v]).double().mean()))
+            d["step0/total64"] = np.array(float(out64["total"]))
+            for k, g64 in grads64.items():
+                idx = sample_idx(g64.numel(), 256, seed=1)
+                d["step0/g64." + k] = npy(g64.reshape(-1)[idx])
+                d["step0/gnorm64." + k] = np.array(float(g64.norm()))
+                for i, gv in enumerate([grads] + variants):
+                    d["step0/g32v%d.%s" % (i, k)] = npy(gv[k].reshape(-1)[idx])
+                d["step0/gerr32." + k] = np.array([float((gv[k].double() - g64).norm() / (g64.norm() + 1e-300)) for gv in [grads] + variants])
         for k in ("total", "commit", "cross", "dist", "reg", "recon"):
             d["step%d/%s" % (s, k)] = np.array(float(out[k]))
         for k in ("ids_1", "ids_2", "recon_1", "recon_2"):
@@ -386,16 +421,104 @@ def gen_gan():
     save("gan.npz", d)
 
 
+def _vq_dist_worker(rank, world, port, tmp):
+    """One rank of the reference's VQModule under torch.distributed (gloo): WORLD_SIZE drives utils.is_distributed()."""
+    import torch.distributed as dist
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Rw = _refshim.load_reference()
+    out = {}
+    for tag, (Bn, D, K, HW, mom) in {"k10": (2, 16, 10, 16, 0.9), "k64": (1, 32, 64, 12, 0.99)}.items():
+        torch.manual_seed(5)                                   # identical replicas, as DDP's broadcast leaves them
+        vq = Rw.vq_module.VQModule(emb_dim=D, dict_size=K, momentum=mom, eps=1e-5, knn_backend="torch")
+        if rank == 0:
+            out[tag + "/embed0"], out[tag + "/momentum"] = npy(vq.embed).copy(), np.array(mom)
+        vq.train()
+        for call in (1, 2):
+            g = torch.Generator().manual_seed(100 * call + rank)
+            x = torch.randn(Bn, D, HW, HW, generator=g) * 1.3
+            q, commit, ids = vq(x)
+            out["%s/r%d/x%d" % (tag, rank, call)] = npy(x)
+            out["%s/r%d/ids%d" % (tag, rank, call)] = npy(ids.transpose(1, 2))
+            out["%s/r%d/commit%d" % (tag, rank, call)] = npy(commit)
+            for b in ("embed", "cluster_size", "embed_avg"):
+                out["%s/r%d/%s_after%d" % (tag, rank, b, call)] = npy(getattr(vq, b)).copy()
+    np.savez(os.path.join(tmp, "r%d.npz" % rank), **out)
+    dist.destroy_process_group()
+
+
+def gen_vq_dist():
+    """The reference-held data-parallel fixture: VQModule under WORLD_SIZE=2, vq_module.py:187-193 -
+    embed_sum is all-reduced and divided by the world size, the counts stay local, so the replicas' cluster_size and
+    codebooks DIVERGE (the upstream quirk `dist_mode="reference"` reproduces)."""
+    import tempfile
+    import torch.multiprocessing as mp
+    tmp = tempfile.mkdtemp()
+    mp.spawn(_vq_dist_worker, args=(2, 29531, tmp), nprocs=2, join=True)
+    d = {}
+    for r in range(2):
+        z = np.load(os.path.join(tmp, "r%d.npz" % r))
+        d.update({k: z[k] for k in z.files})
+    save("vq_dist.npz", d)
+
+
+def gen_utils():
+    """utils/__init__.py: CT window arithmetic (normalize / denormalize, :17-51), norm / denorm (:81-92) and load_json's
+    false -> None convention (:99-106), through the reference's own functions."""
+    import json
+    import tempfile
+    U = _refshim.load_reference_utils()
+    d = {}
+    g = np.random.default_rng(0)
+    hu = np.concatenate([g.uniform(-2200, 2200, 500), np.array([-1300.0, -1299.5, -550.0, 199.5, 200.0, 40.0, -160.0, 240.0])]).astype(np.float32)
+    d["hu"] = hu.copy()
+    windows = {"default": dict(width=1500, center=-550, scale=2.0), "mediastinal": dict(width=400, center=40, scale=2.0),
+               "wide": dict(width=4096, center=0, scale=2.0), "odd": dict(width=401, center=-7, scale=1.0)}
+    for name, w in windows.items():
+        d["window/%s" % name] = np.array([w["width"], w["center"], w["scale"]], dtype=np.float64)
+        n = U.normalize(hu.copy(), **w)
+        d["normalize/%s" % name] = n.copy()
+        d["denormalize/%s" % name] = U.denormalize(n.copy(), **w)
+        # multi_window_trainer.py:93-118: denormalize with the dataset window, normalize with the target window
+        x_ds = U.normalize(hu.copy(), **windows["wide"])           # the dataset's units
+        d["rewindow/%s" % name] = U.normalize(U.denormalize(torch.from_numpy(x_ds), **windows["wide"]).numpy(), **w)
+    x = g.uniform(-1, 1, (2, 1, 8, 8)).astype(np.float32)
+    d["norm/x"] = x.copy()
+    d["norm/y"] = npy(U.norm(torch.from_numpy(x.copy())))
+    d["denorm/y01"] = npy(U.denorm(torch.from_numpy(x.copy()), 0.0, 1.0))
+    d["denorm/y_hu"] = npy(U.denorm(torch.from_numpy(x.copy()), -1300.0, 200.0))
+    cfgj = {"run": {"seed": 3, "flag_false": False, "flag_true": True, "name": "a"}, "list": [1, 2, False]}
+    path = os.path.join(tempfile.mkdtemp(), "c.json")
+    json.dump(cfgj, open(path, "w"))
+    c = U.load_json(path)
+    d["load_json/repr"] = np.array(repr((c.run.seed, c.run.flag_false, c.run.flag_true, c.run.name, c.list)))
+    d["load_json/source"] = np.array(json.dumps(cfgj))
+    save("utils.npz", d)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "gan":
+    what = sys.argv[1:] or ["gan", "extras", "blocks", "vq", "losses", "steps", "cfg4", "vqdist", "utils"]
+    if "gan" in what:
         gen_gan()
-        sys.exit(0)
-    gen_gan()
-    gen_extras()
-    gen_blocks()
-    gen_vq()
-    gen_losses()
-    gen_step("step_small.npz", [16, 16, 32, 32, 32], [16, 32, 32, 32, 64], 6, 32, 2, 3, seed=7,
-             momentum=0.9)
-    gen_step("step_rcfg32.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 32, 4, 1, seed=0)
-    gen_step("step_rcfg64_warm.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 64, 2, 1, seed=0, warm=True)
+    if "extras" in what:
+        gen_extras()
+    if "blocks" in what:
+        gen_blocks()
+    if "vq" in what:
+        gen_vq()
+    if "losses" in what:
+        gen_losses()
+    if "steps" in what:
+        gen_step("step_small.npz", [16, 16, 32, 32, 32], [16, 32, 32, 32, 64], 6, 32, 2, 3, seed=7,
+                 momentum=0.9)
+        gen_step("step_rcfg32.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 32, 4, 1, seed=0)
+        gen_step("step_rcfg64_warm.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 64, 2, 1, seed=0, warm=True)
+    if "cfg4" in what:
+        # BASELINE config 4 scaled down spatially (SURVEY 8d: enc_filters[0] = emb_dim = 256, dict_size 1024)
+        gen_step("step_cfg4_32.npz", [256, 64, 128, 256, 512], [32, 64, 128, 256, 512], 1024, 32, 2, 1, seed=0,
+                 momentum=0.99, warm=True)
+    if "vqdist" in what:
+        gen_vq_dist()
+    if "utils" in what:
+        gen_utils()

@@ -57,3 +57,47 @@ def step_cfg(g):
                 momentum=float(g["cfg/momentum"]),
                 weights=dict(commit=1.0, cross=1.0, dist=1.0, reg=1.0, recon=1.0),
                 optim=dict(lr=float(g["cfg/lr"]), betas=tuple(float(b) for b in g["cfg/betas"]), weight_decay=0.0))
+
+
+def check_grads_vs_fp64(g, grads, factor=2.0, what=""):
+    """Principled end-to-end gradient gate.  The step fixtures hold, per parameter, 256 sampled entries of the gradient the
+    REFERENCE modules produce in fp64 (`step0/g64.*`) and of four fp32 evaluations of the same reference step that are
+    mathematically identical and differ only in the association order of fp32 reductions (`step0/g32v{0..3}.*`: as
+    run_vqwnet would run it, batch order reversed, one thread instead of eight, both).  Their distance from the fp64
+    gradient is the reference's own fp32 spread - 10-100x larger than any single run suggests (the one-thread run of
+    the config-4 fixture is 4e-3 from fp64, the eight-thread run 8e-6).  The implementation under test must be at most
+    `factor` times that spread from the fp64 gradient, per parameter, with the median spread over all parameters as
+    the floor (rounding errors are random: a parameter on which the reference happens to be exact binds nobody).
+
+    `grads`: {"enc.<name>" / "dec.<name>": tensor}.  Returns (median, max) of err_test / max(spread, floor)."""
+    names = [k[len("step0/g64."):] for k in g.files if k.startswith("step0/g64.")]
+    assert names, "fixture has no fp64 gradients"
+    n64 = {k: float(g["step0/gnorm64." + k]) for k in names}
+    gmax = max(n64.values())
+    live = [k for k in names if n64[k] >= 1e-6 * gmax]
+    nvar = len([1 for f in g.files if f.startswith("step0/g32v") and f.endswith("." + names[0])])
+
+    def err(sample, k):
+        ref = torch.from_numpy(np.asarray(g["step0/g64." + k])).double()
+        numel = int(np.prod(grads[k].shape)) if grads.get(k) is not None else 1
+        return float((sample.double() - ref).norm()) / (float(ref.norm()) + n64[k] / numel ** 0.5)
+
+    spread = {k: max(max(err(torch.from_numpy(np.asarray(g["step0/g32v%d.%s" % (i, k)])), k) for i in range(nvar)),
+                     float(np.max(g["step0/gerr32." + k]))) for k in live}
+    floor = float(np.median(list(spread.values())))
+    ratios = []
+    for k in names:
+        gr = grads.get(k)
+        if k not in live:          # analytically zero (bias in front of an InstanceNorm): rounding noise only
+            assert gr is None or float(gr.norm()) < 1e-4 * gmax, "%s %s: analytically zero gradient has norm %.3e" % (what, k, float(gr.norm()))
+            continue
+        assert gr is not None, "%s %s: no gradient" % (what, k)
+        gr = gr.detach().cpu()
+        idx = sample_idx(gr.numel(), 256, seed=1)
+        e = err(gr.reshape(-1)[idx], k)
+        e = max(e, abs(float(gr.double().norm()) - n64[k]) / n64[k])
+        ref_e = max(spread[k], floor)
+        ratios.append(e / ref_e)
+        assert e <= factor * ref_e, "%s grad %s: %.3e from the fp64 gradient > %.1f x the reference's own fp32 spread (%.3e; median over " \
+            "parameters %.3e)" % (what, k, e, factor, spread[k], floor)
+    return float(np.median(ratios)), float(np.max(ratios))

@@ -146,3 +146,47 @@ def test_second_step_two_rank_dp(tmp_path):
             worst = max(worst, d)
             assert d <= 2.5e-3, (k, d)            # one Adam step of lr 1e-3: a sign flip of a ~0 gradient moves 2e-3
     assert worst > 0.0
+
+
+VQ_REF_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "medical-image-editing_amd"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from networks.vq import VQ
+g = np.load(os.path.join(root, "tests", "golden", "vq_dist.npz"))
+for tag in ("k10", "k64"):
+    e0 = torch.from_numpy(g[tag + "/embed0"].copy())
+    K, D = e0.shape
+    vq = VQ(emb_dim=D, dict_size=K, momentum=float(g[tag + "/momentum"]), eps=1e-5, knn_backend="torch")
+    vq.dist_mode = "reference"
+    vq.embed.copy_(e0); vq.embed_avg.copy_(e0.t()); vq.cluster_size.zero_()
+    vq.to("cuda:0").train()
+    for call in (1, 2):
+        x = torch.from_numpy(g["%s/r%d/x%d" % (tag, rank, call)]).to("cuda:0")
+        q, commit, ids = vq(x)
+        agree = np.mean(ids.transpose(1, 2).cpu().numpy() == g["%s/r%d/ids%d" % (tag, rank, call)])
+        assert agree > 0.999, (tag, rank, call, agree)
+        ref_c = float(g["%s/r%d/commit%d" % (tag, rank, call)])
+        assert abs(float(commit) - ref_c) <= 5e-5 * abs(ref_c), (tag, rank, call, float(commit), ref_c)
+        for b in ("embed", "cluster_size", "embed_avg"):
+            ref = torch.from_numpy(g["%s/r%d/%s_after%d" % (tag, rank, b, call)])
+            err = float((getattr(vq, b).cpu() - ref).norm() / ref.norm())
+            assert err < (1e-5 if agree == 1.0 else 5e-3), (tag, rank, call, b, err)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_vq_reference_dist_mode_matches_reference_fixture(tmp_path):
+    """`dist_mode="reference"` (rank-mean embed_sum, local counts: vq_module.py:187-193) on two gloo ranks sharing the
+    GPU, against tests/golden/vq_dist.npz - buffers the REFERENCE's VQModule held after two calls under WORLD_SIZE=2."""
+    script = tmp_path / "vqw.py"
+    script.write_text(VQ_REF_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29651", WORLD_SIZE="2", RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o = p.communicate(timeout=300)[0].decode()
+        assert p.returncode == 0, o[-3000:]

@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import assert_close, build_models, check_init, step_cfg
+from helpers import assert_close, build_models, check_init, step_cfg, check_grads_vs_fp64
 from test_oracle_golden import check_step, GRAD_TOL, apply_warm_state
 
 pytestmark = pytest.mark.gpu
@@ -246,6 +246,14 @@ STATS_CASES_GEMM = [
 ]
 
 
+def _plane_sums_from_partials(part, N, Cout, HW):
+    """(sum, sum of squares) per plane from the conv epilogue's per-tile (sum, M2 about the tile mean) partials, combined in
+    double exactly as the norm kernels do: sum x^2 = sum_t [M2_t + (sum_t)^2 / n_t], n_t = HW / tiles."""
+    p = part.view(N, -1, Cout, 2).double().cpu()
+    nt = HW / p.shape[1]
+    return p[..., 0].sum(1), (p[..., 1] + p[..., 0] ** 2 / nt).sum(1)
+
+
 @pytest.mark.parametrize("case", STATS_CASES_GEMM)
 def test_conv_epilogue_statistics_implicit_gemm(case):
     ops = _ops()
@@ -257,17 +265,17 @@ def test_conv_epilogue_statistics_implicit_gemm(case):
     y, part = ops.conv2d(x, w, b, dilation=dil, up2x=up, want_stats=True)
     assert part is not None, "shape should be served"
     assert torch.equal(y, ops.conv2d(x, w, b, dilation=dil, up2x=up))
-    p = part.view(N, -1, Cout, 2).double().sum(1).cpu()
+    s1, s2 = _plane_sums_from_partials(part, N, Cout, H * W)
     yd = y.double().cpu()
-    assert_close(p[..., 0], yd.sum((2, 3)), 2e-6, "sum", atol=1e-4)
-    assert_close(p[..., 1], (yd * yd).sum((2, 3)), 2e-6, "sum of squares")
+    assert_close(s1, yd.sum((2, 3)), 2e-6, "sum", atol=1e-4)
+    assert_close(s2, (yd * yd).sum((2, 3)), 2e-6, "sum of squares")
     assert_close(ops.instance_norm(y, relu=True, part=part), ops.instance_norm(y, relu=True), 2e-6, "instance norm from conv partials")
 
 
 @pytest.mark.parametrize("case", STATS_CASES)
 def test_conv_epilogue_statistics(case):
-    """conv2d(..., want_stats=True): the per-tile (sum, sum of squares) partials of the halo kernel's epilogue add up to
-    the plane sums of the output, and the InstanceNorm fed with them equals the one that reduces itself."""
+    """conv2d(..., want_stats=True): the per-tile (sum, M2) partials of the halo kernel's epilogue combine to the plane sums
+    of the output, and the InstanceNorm fed with them equals the one that reduces itself."""
     ops = _ops()
     N, H, W, C0, C1, up, Cout = case
     torch.manual_seed(sum(case))
@@ -279,13 +287,33 @@ def test_conv_epilogue_statistics(case):
     assert part is not None, "shape should be served by the halo kernel"
     y_ref = ops.conv2d(x0, w, b, up2x=up, skip=x1)
     assert torch.equal(y, y_ref)
-    p = part.view(N, -1, Cout, 2).double().sum(1).cpu()
+    s1, s2 = _plane_sums_from_partials(part, N, Cout, H * W)
     yd = y.double().cpu()
-    assert_close(p[..., 0], yd.sum((2, 3)), 2e-6, "sum", atol=1e-4)
-    assert_close(p[..., 1], (yd * yd).sum((2, 3)), 2e-6, "sum of squares")
+    assert_close(s1, yd.sum((2, 3)), 2e-6, "sum", atol=1e-4)
+    assert_close(s2, (yd * yd).sum((2, 3)), 2e-6, "sum of squares")
     a = ops.instance_norm(y, relu=True, part=part)
     r = ops.instance_norm(y, relu=True)
     assert_close(a, r, 2e-6, "instance norm from conv partials")
+
+
+@pytest.mark.parametrize("ks,Cin,Cout,S", [(1, 16, 16, 32), (3, 32, 32, 32), (3, 16, 16, 64), (1, 32, 64, 64)])
+def test_conv_epilogue_statistics_far_from_zero(ks, Cin, Cout, S):
+    """Planes whose mean is ~60 standard deviations off zero (conv of a nearly constant positive input, as behind ReLUs on a
+    quantised map): the InstanceNorm fed from the conv epilogue must be as exact as the one that reduces the plane in
+    double - var = E[x^2] - mean^2 from fp32 sums was 3e-4 off here, the (sum, M2) partials are at 1e-5."""
+    ops = _ops()
+    torch.manual_seed(ks * 100 + Cin)
+    x = (torch.randn(2, Cin, S, S) * 0.05 + 3.0 * torch.randn(1, Cin, 1, 1)).to(DEV)
+    w = (torch.randn(Cout, Cin, ks, ks) / (Cin * ks * ks) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device=DEV)
+    y, part = ops.conv2d(x, w, b, want_stats=True)
+    assert part is not None
+    ref = torch.nn.functional.instance_norm(y.double().cpu(), eps=1e-5)
+    a = ops.instance_norm(y, part=part)
+    r = ops.instance_norm(y)
+    e_a = float((a.double().cpu() - ref).norm() / ref.norm())
+    e_r = float((r.double().cpu() - ref).norm() / ref.norm())
+    assert e_a <= 2.0 * e_r + 1e-6, "epilogue statistics %.2e vs own reduction %.2e" % (e_a, e_r)
 
 
 def test_res_tail_norm_matches_separate_ops():
@@ -588,7 +616,7 @@ def _hip_trainer(g):
     return tr, cfg
 
 
-@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg32.npz"])
+@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg32.npz", "step_cfg4_32.npz"])
 def test_first_step_golden(golden, name):
     from oracle import vqwnet_ref as O
     g = golden(name)
@@ -624,6 +652,12 @@ def test_first_step_golden(golden, name):
         PD = dict(tr.decoder.state_dict())
         check_step(g, s, rec, PE, PD, lr, tight=(s == 0), tol=5e-4, grad_tol=max(gt, 5e-3), max_loose=ml + 2,
                    loose_bound=lb)
+        if s == 0:
+            # the principled gate: at most twice as far from the reference's fp64 gradient as the reference's own fp32
+            # evaluations are (tests/helpers.py::check_grads_vs_fp64)
+            grads = {"enc." + k: v for k, v in rec["grads_enc"].items()}
+            grads.update({"dec." + k: v for k, v in rec["grads_dec"].items()})
+            print(name, "HIP grad error / reference fp32 spread (median, max):", check_grads_vs_fp64(g, grads, 2.0, "HIP"))
 
 
 @pytest.mark.parametrize("B,S", [(2, 128), (3, 96), (2, 80)])
@@ -703,6 +737,94 @@ def test_full_size_properties():
     assert torch.unique(e[: 65536], dim=0).shape[0] <= K
     for p in list(tr.encoder.parameters()) + list(tr.decoder.parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
+def test_config4_full_size_properties():
+    """BASELINE config 4 as SURVEY 8d makes it concrete (512x512, dict_size 1024, enc_filters [256,64,128,256,512] so that
+    emb_dim = 256, batch 2 per GPU): one whole training step at full size; properties that need no oracle."""
+    from trainers import FirstStepTrainer
+    from oracle.vqwnet_ref import synthetic_slices
+    from hipops import _lib
+    torch.manual_seed(0)
+    B, S, K, D = 2, 512, 1024, 256
+    assert _lib.load().vqw_vq_plan(D, K) == 2          # fused MFMA score GEMM / arg-max route
+    tr = FirstStepTrainer(enc_filters=(256, 64, 128, 256, 512), dec_filters=(32, 64, 128, 256, 512), dict_size=K, momentum=0.99,
+                          device=DEV)
+    with torch.no_grad():      # checkpoint-like VQ state (every code in use)
+        tr.encoder.vq.cluster_size.fill_(B * S * S / K)
+        tr.encoder.vq.embed_avg.copy_(tr.encoder.vq.embed.t() * tr.encoder.vq.cluster_size[None, :])
+    image, noise = synthetic_slices(B, S, 1234)
+    cs0 = tr.encoder.vq.cluster_size.clone()
+    e0 = tr.encoder.vq.embed.clone()
+    with torch.no_grad():      # the features view 1 is quantised from (before the optimiser moves the weights)
+        feat = tr.encoder.feature_extraction(image.to(DEV)).clone()
+    out = tr.training_step({"image": image.to(DEV)}, noise=noise.to(DEV))
+    sc = tr.scalars(out)
+    assert all(np.isfinite(v) for v in sc.values()), sc
+    for v in ("1", "2"):
+        ids = out["ids_" + v]
+        assert ids.shape == (B, S, S) and int(ids.min()) >= 1 and int(ids.max()) <= K
+    m, N = 0.99, B * S * S
+    expect = m * m * float(cs0.sum()) + (1 - m) * (m * N + N)
+    assert abs(float(tr.encoder.vq.cluster_size.sum()) - expect) <= 1e-4 * expect
+    # view 1 was quantised with the initial codebook: every pixel of embed_1 is exactly the row its id names, and that row
+    # is the nearest one (checked in double on a sample of pixels against all 1024 codes)
+    e1 = out["embed_1"].detach().permute(0, 2, 3, 1).reshape(-1, D)
+    id1 = (out["ids_1"].reshape(-1) - 1)
+    pick = torch.randint(0, e1.shape[0], (4096,), device=DEV)
+    assert torch.equal(e1[pick], e0[id1[pick]])
+    f = feat.permute(0, 2, 3, 1).reshape(-1, D)[pick].double()
+    d2 = (f * f).sum(1, keepdim=True) - 2 * f @ e0.double().t() + (e0.double() ** 2).sum(1)[None]
+    best = d2.argmin(1)
+    mine = d2.gather(1, id1[pick][:, None])[:, 0]
+    assert bool(((mine - d2.min(1).values) <= 1e-4 * (1 + d2.min(1).values.abs())).all()), "ids are not the nearest codes"
+    assert float((best == id1[pick]).float().mean()) > 0.995
+    assert float(out["recon_1"].abs().max()) <= 1.0
+    for p in list(tr.encoder.parameters()) + list(tr.decoder.parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+
+
+def test_config5_full_size_recon_properties():
+    """BASELINE config 5 (run_recon.inner at 256x256, batch 64, eval mode, 10 % masked pixels): full-size properties -
+    deterministic, batch-independent (eval-mode normalisation uses running / per-sample statistics only), masked
+    pixels enter as zeros and the rescale is numel / count."""
+    from networks import UNetEncoder, UNetDecoder
+    from run_recon import reconstruct
+    from hipops import ops
+    torch.manual_seed(0)
+    enc = UNetEncoder(1, [16, 32, 64, 128, 256], 10, 0.999, 'torch', False, 1, True).to(DEV).eval()
+    dec = UNetDecoder(16, 1, [32, 64, 128, 256, 512], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False).to(DEV).eval()
+    B, S = 64, 256
+    g = torch.Generator().manual_seed(1)
+    lab = torch.randint(1, 11, (B, S, S), generator=g)
+    lab[torch.rand(B, S, S, generator=g) < 0.1] = 0
+    lab = lab.to(DEV)
+    with torch.no_grad():
+        rec = reconstruct(enc, dec, lab)
+        assert rec.shape == (B, 1, S, S) and torch.isfinite(rec).all() and float(rec.abs().max()) <= 1.0
+        assert torch.equal(rec, reconstruct(enc, dec, lab))
+        # the rescale couples samples only through the scalar numel / count: with it fixed, a sample's output does not
+        # depend on its batch mates
+        mask, ids0, scale = ops.mask_scale(lab)
+        assert abs(float(scale) - lab.numel() / float((lab != 0).sum())) < 1e-3
+        emb = ops.vq_lookup(ids0, enc.vq.embed, mask=mask, scale=scale)
+        assert float(emb.permute(0, 2, 3, 1)[lab == 0].abs().max()) == 0.0
+        whole = dec(emb)
+        part = dec(emb[5:9].contiguous(memory_format=torch.channels_last))
+        assert_close(part, whole[5:9], 1e-5, "batch independence")
+        assert_close(whole, rec, 1e-6, "reconstruct == lookup + decoder")
+
+
+def test_norm_denorm_golden(golden):
+    """utils.norm / denorm (utils/__init__.py:81-92) against the reference's own outputs, incl. the in-place contract."""
+    import utils as U
+    g = golden("utils.npz")
+    x = g.t("norm/x", DEV)
+    y = U.norm(x)
+    assert y.data_ptr() == x.data_ptr()
+    assert_close(y, g["norm/y"], 1e-7, "norm")
+    assert_close(U.denorm(g.t("norm/x", DEV), 0.0, 1.0), g["denorm/y01"], 1e-6, "denorm [0,1]")
+    assert_close(U.denorm(g.t("norm/x", DEV), -1300.0, 200.0), g["denorm/y_hu"], 1e-6, "denorm HU")
 
 
 # --------------------------------------------------------------------------------------------------
