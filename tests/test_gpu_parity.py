@@ -229,7 +229,7 @@ STATS_CASES = [
     # N, H, W, C0, C1, up, Cout        every halo-kernel template configuration, ragged rows, partial cout tile
     (2, 32, 32, 32, 0, False, 32),     # one chunk, weights resident
     (2, 32, 32, 32, 0, False, 64),     # 64-wide cout tile, 4-row tiles
-    (1, 20, 64, 64, 0, False, 32),     # streamed chunks, H not a multiple of the tile: rows below the image must not count
+    (1, 24, 64, 64, 0, False, 32),     # streamed chunks, three tile rows
     (2, 16, 32, 64, 0, False, 48),     # two cout tiles, the second one partial
     (2, 16, 32, 16, 0, False, 16),     # 16-wide MFMA variant
     (2, 32, 32, 32, 16, True, 16),     # up-sampled + concat source, 16 couts
@@ -294,6 +294,19 @@ def test_conv_epilogue_statistics(case):
     a = ops.instance_norm(y, relu=True, part=part)
     r = ops.instance_norm(y, relu=True)
     assert_close(a, r, 2e-6, "instance norm from conv partials")
+
+
+def test_conv_epilogue_statistics_need_whole_tiles():
+    """The partials carry no pixel count: a plane whose height is not a multiple of the tile height is not served (the norm
+    then reduces the plane itself) and the result is the same."""
+    ops = _ops()
+    torch.manual_seed(3)
+    x = torch.randn(1, 64, 20, 64, device=DEV)
+    w = (torch.randn(32, 64, 3, 3, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last)
+    y, part = ops.conv2d(x, w, None, want_stats=True)
+    assert part is None
+    assert torch.equal(y, ops.conv2d(x, w, None))
+    assert torch.equal(ops.instance_norm(y, relu=True, part=part), ops.instance_norm(y, relu=True))
 
 
 @pytest.mark.parametrize("ks,Cin,Cout,S", [(1, 16, 16, 32), (3, 32, 32, 32), (3, 16, 16, 64), (1, 32, 64, 64)])
