@@ -235,7 +235,9 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
 // ---------------------------------------------------------------------------------------------
 // 3x3 conv over a nearest x2 up-sampled input (blocks.py:106,123-126), collapsed onto the low-resolution grid
 extern "C" int vqw_conv3x3_up2_supported(int Cin, int Cout, int N, int h, int w) {
-    return g_conv_backend == 0 && conv_up2_ok(Cin, Cout, (long)N * h * w) ? 1 : 0;
+    // the collapsed form is chosen in forward and must then also serve the input gradient (roles of Cin / Cout swapped:
+    // Cout % 4 == 0 too), so a layer that took it can always be back-propagated
+    return g_conv_backend == 0 && conv_up2_ok(Cin, Cout, (long)N * h * w) && conv_up2_ok(Cout, Cin, (long)N * h * w) ? 1 : 0;
 }
 extern "C" size_t vqw_conv3x3_up2_ws_bytes(int Cin, int Cout) { return conv_up2_ws_floats(Cin, Cout) * sizeof(float) + 256; }
 extern "C" int vqw_conv3x3_up2_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream) {

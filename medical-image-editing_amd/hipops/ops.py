@@ -19,16 +19,46 @@ from . import _lib
 CL = torch.channels_last
 
 
+# Kernels are reached through the PyTorch dispatcher: every entry point of the C ABI is an operator torch.ops.vqw.<name>
+# with a schema derived from its prototype (hipops/library.py; mutation annotations from the `const` qualifiers).
+# VQW_DISPATCH=0 calls the C functions directly through ctypes instead (A/B of the host-side cost).
+DISPATCH = os.environ.get("VQW_DISPATCH", "1") != "0"
+_dispatch = None
+
+
 def _L():
-    return _lib.load()
+    global _dispatch
+    if not DISPATCH:
+        return _lib.load()
+    if _dispatch is None:
+        from . import library
+        _dispatch = library.Dispatch()
+    return _dispatch
 
 
-def _st():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+if DISPATCH:
+    from .library import Dispatch as _D
+
+    def _st():
+        return _D.STREAM
+
+    def _p(t):
+        return t
+else:
+    def _st():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _p(t):
+def _raw(t):
+    """Raw device pointer for the few host-side entry points that take pointer arrays by value."""
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _raw_stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _dev(*ts):
@@ -80,6 +110,22 @@ WGRAD_ASYNC = os.environ.get("VQW_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
 _join_queued = False
 grad_ready_listeners = []      # callables(param): the param's gradient is final and enqueued on the side stream
+
+
+def wgrad_through_autograd(*params):
+    """True when weight gradients must flow through autograd instead of being written out-of-band on a side stream:
+    inside a torch DistributedDataParallel forward (its reducer learns about a gradient from the AccumulateGrad hook of
+    the parameter; the reference launches under Lightning's DDPPlugin, run_vqwnet.py:112-121) or when somebody
+    registered a hook on the parameter."""
+    if getattr(torch.nn.parallel.DistributedDataParallel, "_active_ddp_module", None) is not None:
+        return True
+    for p in params:
+        if p is None:
+            continue
+        # (the data-parallel reducer of this package listens on both routes and marks its own hooks)
+        if p._backward_hooks or len(getattr(p, "_post_accumulate_grad_hooks", None) or ()) > p.__dict__.get("_vqw_own_hooks", 0):
+            return True
+    return False
 
 
 def _order_begin(token):
@@ -357,7 +403,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x0, x1, w, y if relu else None)
         ctx.cfg = (dilation, up0, ks, N, H, W, Cout, bias is not None)
         # leaf parameters get their gradient written out-of-band on the side stream (see _deferred_wgrad)
-        ctx.defer = (WGRAD_ASYNC and ctx.needs_input_grad[2] and weight.is_leaf and w is weight
+        ctx.defer = (WGRAD_ASYNC and ctx.needs_input_grad[2] and weight.is_leaf and w is weight and not wgrad_through_autograd(weight, bias)
                      and (bias is None or (bias.is_leaf and bias.is_contiguous())))
         if ctx.defer:
             ctx.params = (weight, bias)
@@ -372,50 +418,62 @@ class _Conv2d(torch.autograd.Function):
     def backward(ctx, gy, *_):
         x0, x1, w, y_relu = ctx.saved_tensors
         dilation, up0, ks, N, H, W, Cout, has_bias = ctx.cfg
-        L = _L()
-        gy = nhwc(gy)
-        if y_relu is not None:   # fused ReLU epilogue: mask the incoming gradient first
-            gm = torch.empty_like(y_relu, memory_format=CL)
-            _lib.check(L.vqw_relu_bwd(_p(y_relu), _p(gy), _p(gm), gy.numel(), _st()), "vqw_relu_bwd")
-            gy = gm
-        C0 = x0.shape[1]
-        C1 = 0 if x1 is None else x1.shape[1]
-        Cin = C0 + C1
-        g0 = g1 = gw = gb = None
         need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        if need0 and ctx.up_ws is not None:
-            g0 = torch.empty_like(x0, memory_format=CL)
-            _lib.check(L.vqw_conv3x3_up2_dgrad(_p(gy), _p(ctx.up_ws), _p(g0), N, H // 2, W // 2, Cin, Cout, _st()),
-                       "vqw_conv3x3_up2_dgrad")
-        elif need0 or (need1 and x1 is not None):
-            def _pack():
-                buf = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
-                _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
-                return buf
-            wt = _cached(w, "dgrad", _pack)
-            g_full = empty_nhwc(N, Cin, H, W, gy)
-            _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
-                       "vqw_conv2d_fwd(dgrad)")
-            if not up0 and x1 is None:
-                g0 = g_full
-            else:
-                if need0:
-                    g0 = torch.empty_like(x0, memory_format=CL)
-                    _lib.check(L.vqw_input_grad_gather(_p(g_full), Cin, 0, C0, int(up0), _p(g0), 0, N, H, W, _st()),
-                               "vqw_input_grad_gather")
-                if need1 and x1 is not None:
-                    g1 = torch.empty_like(x1, memory_format=CL)
-                    _lib.check(L.vqw_input_grad_gather(_p(g_full), Cin, C0, C1, 0, _p(g1), 0, N, H, W, _st()),
-                               "vqw_input_grad_gather")
-        if ctx.defer and (needw or (needb and has_bias)):
+        defer = ctx.defer and (needw or (needb and has_bias))
+        g0, g1, gw, gb, gy = conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, ctx.up_ws, need0, need1,
+                                                  needw and not defer, needb and not defer)
+        if defer:
             weight, bias = ctx.params
             _deferred_wgrad(weight, bias if (has_bias and bias.requires_grad) else None, x0, x1, gy, up0, ks, dilation,
                             N, H, W, Cout, collapsed=ctx.up_ws is not None)
-        elif needw or (needb and has_bias):
-            gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
-            gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
-            _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, False, ctx.up_ws is not None)
         return g0, g1, gw, gb, None, None, None, None
+
+
+def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb):
+    """Input / weight / bias gradients of conv2d on the current stream -> (g0, g1, gw, gb, masked gy).  x0 / x1 / w are the
+    NHWC tensors the forward saw, y_relu its output when the ReLU was fused (the incoming gradient is masked first),
+    up_ws the collapsed-weight buffer when the forward took the low-resolution form."""
+    L = _L()
+    Cout, Cin, ks, _ = w.shape
+    N = x0.shape[0]
+    H, W = (x0.shape[2] * 2, x0.shape[3] * 2) if up0 else (x0.shape[2], x0.shape[3])
+    gy = nhwc(gy)
+    if y_relu is not None:   # fused ReLU epilogue: mask the incoming gradient first
+        gm = torch.empty_like(y_relu, memory_format=CL)
+        _lib.check(L.vqw_relu_bwd(_p(y_relu), _p(gy), _p(gm), gy.numel(), _st()), "vqw_relu_bwd")
+        gy = gm
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    g0 = g1 = gw = gb = None
+    if need0 and up_ws is not None:
+        g0 = torch.empty_like(x0, memory_format=CL)
+        _lib.check(L.vqw_conv3x3_up2_dgrad(_p(gy), _p(up_ws), _p(g0), N, H // 2, W // 2, Cin, Cout, _st()),
+                   "vqw_conv3x3_up2_dgrad")
+    elif need0 or (need1 and x1 is not None):
+        def _pack():
+            buf = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
+            _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
+            return buf
+        wt = _cached(w, "dgrad", _pack)
+        g_full = empty_nhwc(N, Cin, H, W, gy)
+        _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
+                   "vqw_conv2d_fwd(dgrad)")
+        if not up0 and x1 is None:
+            g0 = g_full
+        else:
+            if need0:
+                g0 = torch.empty_like(x0, memory_format=CL)
+                _lib.check(L.vqw_input_grad_gather(_p(g_full), Cin, 0, C0, int(up0), _p(g0), 0, N, H, W, _st()),
+                           "vqw_input_grad_gather")
+            if need1 and x1 is not None:
+                g1 = torch.empty_like(x1, memory_format=CL)
+                _lib.check(L.vqw_input_grad_gather(_p(g_full), Cin, C0, C1, 0, _p(g1), 0, N, H, W, _st()),
+                           "vqw_input_grad_gather")
+    if needw or (needb and has_bias):
+        gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+        gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
+        _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, False, up_ws is not None)
+    return g0, g1, gw, gb, gy
 
 
 def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, want_stats=False):
@@ -509,7 +567,7 @@ class _ConvCat(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.cfg = (ks, N, H, W, Ca, Cb)
         ctx.params = (wa, ba, wb, bb)
-        ctx.defer = (WGRAD_ASYNC and all(ctx.needs_input_grad[1:5]) and all(p.is_leaf for p in (wa, ba, wb, bb))
+        ctx.defer = (WGRAD_ASYNC and all(ctx.needs_input_grad[1:5]) and all(p.is_leaf for p in (wa, ba, wb, bb)) and not wgrad_through_autograd(wa, ba, wb, bb)
                      and nhwc(wa) is wa and nhwc(wb) is wb and ba.is_contiguous() and bb.is_contiguous())
         if ctx.defer:
             wa._vqw_pending = getattr(wa, "_vqw_pending", 0) + 1
@@ -666,8 +724,8 @@ class _Spade(torch.autograd.Function):
         else:
             beta = nhwc(beta)
         gbs = 2 * C if fused else C
-        gptr = gamma.data_ptr()
-        bptr = gptr + 4 * C if fused else beta.data_ptr()
+        gptr = _p(gamma)
+        bptr = _p(gamma.narrow(1, C, C) if fused else beta)      # fused: beta = channels C..2C of the same NHWC map
         L = _L()
         mr = torch.empty(2 * C, dtype=torch.float32, device=x.device)
         count = float(N * H * W)
@@ -715,12 +773,12 @@ class _Spade(torch.autograd.Function):
         gy = nhwc(gy)
         if fused:
             dgamma, dbeta, gbs = torch.empty_like(gamma, memory_format=CL), None, 2 * C
-            gptr, dgptr = gamma.data_ptr(), dgamma.data_ptr()
-            bptr, dbptr = gptr + 4 * C, dgptr + 4 * C
+            gptr, dgptr = _p(gamma), _p(dgamma)
+            bptr, dbptr = _p(gamma.narrow(1, C, C)), _p(dgamma.narrow(1, C, C))
         else:
             dgamma = torch.empty_like(x, memory_format=CL)
             dbeta = torch.empty_like(x, memory_format=CL)
-            gbs, gptr, bptr, dgptr, dbptr = C, gamma.data_ptr(), beta.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+            gbs, gptr, bptr, dgptr, dbptr = C, _p(gamma), _p(beta), _p(dgamma), _p(dbeta)
         gx = torch.empty_like(x, memory_format=CL)
         sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
         ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
@@ -1031,7 +1089,7 @@ class _WeightedSum(torch.autograd.Function):
             # backward pass —, a pinned staging buffer per call makes the host allocator wait for the device now and then)
             tp = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
             tw = (ctypes.c_float * len(terms))(*[float(x) for x in weights])
-            _lib.check(_L().vqw_weighted_sum_host(tp, tw, len(terms), _p(out), _st()), "vqw_weighted_sum_host")
+            _lib.check(_lib.load().vqw_weighted_sum_host(tp, tw, len(terms), _raw(out), _raw_stream()), "vqw_weighted_sum_host")
         else:
             ptrs = torch.tensor([t.data_ptr() for t in terms], dtype=torch.int64).to(dev)
             w = torch.tensor(list(weights), dtype=torch.float32).to(dev)

@@ -35,14 +35,30 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._pin_rings = {}          # (group, table size) -> [[pinned int64 buffer, event of its last upload], ...]
 
+    def load_state_dict(self, state_dict):
+        """Accepts the state a stock torch.optim.Adam saved for the reference (Lightning checkpoint `optimizer_states`):
+        its moments keep the NCHW strides they were saved with and `step` is a tensor; both are brought to this
+        optimiser's conventions (moments in the parameter's own - channels_last - layout, integer step)."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                if torch.is_tensor(st.get("step")):
+                    st["step"] = int(st["step"].item())
+                for k in ("exp_avg", "exp_avg_sq"):
+                    t = st.get(k)
+                    if t is not None and not _same_layout(t, p):
+                        st[k] = torch.empty_strided(p.size(), p.stride(), dtype=p.dtype, device=p.device).copy_(t)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        L = _lib.load()
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L, st = _ops._L(), _ops._st()         # torch.ops.vqw.adam_step / adam_multi (hipops/library.py)
         for group in self.param_groups:
             b1, b2 = group["betas"]
             if MULTI_TENSOR and self._step_multi(L, st, group):
@@ -66,8 +82,7 @@ class Adam(torch.optim.Optimizer):
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 if not (_same_layout(m, p) and _same_layout(v, p)):
                     raise RuntimeError("Adam state layout does not match the parameter layout")
-                _lib.check(L.vqw_adam_step(ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
-                                           ctypes.c_void_p(m.data_ptr()), ctypes.c_void_p(v.data_ptr()), p.numel(),
+                _lib.check(L.vqw_adam_step(_ops._p(p), _ops._p(g), _ops._p(m), _ops._p(v), p.numel(),
                                            group["lr"], b1, b2, group["eps"], group["weight_decay"],
                                            1.0 - b1 ** t, 1.0 - b2 ** t, st), "vqw_adam_step")
         _ops.bump_weight_epoch()      # parameters changed through raw pointers: invalidate derived weight layouts
@@ -123,7 +138,7 @@ class Adam(torch.optim.Optimizer):
         table = slot[0].to(dev, non_blocking=True).view(arr.shape)
         slot[1].record(torch.cuda.current_stream())
         b1, b2 = group["betas"]
-        _lib.check(L.vqw_adam_multi(ctypes.c_void_p(table.data_ptr()), len(rows), group["lr"], b1, b2, group["eps"],
+        _lib.check(L.vqw_adam_multi(_ops._p(table), len(rows), group["lr"], b1, b2, group["eps"],
                                     group["weight_decay"], 1.0 - b1 ** t, 1.0 - b2 ** t, st), "vqw_adam_multi")
         table.record_stream(torch.cuda.current_stream())
         return True

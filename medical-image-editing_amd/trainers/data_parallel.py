@@ -39,6 +39,9 @@ class GradientAllReducer:
         # gradients that flow through autograd announce themselves via the hook; conv weight gradients written
         # out-of-band on the side stream announce themselves via hipops.ops.grad_ready_listeners (when importable)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        for p in params:           # hipops.ops.wgrad_through_autograd: these hooks do not force the autograd route
+            p.__dict__["_vqw_own_hooks"] = p.__dict__.get("_vqw_own_hooks", 0) + 1
+        self._events = {}
         self._armed = False
         self._sync_lanes = None
         try:
@@ -65,6 +68,10 @@ class GradientAllReducer:
         if p.grad is None:
             return          # hook fired for a gradient that is written out-of-band: wait for the listener
         self._seen.add(id(p))
+        if p.grad.is_cuda:
+            # the gradient was produced on the stream that announces it (a view's stream through autograd, a
+            # weight-gradient lane out-of-band): the stream that flattens the bucket orders itself after every one of them
+            self._events[id(p)] = torch.cuda.current_stream(p.grad.device).record_event()
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
@@ -72,8 +79,12 @@ class GradientAllReducer:
 
     def _launch(self, bi):
         grads = [p.grad for p in self.buckets[bi]]
-        if self._sync_lanes is not None:
-            self._sync_lanes()      # the bucket's gradients were written on several weight-gradient lanes
+        if grads[0].is_cuda:
+            cur = torch.cuda.current_stream(grads[0].device)
+            for p in self.buckets[bi]:
+                ev = self._events.pop(id(p), None)
+                if ev is not None:
+                    cur.wait_event(ev)
         # flatten in MEMORY order (grads may be channels_last): view each as its dense storage
         views = [_dense_1d(g) for g in grads]
         flat = torch.cat(views)

@@ -190,3 +190,85 @@ def test_vq_reference_dist_mode_matches_reference_fixture(tmp_path):
     for p in procs:
         o = p.communicate(timeout=300)[0].decode()
         assert p.returncode == 0, o[-3000:]
+
+
+DDP_WORKER = r'''
+import copy, os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "medical-image-editing_amd"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from torch.nn.parallel import DistributedDataParallel as DDP
+from networks import UNetEncoder, UNetDecoder
+from trainers.data_parallel import GradientAllReducer
+from hipops import ops
+from oracle.vqwnet_ref import synthetic_slices
+torch.manual_seed(5)
+K = 10
+enc0 = UNetEncoder(1, [16, 32, 32, 64, 64], K, 0.99, "torch", False, 1, True)
+dec0 = UNetDecoder(16, 1, [32, 32, 64, 64, 128], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
+img, _ = synthetic_slices(4, 64, 11)
+x = img[rank * 2:(rank + 1) * 2].cuda()
+
+def loss_of(enc, dec):
+    q, commit, ids = enc(x)
+    rec = dec(q)
+    return ops.mse_loss(rec, x) + commit
+
+# (A) torch DistributedDataParallel: its reducer hears of a gradient through the parameter's AccumulateGrad hook
+encA, decA = copy.deepcopy(enc0).cuda(), copy.deepcopy(dec0).cuda()
+encA.eval(); decA.train()          # VQ in eval mode: no EMA update in this comparison; SyncBN statistics in the decoder
+dA_enc, dA_dec = DDP(encA, device_ids=[0]), DDP(decA, device_ids=[0])
+loss_of(dA_enc, dA_dec).backward()
+torch.cuda.synchronize()
+gA = {("enc." + k): p.grad.clone() for k, p in encA.named_parameters()}
+gA.update({("dec." + k): p.grad.clone() for k, p in decA.named_parameters()})
+assert all(g is not None for g in gA.values())
+
+# (B) this package's reducer: out-of-band weight gradients on side streams, bucketed all-reduce
+encB, decB = copy.deepcopy(enc0).cuda(), copy.deepcopy(dec0).cuda()
+encB.eval(); decB.train()
+params = [p for p in list(decB.parameters())[::-1] + list(encB.parameters())[::-1] if p.requires_grad]
+red = GradientAllReducer(params, bucket_bytes=1 << 20)
+red.prepare()
+ops.reset_pending(params)
+loss_of(encB, decB).backward()
+red.finish()
+torch.cuda.synchronize()
+gB = {("enc." + k): p.grad for k, p in encB.named_parameters()}
+gB.update({("dec." + k): p.grad for k, p in decB.named_parameters()})
+gmax = max(float(g.norm()) for g in gA.values())
+worst = 0.0
+for k in gA:
+    na = float(gA[k].norm())
+    if na < 1e-6 * gmax:
+        continue
+    e = float((gA[k] - gB[k]).norm()) / na
+    worst = max(worst, e)
+    assert e < 2e-4, (k, e)
+# and DDP really averaged over the ranks: the gradient is not the local one
+encC, decC = copy.deepcopy(enc0).cuda(), copy.deepcopy(dec0).cuda()
+encC.eval(); decC.train()
+loss_of(encC, decC).backward()
+torch.cuda.synchronize()
+k = "dec.conv1x1.weight"
+assert float((decC.conv1x1.weight.grad - gA[k]).norm()) > 1e-3 * float(gA[k].norm())
+print("rank", rank, "worst DDP-vs-reducer gradient difference %.2e" % worst)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_torch_ddp_wrapper_equals_gradient_all_reducer(tmp_path):
+    """The modules under torch.nn.parallel.DistributedDataParallel (what the reference launches with, run_vqwnet.py:112-121;
+    gloo, two ranks on one GPU): inside a DDP forward the conv weight gradients take the autograd route, so DDP's reducer
+    sees every parameter; the averaged gradients equal the ones this package's own reducer produces."""
+    script = tmp_path / "ddpw.py"
+    script.write_text(DDP_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29661", WORLD_SIZE="2", RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o = p.communicate(timeout=500)[0].decode()
+        assert p.returncode == 0, o[-3000:]

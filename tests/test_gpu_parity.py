@@ -296,6 +296,32 @@ def test_conv_epilogue_statistics(case):
     assert_close(a, r, 2e-6, "instance norm from conv partials")
 
 
+def test_up_block_with_cout_not_multiple_of_four():
+    """StyledResUpBlock whose out_channels is not a multiple of 4 (10): the collapsed 3x3-over-upsample form needs
+    Cout % 4 == 0 for its input gradient, so the layer must take a route it can also back-propagate."""
+    from networks import blocks as Bk
+    from oracle import vqwnet_ref as O
+    torch.manual_seed(5)
+    m = Bk.StyledResUpBlock(16, 8, 10, use_pixel_shuffle=False)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    down, skip, r = torch.randn(2, 16, 8, 8), torch.randn(2, 8, 16, 16), torch.randn(2, 10, 16, 16)
+    P = {"m." + k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for k in O.trainable_keys(P):
+        P[k].requires_grad_(True)
+    d64, s64 = down.double().requires_grad_(True), skip.double().requires_grad_(True)
+    y64 = O.styled_res_up_block(P, "m", d64, s64, True)
+    (y64 * r.double()).sum().backward()
+    mm = m.to(DEV).train()
+    d_, s_ = down.to(DEV).requires_grad_(True), skip.to(DEV).requires_grad_(True)
+    y = mm(d_, s_)
+    (y * r.to(DEV)).sum().backward()
+    assert_close(y, y64, 1e-5, "y")
+    assert_close(d_.grad, d64.grad, 1e-5, "g_down")
+    assert_close(s_.grad, s64.grad, 1e-5, "g_skip")
+    for k, p in mm.named_parameters():
+        assert_close(p.grad, P["m." + k].grad, 2e-5, "g " + k, atol=2e-5)     # conv1 / conv2 biases sit in front of a BatchNorm: zero + noise
+
+
 def test_conv_epilogue_statistics_need_whole_tiles():
     """The partials carry no pixel count: a plane whose height is not a multiple of the tile height is not served (the norm
     then reduces the plane itself) and the result is the same."""
@@ -1374,3 +1400,79 @@ def test_conv_tensors_beyond_4gib_run_as_image_groups():
     assert torch.equal(gx[:h], gx1) and torch.equal(gx[h:], gx2)
     assert_close(gw, gw1 + gw2, 2e-5, "dw over image groups")
     assert_close(gb, gb1 + gb2, 1e-4, "db over image groups", atol=1e-2)
+
+
+# --------------------------------------------------------------------------------------------------
+# dispatcher operators (the boundary is a set of PyTorch custom ops)
+# --------------------------------------------------------------------------------------------------
+def test_functional_dispatcher_ops_match_module_ops_and_pass_opcheck():
+    """torch.ops.vqw.{conv2d, instance_norm, vq_forward, embed_cross_loss, res_tail}: functional operators with
+    register_autograd formulas over the kernel operators - same values and gradients as the autograd.Function operators
+    the modules use, and torch.library.opcheck (schema, fake tensors, autograd registration) is clean."""
+    ops = _ops()
+    from hipops import functional  # noqa: F401  (registers the operators)
+    tests = ("test_schema", "test_autograd_registration", "test_faketensor")
+    torch.manual_seed(0)
+    # conv2d: plain, up-sampled + concat, fused ReLU
+    for (Ci, Cs, Co, up, relu, dil) in [(16, 0, 32, False, False, 1), (32, 16, 32, True, True, 1), (16, 0, 16, False, False, 6)]:
+        x = torch.randn(2, Ci, 8 if up else 16, 8 if up else 16, device=DEV, requires_grad=True)
+        sk = torch.randn(2, Cs, 16, 16, device=DEV, requires_grad=True) if Cs else None
+        w = (torch.randn(Co, Ci + Cs, 3, 3, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        b = torch.randn(Co, device=DEV, requires_grad=True)
+        r = torch.randn(2, Co, 16, 16, device=DEV)
+        y = torch.ops.vqw.conv2d(x, w, b, dil, up, sk, relu)
+        gs = torch.autograd.grad((y * r).sum(), [t for t in (x, w, b, sk) if t is not None])
+        x2, w2, b2 = x.detach().requires_grad_(True), w.detach().requires_grad_(True), b.detach().requires_grad_(True)
+        s2 = sk.detach().requires_grad_(True) if sk is not None else None
+        y2 = ops.conv2d(x2, w2, b2, dilation=dil, up2x=up, skip=s2, relu=relu)
+        assert torch.equal(y, y2)
+        (y2 * r).sum().backward()
+        torch.cuda.synchronize()
+        for a, ref in zip(gs, [t.grad for t in (x2, w2, b2, s2) if t is not None]):
+            assert_close(a, ref, 1e-6, "conv2d functional grad", atol=1e-7)
+        torch.library.opcheck(torch.ops.vqw.conv2d.default, (x, w, b, dil, up, sk, relu), test_utils=tests)
+    # instance norm (+ReLU)
+    x = torch.randn(2, 16, 12, 12, device=DEV, requires_grad=True)
+    r = torch.randn(2, 16, 12, 12, device=DEV)
+    y, mr = torch.ops.vqw.instance_norm(x, True, 1e-5)
+    (gx,) = torch.autograd.grad((y * r).sum(), [x])
+    x2 = x.detach().requires_grad_(True)
+    y2 = ops.instance_norm(x2, relu=True)
+    (y2 * r).sum().backward()
+    assert torch.equal(y, y2) and torch.equal(gx, x2.grad)
+    torch.library.opcheck(torch.ops.vqw.instance_norm.default, (x, True, 1e-5), test_utils=tests)
+    # VQ forward (search + gather + commit) with the straight-through backward
+    embed = torch.randn(10, 16, device=DEV)
+    x = torch.randn(2, 16, 8, 8, device=DEV, requires_grad=True)
+    r = torch.randn(2, 16, 8, 8, device=DEV)
+    q, commit, ids = torch.ops.vqw.vq_forward(x, embed, 1)
+    (gx,) = torch.autograd.grad((q * r).sum() + 3.0 * commit, [x])
+    x2 = x.detach().requires_grad_(True)
+    q2, c2, ids2 = ops.vq_quantize(x2, embed.clone(), torch.zeros(10, device=DEV), embed.t().contiguous(), False, 0.9, 1e-5, id_base=1)
+    ((q2 * r).sum() + 3.0 * c2).backward()
+    assert torch.equal(ids, ids2) and torch.equal(q, q2) and torch.equal(commit, c2) and torch.equal(gx, x2.grad)
+    torch.library.opcheck(torch.ops.vqw.vq_forward.default, (x, embed, 1), test_utils=tests)
+    # cross loss on integer labels
+    lab = torch.randint(0, 11, (2, 8, 8), device=DEV, dtype=torch.int32)
+    e = torch.randn(2, 16, 8, 8, device=DEV, requires_grad=True)
+    loss, coef = torch.ops.vqw.embed_cross_loss(e, lab, embed)
+    (ge,) = torch.autograd.grad(2.0 * loss, [e])
+    e2 = e.detach().requires_grad_(True)
+    l2 = ops.cross_loss_labels(e2, lab, embed)
+    (2.0 * l2).backward()
+    assert torch.equal(loss, l2) and torch.equal(ge, e2.grad)
+    torch.library.opcheck(torch.ops.vqw.embed_cross_loss.default, (e, lab, embed), test_utils=tests)
+    # ResBlock tail
+    a = torch.randn(2, 16, 8, 8, device=DEV, requires_grad=True)
+    b = torch.randn(2, 16, 8, 8, device=DEV, requires_grad=True)
+    rp, ro = torch.randn(2, 16, 4, 4, device=DEV), torch.randn(2, 16, 8, 8, device=DEV)
+    pooled, out = torch.ops.vqw.res_tail(a, b)
+    ga, gb = torch.autograd.grad((pooled * rp).sum() + (out * ro).sum(), [a, b])
+    a2, b2 = a.detach().requires_grad_(True), b.detach().requires_grad_(True)
+    p2, o2 = ops.res_tail(a2, b2)
+    ((p2 * rp).sum() + (o2 * ro).sum()).backward()
+    assert torch.equal(pooled, p2) and torch.equal(out, o2) and torch.equal(ga, a2.grad) and torch.equal(gb, b2.grad)
+    torch.library.opcheck(torch.ops.vqw.res_tail.default, (a, b), test_utils=tests)
+    # kernel operators carry their mutation annotations: the in-place codebook update
+    sch = str(torch.ops.vqw.vq_ema_update.default._schema)
+    assert "Tensor(a!)? embed" in sch and "Tensor(b!)? cluster_size" in sch and "Tensor(c!)? embed_avg" in sch

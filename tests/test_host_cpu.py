@@ -84,6 +84,51 @@ def test_module_contract():
         UNetDecoder(16, 1, [32, 64], use_styled_up_block=False)         # unet_decoder.py:35
 
 
+def test_adam_loads_stock_torch_state_dict():
+    """hipops.Adam.load_state_dict takes the state of a torch.optim.Adam that trained NCHW parameters (a reference
+    checkpoint's optimizer_states): moments re-laid out like the channels_last parameters, tensor `step` -> int."""
+    from hipops import Adam
+    from hipops.optim import _same_layout
+    torch.manual_seed(0)
+    ref = torch.nn.Conv2d(8, 4, 3)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    for _ in range(2):
+        opt.zero_grad(); ref(torch.randn(2, 8, 6, 6)).pow(2).sum().backward(); opt.step()
+    sd = opt.state_dict()
+    mine = torch.nn.Conv2d(8, 4, 3)
+    mine.weight.data = mine.weight.data.contiguous(memory_format=torch.channels_last)
+    o2 = Adam(mine.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    o2.load_state_dict(sd)
+    st = o2.state[mine.weight]
+    assert st["step"] == 2 and isinstance(st["step"], int)
+    assert _same_layout(st["exp_avg"], mine.weight) and _same_layout(st["exp_avg_sq"], mine.weight)
+    assert torch.equal(st["exp_avg"], opt.state[ref.weight]["exp_avg"])          # same values, other strides
+    assert torch.equal(o2.state[mine.bias]["exp_avg_sq"], opt.state[ref.bias]["exp_avg_sq"])
+
+
+def test_dispatcher_registration_matches_header():
+    """Every kernel entry point of the C ABI is a torch.ops.vqw operator whose schema (incl. the mutation annotations) is
+    derived from the header prototype; host-side queries stay C calls; a CPU tensor reaches no kernel."""
+    from hipops import library, _lib
+    ops = library.register()
+    protos = library.parse_header()
+    assert set(protos) == set(_lib.SIGNATURES)
+    kernels = {n for n, (r, a) in protos.items() if a and a[-1][0] == "stream" and not n.endswith("_host")}
+    assert set(ops) == kernels and len(kernels) >= 70
+    sch = str(torch.ops.vqw.vq_ema_update.default._schema)
+    assert "Tensor(a!)? embed" in sch and "Tensor(b!)? cluster_size" in sch and "Tensor(c!)? embed_avg" in sch and "Tensor? stats" in sch
+    sch = str(torch.ops.vqw.conv2d_fwd.default._schema)
+    assert "Tensor? src0" in sch and "Tensor(a!)? y" in sch and sch.endswith("-> ()")
+    assert "Tensor(a!)? p," in str(torch.ops.vqw.adam_step.default._schema) and "Tensor? g," in str(torch.ops.vqw.adam_step.default._schema)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.vqw.add(torch.zeros(4), torch.zeros(4), torch.zeros(4), 4, 0)
+    # fake kernels: traced under FakeTensorMode without touching a device
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        a = torch.empty(8, device="cuda")
+        assert torch.ops.vqw.add(a, a, torch.empty(8, device="cuda"), 8, 0) is None
+
+
 def test_load_json_false_becomes_none(tmp_path):
     from utils import load_json, get_world_size, is_distributed
     p = tmp_path / "c.json"
