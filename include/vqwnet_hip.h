@@ -194,6 +194,11 @@ int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int id_base, fl
  * sum_scale multiplies embed_sum before the EMA (1/world_size in the reference's quirk mode). */
 int vqw_vq_ema_update(const double* stats, float* embed, float* cluster_size, float* embed_avg,
                       float momentum, float eps, float sum_scale, int D, int K, void* stream);
+/* One Lloyd iteration of the k-means codebook initialisation (unet_encoder.py:66-91): centres[k] <- mean of its members
+ * from the statistics vqw_vq_fwd leaves (codes without members keep their centre).  shift[0] = sum_k |delta_k|_2,
+ * shift[1] = number of empty codes.  ws: 16 K bytes. */
+int vqw_kmeans_update(const double* stats, float* centres, double* shift, void* ws, size_t ws_bytes, int D, int K,
+                      void* stream);
 int vqw_vq_lookup(const int64_t* ids, const float* embed, const uint8_t* mask /*nullable*/,
                   const float* scale_dev /*nullable, 1 float*/, float* out, long Npix, int D, int K,
                   void* stream);

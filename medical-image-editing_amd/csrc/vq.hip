@@ -768,6 +768,47 @@ extern "C" int vqw_vq_ema_update(const double* stats, float* embed, float* clust
     return VQW_OK;
 }
 
+// One Lloyd update of the k-means codebook initialisation (unet_encoder.py:66-91; kmeans_pytorch's loop): centre k
+// becomes the mean of its members (statistics of vqw_vq_fwd); a code without members keeps its centre (kmeans_pytorch
+// 0.3.0 writes NaN there).  shift[0] = sum_k |new_k - old_k|_2 (its convergence measure), shift[1] = #empty codes.
+__global__ void __launch_bounds__(256) k_kmeans_update(const double* __restrict__ stats, float* __restrict__ centres,
+                                                       double* __restrict__ part, int D, int K) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= K) return;
+    const double cnt = stats[k];
+    double d2 = 0.0;
+    if (cnt > 0.0)
+        for (int d = lane; d < D; d += 64) {
+            const float nv = (float)(stats[K + (size_t)d * K + k] / cnt), ov = centres[(size_t)k * D + d];
+            centres[(size_t)k * D + d] = nv;
+            d2 += ((double)nv - ov) * ((double)nv - ov);
+        }
+    d2 = wave_sum_d(d2);
+    if (lane == 0) { part[2 * k] = sqrt(d2); part[2 * k + 1] = cnt > 0.0 ? 0.0 : 1.0; }
+}
+__global__ void k_kmeans_shift(const double* __restrict__ part, double* __restrict__ shift, int K) {
+    __shared__ double sa[256], sb[256];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) { a += part[2 * k]; b += part[2 * k + 1]; }
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) { sa[threadIdx.x] += sa[threadIdx.x + w]; sb[threadIdx.x] += sb[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { shift[0] = sa[0]; shift[1] = sb[0]; }
+}
+extern "C" int vqw_kmeans_update(const double* stats, float* centres, double* shift, void* ws, size_t ws_bytes, int D, int K,
+                                 void* stream) {
+    VQW_CHECK(stats && centres && shift && ws && D > 0 && K > 0, "vqw_kmeans_update: bad arguments");
+    VQW_CHECK(ws_bytes >= (size_t)2 * K * sizeof(double), "vqw_kmeans_update: workspace too small (needs 16 K bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    k_kmeans_update<<<ceil_div(K, 4), 256, 0, st>>>(stats, centres, (double*)ws, D, K);
+    k_kmeans_shift<<<1, 256, 0, st>>>((const double*)ws, shift, K);
+    VQW_LAUNCH_CHECK("vqw_kmeans_update");
+    return VQW_OK;
+}
+
 __global__ void k_vq_lookup(const int64_t* __restrict__ ids, const float* __restrict__ embed, const uint8_t* __restrict__ mask,
                             const float* __restrict__ scale, float* __restrict__ out, long total, int D, int K) {
     long stride = (long)gridDim.x * blockDim.x;

@@ -76,6 +76,7 @@ SIGNATURES = {
     "vqw_vq_plan": (c_i, [c_i, c_i]),
     "vqw_vq_fwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_sz, c_l, c_i, c_i, c_p]),
     "vqw_vq_ema_update": (c_i, [c_p, c_p, c_p, c_p, c_f, c_f, c_f, c_i, c_i, c_p]),
+    "vqw_kmeans_update": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_p]),
     "vqw_vq_lookup": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_p]),
     "vqw_vq_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_p]),
     "vqw_mask_scale": (c_i, [c_p, c_p, c_p, c_p, c_l, c_p]),

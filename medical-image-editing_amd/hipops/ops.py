@@ -1175,6 +1175,39 @@ def vq_quantize(x, embed, cluster_size, embed_avg, training, momentum, eps, dist
     return _VQ.apply(x, embed, cluster_size, embed_avg, bool(training), float(momentum), float(eps), dist_mode, int(id_base))
 
 
+def kmeans_codebook(features, dict_size, seed=0, tol=1e-4, max_iter=100):
+    """Lloyd's k-means over pixel features (P, D) -> centres (K, D): what kmeans_pytorch.kmeans (the reference's codebook
+    initialisation, unet_encoder.py:77-82) computes.  Own semantics (the dependency is absent, parity unpinned): centres
+    start from K distinct random rows (seeded), an iteration = nearest-centre assignment + per-centre mean (the VQ search /
+    statistics kernels and vqw_kmeans_update), empty clusters keep their centre, stop when (sum_k |delta_k|)^2 < tol as
+    kmeans_pytorch does, or after max_iter.  Returns (centres, list of (inertia, shift, empty codes) per iteration)."""
+    _dev(features)
+    P, D = features.shape
+    if P < dict_size:
+        raise RuntimeError("k-means needs at least dict_size = %d feature rows, got %d" % (dict_size, P))
+    L = _L()
+    x = features.detach().contiguous().float()
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    centres = x[torch.randperm(P, generator=g)[:dict_size].to(x.device)].clone()
+    ids = torch.empty(P, dtype=torch.int64, device=x.device)
+    q = torch.empty_like(x)
+    commit = torch.empty((), dtype=torch.float32, device=x.device)
+    stats = torch.empty(dict_size + D * dict_size, dtype=torch.float64, device=x.device)
+    shift = torch.empty(2, dtype=torch.float64, device=x.device)
+    ws = _ws(L.vqw_vq_ws_bytes(P, D, dict_size), x)
+    ws2 = _ws(16 * dict_size, x)
+    history = []
+    for _ in range(int(max_iter)):
+        _lib.check(L.vqw_vq_fwd(_p(x), _p(centres), _p(ids), 0, _p(q), _p(commit), _p(stats), _p(ws), ws.numel(), P, D, dict_size, _st()),
+                   "vqw_vq_fwd")
+        _lib.check(L.vqw_kmeans_update(_p(stats), _p(centres), _p(shift), _p(ws2), ws2.numel(), D, dict_size, _st()), "vqw_kmeans_update")
+        sh = shift.tolist()                      # one host sync per iteration of a one-off initialisation
+        history.append((float(commit) * D, sh[0], int(sh[1])))       # commit = mean squared distance per element -> per row
+        if sh[0] ** 2 < tol:
+            break
+    return centres, history
+
+
 def vq_lookup(ids, embed, mask=None, scale=None):
     """embed[ids] as (N,D,H,W) NHWC; optional mask (uint8 (N,H,W)) and device scalar scale."""
     _dev(ids, embed)

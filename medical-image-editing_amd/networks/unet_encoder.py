@@ -34,11 +34,28 @@ class UNetEncoder(nn.Module):
         return 'UNetEncoder'
 
     def initialize_embed(self, embed, rank):
-        """Upstream runs a one-off k-means (third-party kmeans_pytorch, unet_encoder.py:66-91) over the
-        gathered feature maps.  That dependency is not part of this build: supply the codebook
-        (`encoder.vq.embed.copy_(centres)`) and construct with init_embed=True."""
-        raise RuntimeError("k-means codebook initialisation is not available; load a codebook into "
-                           "encoder.vq.embed and pass init_embed=True (config use_init_embed falsy)")
+        """One-off k-means initialisation of the codebook from the first batch's feature maps (unet_encoder.py:66-91):
+        the ranks' features are all-gathered, rank 0 clusters them and broadcasts `vq.embed`.  Only `vq.embed` changes,
+        as upstream (`embed_avg` / `cluster_size` keep their constructor values).  kmeans_pytorch is not available
+        offline: hipops.ops.kmeans_codebook restates Lloyd's iteration on the VQ kernels (own semantics, documented
+        there); `kmeans_seed` / `kmeans_max_iter` are attributes of this module."""
+        import torch.distributed as dist
+        feats = embed.detach()
+        on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if on:
+            parts = [torch.zeros_like(feats) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, feats.contiguous())
+            feats = torch.cat(parts, dim=0)
+        is_root = (not on) or dist.get_rank() == 0
+        if is_root:
+            rows = feats.permute(0, 2, 3, 1).reshape(-1, self.dims)
+            centres, self.kmeans_history = ops.kmeans_codebook(rows, self.dict_size, seed=getattr(self, "kmeans_seed", 0),
+                                                               max_iter=getattr(self, "kmeans_max_iter", 100))
+            with torch.no_grad():
+                self.vq.embed.copy_(centres)
+        if on:
+            dist.broadcast(self.vq.embed, 0)
+        self.init_embed = True
 
     def feature_extraction(self, x):
         return run_half(self, 1, self._levels, x)

