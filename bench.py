@@ -42,6 +42,17 @@ def synthetic_batch(batch, size, seed, device):
     return img.to(device), noise.to(device)
 
 
+def csrc_digest():
+    """sha1 over the convolution kernel sources: ties a committed PMC traffic file to the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "medical-image-editing_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("conv") and f.endswith((".hip", ".h")) or f == "mfma_util.h":
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def host_cores():
     """Usable host cores: min(affinity, cgroup CPU quota), capped at 16 (the CPU share of a 1-GPU box)."""
     n = os.cpu_count() or 1
@@ -58,33 +69,41 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(size, batch, steps):
-    """The oracle's training step on the host cores (bounded sample of the same workload)."""
+def cpu_baseline(size):
+    """The oracle's training step on the host cores, a bounded sample of the same workload:
+    batch 2 at `size`: one warm-up + 3 timed steps on all usable cores (`value`), 2 more timed steps on 8 threads
+    (comparable with the reference's own 0.31 images/s measured on 8 cores in the build container); and BASELINE
+    config 1 (32x32, batch 4), 3 timed steps."""
     from oracle import vqwnet_ref as O
     from networks import UNetEncoder, UNetDecoder
     cores = host_cores()
-    torch.set_num_threads(cores)
-    print("[bench] cpu_baseline: %d threads, batch %d at %dx%d" % (cores, batch, size, size), file=sys.stderr, flush=True)
-    torch.manual_seed(0)
-    enc = UNetEncoder(1, [16, 32, 64, 128, 256], 10, 0.999, 'torch', False, 1, True)
-    dec = UNetDecoder(16, 1, [32, 64, 128, 256, 512], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
-    PE = {k: v.detach().clone().contiguous() for k, v in enc.state_dict().items()}
-    PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
-    cfg = dict(dict_size=10, margin=0.5, border=0, momentum=0.999,
-               weights=dict(commit=1.0, cross=1.0, dist=1.0, reg=1.0, recon=1.0),
-               optim=dict(lr=1e-4, betas=(0.5, 0.999), weight_decay=0.0))
-    tr = O.FirstStepTrainer(PE, PD, cfg)
-    img, noise = O.synthetic_slices(batch, size, 1234)
-    tr.step(img, noise)                                   # warm-up (allocator, oneDNN primitives)
-    t0 = time.perf_counter()
-    for s in range(steps):
-        img, noise = O.synthetic_slices(batch, size, 1235 + s)
-        tr.step(img, noise)
-        print("[bench] cpu_baseline step %d: %.1f s elapsed" % (s, time.perf_counter() - t0), file=sys.stderr, flush=True)
-    dt = (time.perf_counter() - t0) / steps
-    return dict(value=batch / dt, unit="images/sec", cores=cores, kind="port",
-                sample="%d steps of the oracle's first training step, batch %d at %dx%d, torch %s CPU (fp32)"
-                       % (steps, batch, size, size, torch.__version__))
+
+    def run(sz, batch, threads, steps, warm):
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        enc = UNetEncoder(1, [16, 32, 64, 128, 256], 10, 0.999, 'torch', False, 1, True)
+        dec = UNetDecoder(16, 1, [32, 64, 128, 256, 512], use_dropblock=False, dropped_skip_layers=[], use_pixel_shuffle=False)
+        PE = {k: v.detach().clone().contiguous() for k, v in enc.state_dict().items()}
+        PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
+        cfg = dict(dict_size=10, margin=0.5, border=0, momentum=0.999,
+                   weights=dict(commit=1.0, cross=1.0, dist=1.0, reg=1.0, recon=1.0),
+                   optim=dict(lr=1e-4, betas=(0.5, 0.999), weight_decay=0.0))
+        tr = O.FirstStepTrainer(PE, PD, cfg)
+        for s in range(warm):
+            tr.step(*O.synthetic_slices(batch, sz, 1234))   # allocator, oneDNN primitives
+        t0 = time.perf_counter()
+        for s in range(steps):
+            tr.step(*O.synthetic_slices(batch, sz, 1235 + s))
+            print("[bench] cpu_baseline %dx%d batch %d, %d threads, step %d: %.1f s elapsed"
+                  % (sz, sz, batch, threads, s, time.perf_counter() - t0), file=sys.stderr, flush=True)
+        return batch * steps / (time.perf_counter() - t0)
+    v_all = run(size, 2, cores, 3, 1)
+    v_8 = run(size, 2, min(8, cores), 2, 0) if cores > 8 else v_all
+    v_c1 = run(32, 4, cores, 3, 1)
+    return dict(value=v_all, unit="images/sec", cores=cores, kind="port", value_8_threads=v_8, config1_32x32_batch4_images_per_sec=v_c1,
+                sample="the oracle's first training step (oracle/vqwnet_ref.py, torch %s CPU, fp32): batch 2 at %dx%d, 3 timed steps after "
+                       "1 warm-up on %d threads (value), 2 timed steps on 8 threads (value_8_threads); BASELINE config 1 (32x32, "
+                       "batch 4), 3 timed steps on %d threads" % (torch.__version__, size, size, cores, cores))
 
 
 def main():
@@ -92,8 +111,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="source images per GPU per step")
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=None, help="source images per GPU per step (default: the config's batch_size)")
+    ap.add_argument("--size", type=int, default=None, help="slice size (default: the config's image_size)")
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "baseline2_256x256_b32_1gpu.json"),
+                    help="reference-style JSON config (configs/); --batch / --size override its dataset section")
+    ap.add_argument("--serial-steps", type=int, default=5, help="steps of the serialised per-kernel timing pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -119,11 +141,18 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from hipops import _lib
-    from trainers import FirstStepTrainer
+    from trainers import build_first_step_trainer
+    from utils import load_json
     L = _lib.load()
 
+    cfg = load_json(args.config)                           # the reference's config keys (trainers/base.py:164-278)
+    if args.batch is None:
+        args.batch = int(cfg.dataset.batch_size)
+    if args.size is None:
+        args.size = int(cfg.dataset.image_size)
+    g = cfg.model.vqmodel
     torch.manual_seed(0)                                   # identical replicas on every rank
-    tr = FirstStepTrainer(device=dev, data_parallel=world > 1)
+    tr = build_first_step_trainer(cfg, device=dev, data_parallel=world > 1)
     pool = [synthetic_batch(args.batch, args.size, 1234 + 1000 * rank + s, dev) for s in range(4)]
 
     # the dependency chain of the step runs on a high-priority stream, the off-chain weight gradients on the (normal
@@ -175,7 +204,7 @@ def main():
         step(0)
         torch.cuda.synchronize()
         _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
-        for i in range(2):
+        for i in range(args.serial_steps):
             step(1 + i)
         torch.cuda.synchronize()
         _lib.check(L.vqw_profile_end(prof_x), "vqw_profile_end")
@@ -203,25 +232,30 @@ def main():
                                      avg_launch_ms=ms / n, gflop_per_launch=fl / n / 1e9, bytes_per_launch=by / n)
             return out
         kern_c = families(prof, args.steps)          # timed region: three streams share the GPU
-        kern_x = families(prof_x, 2)                 # serialised pass: each kernel alone on the GPU
+        kern_x = families(prof_x, args.serial_steps)  # serialised pass: each kernel alone on the GPU
         roofline = None
         primary = kern_x if kern_x else kern_c
         if primary:
             dom = max(primary, key=lambda k: primary[k]["ms_per_step"])
             ach = primary[dom]["tflops"]
-            # HBM bytes per launch of that family from the committed PMC passes of this same command
-            # (profiles/r01_hbm_traffic.json, produced by tools/pmc_traffic.py); null when the file is absent
-            traffic = None
+            # HBM bytes per launch of that family: NOT measured by this run (PMC counters need rocprofv3 around the
+            # process) but read from the committed PMC passes of this same command (tools/pmc_traffic.py); the file
+            # names the digest of the kernel sources it was taken with, and a stale or missing file gives null
+            traffic, traffic_source = None, "none: profiles/r02_hbm_traffic.json missing"
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-                traffic = tj["families"][dom]["hbm_bytes_per_launch"]
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
+                if tj.get("csrc_digest") == csrc_digest():
+                    traffic = tj["families"][dom]["hbm_bytes_per_launch"]
+                    traffic_source = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel sources %s)" % tj["csrc_digest"][:12]
+                else:
+                    traffic_source = "none: profiles/r02_hbm_traffic.json was taken with other kernel sources"
             except Exception:
                 pass
             roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s",
-                            frac=ach / (PEAK_FP32_MFMA / 1e12), traffic=traffic,
+                            frac=ach / (PEAK_FP32_MFMA / 1e12), traffic=traffic, traffic_source=traffic_source,
                             algorithmic_bytes_per_launch=primary[dom]["bytes_per_launch"],
                             avg_launch_ms=primary[dom]["avg_launch_ms"],
-                            measured=("HIP events on the launch stream around every launch of the family, over 2 steps run "
+                            measured=("HIP events on the launch stream around every launch of the family, over the steps run "
                                       "right after the timed region with the streams serialised (VQW_WGRAD_STREAM=0, "
                                       "VQW_CONCURRENT_VIEWS=0 equivalent): each kernel alone on the GPU"
                                       if kern_x else "HIP events over the timed region"),
@@ -236,21 +270,29 @@ def main():
                          "is what the concurrency buys")
         per_gpu = imgs / world
         scale = (args.size / 256.0) ** 2
+        # FLOPs the kernels actually executed per step (collapsed up-sampled convs at 4/9 of the reference's count), from the
+        # same launch records: hardware utilisation; the algorithmic figure prices the step at the reference's conv FLOPs
+        executed = sum(prof[4 * f + 2] for f in range(4)) / args.steps if timing else None
+        rcfg = list(g.enc_filters) == [16, 32, 64, 128, 256] and list(g.dec_filters) == [32, 64, 128, 256, 512]
         line = {
             "metric": "images/sec (train step, 256x256 2D slices)", "value": imgs, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "VQ-W-Net first training step (2 views: encoder+VQ+decoder fwd/bwd + 2x Adam), "
-                                   "R-cfg filters enc [16,32,64,128,256] dec [32,64,128,256,512], dict_size 10, "
-                                   "%dx%d 1-ch synthetic slices" % (args.size, args.size),
+                                   "filters enc %s dec %s, dict_size %d, %dx%d 1-ch synthetic slices (%s)"
+                                   % (list(g.enc_filters), list(g.dec_filters), g.dict_size, args.size, args.size, os.path.basename(args.config)),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world},
-            "step_fraction_of_fp32_mfma_roofline": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA,
-            "step_fraction_of_hbm_roofline": per_gpu * BYTES_PER_IMAGE * scale / PEAK_HBM,
+            # whole step against the two rooflines.  "algorithmic" = the reference's conv FLOPs / bytes, i.e.
+            # credit for work avoided (collapsed up-sampled layers); "executed" = FLOPs the kernels ran = hardware utilisation
+            "step_fraction_of_fp32_mfma_roofline": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA if rcfg else None,
+            "step_fraction_of_fp32_mfma_roofline_algorithmic": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA if rcfg else None,
+            "step_fraction_of_fp32_mfma_roofline_executed": executed / (ms_per_step * 1e-3) / PEAK_FP32_MFMA if executed else None,
+            "step_fraction_of_hbm_roofline": per_gpu * BYTES_PER_IMAGE * scale / PEAK_HBM if rcfg else None,
             "loss_total": total,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.size, 1, 2)
+            line["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

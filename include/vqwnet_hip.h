@@ -226,8 +226,9 @@ int vqw_cross_loss_dense_fwd(const float* embed, const float* r_nchw, const floa
 int vqw_cross_loss_dense_bwd(const float* embed, const float* r_nchw, const float* codebook_kd,
                              const float* coef, const float* gloss, float* gembed,
                              int B, long HW, int D, int K, void* stream);
+/* l_dist / l_reg of embed_loss.py:68-88 (no gradient: the codebook is a buffer); ws: 16 K bytes */
 int vqw_codebook_losses(const float* codebook_kd, float margin, float* l_dist, float* l_reg,
-                        int D, int K, void* stream);
+                        void* ws, size_t ws_bytes, int D, int K, void* stream);
 int vqw_onehot(const int32_t* labels, float* out_nchw, int B, long HW, int n_classes, void* stream);
 int vqw_flip_labels(const int64_t* ids, int32_t* out, int border, int B, int H, int W, void* stream);
 

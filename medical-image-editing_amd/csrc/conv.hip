@@ -206,7 +206,7 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
     const double px = (double)N * H * W;
     const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
-    if (g_conv_backend == 0 && conv_stem_ok(in, Cout, ksize) && Cout == 16) {
+    if (g_conv_backend == 0 && conv_stem_wgrad_ok(in, Cout, ksize)) {
         ProfScope ps(3, flops, st, bytes);
         return conv_stem_wgrad(in, dy, dw_ohwi, dbias, wsf, N, H, W, Cout, ksize, dil, accumulate, st);
     }

@@ -71,6 +71,7 @@ int conv_k4s1_wgrad_grid(const float* x, const float* dy_grid, float* dw, float*
 
 // thin-channel streams (conv_thin.hip): 1-channel stem, 1-channel 1x1 head
 bool conv_stem_ok(const ConvIn& in, int Cout, int ks);
+bool conv_stem_wgrad_ok(const ConvIn& in, int Cout, int ks);
 int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
                   int relu, hipStream_t st);
 size_t conv_stem_wgrad_ws_floats(int Cout);

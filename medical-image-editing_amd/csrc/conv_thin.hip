@@ -115,12 +115,95 @@ __global__ void k_stem_wgrad_finalize(const float* __restrict__ part, float* __r
     else if (t == 9 && db) db[c] = acc ? db[c] + s : s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// wide stem (Cin == 1, Cout a multiple of 64: BASELINE config 4's 1 -> 256 first block).  Lanes run over the output
+// channels, so one pixel's Cout floats are one coalesced row; a thread owns 4 channels (float4) for every pixel of its
+// pixel lane and keeps their 9 tap weights (forward) or 10 partial sums (weight gradient: 9 taps + bias) in registers.
+// Forward writes / weight gradient reads N*H*W*Cout floats once: HBM-bound streams.
+__device__ __forceinline__ void stem_taps(const float* __restrict__ x, long p, int H, int W, int ks, int dil, float* v) {
+    const int xw = (int)(p % W), yh = (int)((p / W) % H), half = ks >> 1, taps = ks * ks;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int hy = yh + (t / ks - half) * dil, wx = xw + (t % ks - half) * dil;
+        v[t] = (t < taps && hy >= 0 && hy < H && wx >= 0 && wx < W) ? x[p + (long)(hy - yh) * W + (wx - xw)] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) k_stem_wide_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, long P, int H, int W, int Cout, int ks, int dil, int relu) {
+    const int C4 = Cout >> 2, taps = ks * ks;
+    const int tc = threadIdx.x % C4, tr = threadIdx.x / C4, rows = 256 / C4;     // Cout % 64 == 0 -> C4 in {16, 32, 64}
+    float wr[4][9], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        b[k] = bias ? bias[4 * tc + k] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[k][t] = t < taps ? w[(4 * tc + k) * taps + t] : 0.f;
+    }
+    for (long p = (long)blockIdx.x * rows + tr; p < P; p += (long)gridDim.x * rows) {
+        float v[9];
+        stem_taps(x, p, H, W, ks, dil, v);
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = b[k];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(v[t], wr[k][t], a);
+            r[k] = relu ? fmaxf(a, 0.f) : a;
+        }
+        ((float4*)(y + p * Cout))[tc] = float4{r[0], r[1], r[2], r[3]};
+    }
+}
+// part[block][Cout][10]: per-block sums in pixel order (a thread's pixels strided by the grid), the block's pixel lanes
+// folded through LDS in lane order; k_stem_wgrad_finalize sums the blocks.
+__global__ void __launch_bounds__(256) k_stem_wide_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                         long P, int H, int W, int Cout, int ks, int dil) {
+    extern __shared__ float s_acc[];             // [rows][Cout][10]
+    const int C4 = Cout >> 2;
+    const int tc = threadIdx.x % C4, tr = threadIdx.x / C4, rows = 256 / C4;
+    float acc[4][10];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) acc[k][t] = 0.f;
+    for (long p = (long)blockIdx.x * rows + tr; p < P; p += (long)gridDim.x * rows) {
+        float v[10];
+        stem_taps(x, p, H, W, ks, dil, v);
+        v[9] = 1.f;
+        const float4 d = ((const float4*)(dy + p * Cout))[tc];
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int t = 0; t < 10; ++t) acc[k][t] = fmaf(dv[k], v[t], acc[k][t]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 10; ++t) s_acc[(tr * Cout + 4 * tc + k) * 10 + t] = acc[k][t];
+    __syncthreads();
+    for (int i = threadIdx.x; i < Cout * 10; i += 256) {
+        float a = s_acc[i];
+        for (int r = 1; r < rows; ++r) a += s_acc[r * Cout * 10 + i];
+        part[(long)blockIdx.x * Cout * 10 + i] = a;
+    }
+}
+static inline bool stem_wide(int Cout) { return Cout % 64 == 0 && Cout >= 128 && Cout <= 256; }
+bool conv_stem_wgrad_ok(const ConvIn& in, int Cout, int ks) {       // the weight gradient: 16 channels or the wide form
+    return in.C0 == 1 && in.C1 == 0 && !in.up0 && (ks == 1 || ks == 3) && (Cout == 16 || (Cout % 64 == 0 && Cout >= 64 && Cout <= 256));
+}
+
 bool conv_stem_ok(const ConvIn& in, int Cout, int ks) {
-    return in.C0 == 1 && in.C1 == 0 && !in.up0 && (ks == 1 || ks == 3) && (Cout == 16 || Cout == 32 || Cout == 64);
+    return in.C0 == 1 && in.C1 == 0 && !in.up0 && (ks == 1 || ks == 3) && (Cout == 16 || Cout == 32 || Cout == 64 || stem_wide(Cout));
 }
 int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
                   int relu, hipStream_t st) {
     int g = stream_grid((long)N * H * W, 256);
+    if (stem_wide(Cout)) {
+        const int rows = 256 / (Cout / 4);
+        k_stem_wide_fwd<<<stream_grid((long)N * H * W, rows), 256, 0, st>>>(in.src0, w, bias, y, (long)N * H * W, H, W, Cout, ks, dil, relu);
+        VQW_LAUNCH_CHECK("conv_stem_fwd(wide)");
+        return VQW_OK;
+    }
     if (Cout == 16) k_stem_fwd<16><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
     else if (Cout == 32) k_stem_fwd<32><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
     else k_stem_fwd<64><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
@@ -132,6 +215,13 @@ size_t conv_stem_wgrad_ws_floats(int Cout) { return (size_t)STEM_WG_BLOCKS * Cou
 int conv_stem_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, float* ws, int N, int H, int W, int Cout, int ks,
                     int dil, int acc, hipStream_t st) {
     int nb = imin(STEM_WG_BLOCKS, imax(1, (int)(((long)N * H * W + 255) / 256)));
+    if (Cout != 16) {
+        const int rows = 256 / (Cout / 4);
+        k_stem_wide_wgrad<<<nb, 256, (size_t)rows * Cout * 10 * sizeof(float), st>>>(in.src0, dy, ws, (long)N * H * W, H, W, Cout, ks, dil);
+        k_stem_wgrad_finalize<<<Cout * 10, 256, 0, st>>>(ws, dw, dbias, nb, Cout, ks * ks, acc);
+        VQW_LAUNCH_CHECK("conv_stem_wgrad(wide)");
+        return VQW_OK;
+    }
     if (Cout != 16) { vqw_set_error("conv_stem_wgrad: only Cout == 16"); return VQW_ERR_ARG; }
     k_stem_wgrad<16><<<nb, 256, 0, st>>>(in.src0, dy, ws, N, H, W, ks, dil);
     k_stem_wgrad_finalize<<<Cout * 10, 256, 0, st>>>(ws, dw, dbias, nb, Cout, ks * ks, acc);

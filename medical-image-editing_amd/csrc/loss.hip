@@ -228,39 +228,57 @@ extern "C" int vqw_cross_loss_dense_bwd(const float* embed, const float* r_nchw,
     return VQW_OK;
 }
 
-// embed_loss.py:68-88.  Single block; K^2 pairs (i == j included, each contributing (2*margin)^2).
-__global__ void k_codebook_losses(const float* __restrict__ cb, float margin, float* __restrict__ l_dist,
-                                  float* __restrict__ l_reg, int D, int K) {
-    __shared__ double s_a[16], s_b[16];
-    double dsum = 0.0, rsum = 0.0;
-    long pairs = (long)K * K;
-    for (long ij = threadIdx.x; ij < pairs; ij += blockDim.x) {
-        int i = (int)(ij / K), j = (int)(ij % K);
+// embed_loss.py:68-88: l_dist = sum_{i,j} clamp(2 margin - |c_i - c_j|, 0)^2 / (2 K (K-1)) over all K^2 pairs (i == j
+// included, each contributing (2 margin)^2, as upstream), l_reg = mean_k |c_k|.  One workgroup per row i: its four waves
+// take the partners j round-robin, lanes run over the channels (coalesced rows from L2), wave butterfly per pair, pair
+// terms summed in double in a fixed order; a second launch folds the K row partials.  (A single workgroup over the K^2
+// pairs took 123 ms at K = 1024, D = 256 - a third of BASELINE config 4's step.)
+__global__ void __launch_bounds__(256) k_codebook_rows(const float* __restrict__ cb, float margin, double* __restrict__ part, int D, int K) {
+    __shared__ double s_a[4];
+    const int i = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float* ci = cb + (long)i * D;
+    double dsum = 0.0;
+    for (int j = wv; j < K; j += 4) {
+        const float* cj = cb + (long)j * D;
         float s = 0.f;
-        for (int d = 0; d < D; ++d) { float a = cb[(long)i * D + d] - cb[(long)j * D + d]; s = fmaf(a, a, s); }
+        for (int d = lane; d < D; d += 64) { const float a = ci[d] - cj[d]; s = fmaf(a, a, s); }
+        s = wave_sum_f(s);
         float h = 2.f * margin - sqrtf(s);
         h = h > 0.f ? h : 0.f;
         dsum += (double)(h * h);
     }
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        float s = 0.f;
-        for (int d = 0; d < D; ++d) { float a = cb[(long)k * D + d]; s = fmaf(a, a, s); }
-        rsum += (double)sqrtf(s);
-    }
-    dsum = wave_sum_d(dsum);
-    rsum = wave_sum_d(rsum);
-    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = dsum; s_b[threadIdx.x >> 6] = rsum; }
+    float n2 = 0.f;
+    for (int d = lane; d < D; d += 64) n2 = fmaf(ci[d], ci[d], n2);
+    n2 = wave_sum_f(n2);
+    if (lane == 0) s_a[wv] = dsum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = 0.0, b = 0.0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += s_a[w]; b += s_b[w]; }
-        l_dist[0] = (float)(a / (2.0 * K * (K - 1)));
-        l_reg[0] = (float)(b / K);
+        part[2 * i] = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        part[2 * i + 1] = (double)sqrtf(n2);
     }
 }
-extern "C" int vqw_codebook_losses(const float* codebook_kd, float margin, float* l_dist, float* l_reg, int D, int K, void* stream) {
-    VQW_CHECK(codebook_kd && l_dist && l_reg && D > 0 && K > 1, "vqw_codebook_losses: bad arguments (K must be > 1)");
-    k_codebook_losses<<<1, 1024, 0, (hipStream_t)stream>>>(codebook_kd, margin, l_dist, l_reg, D, K);
+__global__ void __launch_bounds__(256) k_codebook_fold(const double* __restrict__ part, float* __restrict__ l_dist, float* __restrict__ l_reg, int K) {
+    __shared__ double s_a[256], s_b[256];
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) { a += part[2 * k]; b += part[2 * k + 1]; }
+    s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { s_a[threadIdx.x] += s_a[threadIdx.x + w]; s_b[threadIdx.x] += s_b[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        l_dist[0] = (float)(s_a[0] / (2.0 * K * (K - 1)));
+        l_reg[0] = (float)(s_b[0] / K);
+    }
+}
+extern "C" int vqw_codebook_losses(const float* codebook_kd, float margin, float* l_dist, float* l_reg, void* ws, size_t ws_bytes, int D,
+                                   int K, void* stream) {
+    VQW_CHECK(codebook_kd && l_dist && l_reg && ws && D > 0 && K > 1, "vqw_codebook_losses: bad arguments (K must be > 1)");
+    VQW_CHECK(ws_bytes >= (size_t)16 * K, "vqw_codebook_losses: workspace too small (needs 16 K bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    k_codebook_rows<<<K, 256, 0, st>>>(codebook_kd, margin, (double*)ws, D, K);
+    k_codebook_fold<<<1, 256, 0, st>>>((const double*)ws, l_dist, l_reg, K);
     VQW_LAUNCH_CHECK("vqw_codebook_losses");
     return VQW_OK;
 }

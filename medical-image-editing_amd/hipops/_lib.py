@@ -85,7 +85,7 @@ SIGNATURES = {
     "vqw_cross_loss_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p]),
     "vqw_cross_loss_dense_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_l, c_i, c_i, c_p]),
     "vqw_cross_loss_dense_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_p]),
-    "vqw_codebook_losses": (c_i, [c_p, c_f, c_p, c_p, c_i, c_i, c_p]),
+    "vqw_codebook_losses": (c_i, [c_p, c_f, c_p, c_p, c_p, c_sz, c_i, c_i, c_p]),
     "vqw_onehot": (c_i, [c_p, c_p, c_i, c_l, c_i, c_p]),
     "vqw_flip_labels": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_warp_image": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

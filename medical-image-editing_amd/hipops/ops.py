@@ -1291,7 +1291,8 @@ def codebook_losses(codebook_kd, margin):
     K, D = cb.shape
     ld = torch.empty((), dtype=torch.float32, device=cb.device)
     lr = torch.empty((), dtype=torch.float32, device=cb.device)
-    _lib.check(_L().vqw_codebook_losses(_p(cb), float(margin), _p(ld), _p(lr), D, K, _st()), "vqw_codebook_losses")
+    ws = _ws(16 * K, cb)
+    _lib.check(_L().vqw_codebook_losses(_p(cb), float(margin), _p(ld), _p(lr), _p(ws), ws.numel(), D, K, _st()), "vqw_codebook_losses")
     return ld, lr
 
 

@@ -72,6 +72,12 @@ CONV_CASES = [
     (1, 64, 64, 48, 0, False, 24, 3, 12, True, False),
     (2, 16, 16, 64, 0, False, 128, 3, 1, True, False),
     (3, 24, 40, 16, 0, False, 96, 3, 2, True, False),
+    # wide 1-channel stem (BASELINE config 4's first block 1 -> 256): lanes over the output channels
+    (2, 24, 20, 1, 0, False, 256, 3, 1, True, False),
+    (1, 32, 32, 1, 0, False, 256, 1, 1, False, False),
+    (2, 16, 16, 1, 0, False, 128, 3, 1, True, True),
+    (2, 16, 16, 1, 0, False, 64, 3, 1, True, False),
+    (1, 20, 12, 1, 0, False, 192, 3, 2, False, False),
 ]
 
 
@@ -595,6 +601,25 @@ def test_vq_statistics_skewed_and_exact(K, D):
     assert torch.equal(cs.cpu(), counts)
     assert torch.equal(ea.cpu(), sums.t())
     assert int(counts[0]) >= n - 97 and int((counts == 0).sum()) >= K - 98 - 1
+
+
+@pytest.mark.parametrize("K,D", [(1024, 256), (10, 16), (64, 32), (7, 5)])
+def test_codebook_losses_vs_float64(K, D):
+    """l_dist / l_reg (embed_loss.py:68-88) on the row-parallel kernel against the formula in double, incl. the i == j
+    terms and codes closer than the margin."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K)
+    cb = torch.randn(K, D, generator=g) * (0.05 if K > 100 else 0.5)      # many pairs inside 2 * margin
+    cb[1] = cb[0]
+    ld, lr = ops.codebook_losses(cb.to(DEV), 0.5)
+    c = cb.double()
+    dist = torch.cdist(c, c)
+    ref_d = (torch.clamp(1.0 - dist, min=0) ** 2).sum() / (2 * K * (K - 1))
+    ref_r = c.norm(dim=1).mean()
+    assert_close(ld, ref_d, 2e-6, "l_dist")
+    assert_close(lr, ref_r, 2e-6, "l_reg")
+    ld2, _ = ops.codebook_losses(cb.to(DEV), 0.5)
+    assert torch.equal(ld, ld2)
 
 
 def test_vq_conservation_and_ties():

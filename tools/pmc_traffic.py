@@ -5,7 +5,8 @@ FETCH_SIZE counts exactly half of the bytes of wide coalesced reads, so reads = 
 
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_hbm_traffic.json
 """
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FAMILIES = {"conv_mfma_fwd_dgrad": ("k_conv_mfma_fwd", "k_conv_halo"),
             "conv_mfma_wgrad": ("k_conv_wgrad9", "k_conv_wgrad_up", "k_conv_mfma_wgrad", "k_conv_wgrad_tile"),
@@ -39,7 +40,8 @@ def main(fetch_dir, write_dir, out):
         n = sum(v["launches"] for v in sel)
         if n:
             fam[name] = dict(launches=n, hbm_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n)
-    json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1`",
+    import bench
+    json.dump(dict(csrc_digest=bench.csrc_digest(), source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1`",
                    correction="reads = 2*FETCH_SIZE*1024 (gfx950 half-count), writes = WRITE_SIZE*1024",
                    families=fam, kernels=kernels), open(out, "w"), indent=1, sort_keys=True)
     for k, v in fam.items():

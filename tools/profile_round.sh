@@ -1,7 +1,13 @@
+# Round profile: bench (default + 20 steps), rocprofv3 kernel summaries of the default and the serialised schedule, the two
+# PMC passes for HBM traffic; config 4 (training step + VQ alone) and config 5 (run_recon) with their kernel summaries.
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'   ->   gpurun_out/<tag>/...
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r1h; mkdir -p $O
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 500 python3 $R/bench.py --steps 20 --warmup 3 > $O/bench_steps20.json 2> $O/bench_steps20.err
+timeout -k 10 500 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+echo "bench default done"
+timeout -k 10 500 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_steps20.json 2> $O/bench_steps20.err
 echo "bench20 done"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/conc.err
 echo "conc done"
@@ -13,5 +19,12 @@ timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 echo "fetch done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
 echo "write done"
-rm -f $O/pmc_fetch/*kernel_trace.csv $O/pmc_write/*kernel_trace.csv
-ls -la $O $O/pmc_fetch | head -30
+# config 4 and config 5
+timeout -k 10 300 python3 $R/tools/config4_bench.py > $O/config4_bench.json 2> $O/config4_bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4 -o t -- python3 $R/tools/config4_bench.py --steps 3 --warmup 1 > /dev/null 2> $O/cfg4.err
+echo "cfg4 done"
+timeout -k 10 300 python3 $R/tools/recon_bench.py > $O/config5_recon_bench.txt 2> $O/config5.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -o t -- python3 $R/tools/recon_bench.py > /dev/null 2> $O/cfg5.err
+echo "cfg5 done"
+rm -f $O/*/*kernel_trace.csv $O/*/*agent_info.csv
+ls -la $O | head -40
