@@ -254,6 +254,163 @@ __global__ void __launch_bounds__(VQ_BLOCK) k_vq_fwd(const float* __restrict__ x
     }
 }
 
+// Tile form of the SMALL route (D in {16, 32, 64}, codebook in LDS): a wave owns 64 consecutive pixels at a time.  Their rows
+// are loaded with fully coalesced float4 loads (lane i <-> float4 i of the 64 x D chunk; the next tile's loads are in
+// flight while this one is scored), committed to a wave-private padded LDS tile, and every lane reads its own row back
+// (conflict-free with the DT + 4 stride).  The same tile is the A operand of the statistics MFMAs, then receives the
+// gathered codes and is written out with coalesced float4 stores.  The row-per-lane global accesses of k_vq_fwd (64-byte
+// lane stride: 32 cache lines per wave instruction) held it at 3.6 TB/s.
+template <int DT, int NT>
+__global__ void __launch_bounds__(VQ_BLOCK) k_vq_tile(const float* __restrict__ x, const float* __restrict__ embed,
+                                                      int64_t* __restrict__ ids, float* __restrict__ q,
+                                                      double* __restrict__ commit_part, float* __restrict__ stat_part,
+                                                      long Npix, int K, int want_stats, int id_base) {
+    constexpr int D = DT, C4 = DT / 4, XS = DT + 4;
+    constexpr int MT = NT > 0 ? DT / 16 + 1 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_cb = smem;                                   // [K][D]
+    float* s_nrm = smem + K * D;                          // [K]
+    float* s_x = s_nrm + ((K + 3) & ~3);                  // [waves][64][XS] tiles, later [waves][K*(D+1)] slabs
+    __shared__ double s_red[VQ_BLOCK / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int i = t; i < K * D; i += VQ_BLOCK) s_cb[i] = embed[i];
+    for (int k = t; k < K; k += VQ_BLOCK) {
+        float n2 = 0.f;
+        for (int d = 0; d < D; ++d) { const float e = embed[k * D + d]; n2 = fmaf(e, e, n2); }
+        s_nrm[k] = n2;
+    }
+    __syncthreads();
+    f32x4 acc[MT][NT > 0 ? NT : 1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < (NT > 0 ? NT : 1); ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float* xt = s_x + wv * 64 * XS;
+    const long ntiles = (Npix + 63) / 64, tstride = (long)gridDim.x * (VQ_BLOCK / 64);
+    const long nf4 = Npix * C4;                           // float4 elements of x / q
+    const float4* x4 = (const float4*)x;
+    float4* q4 = (float4*)q;
+    float4 pre[C4];
+    long tile = (long)blockIdx.x * (VQ_BLOCK / 64) + wv;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int r = 0; r < C4; ++r) { const long f = tile * 64 * C4 + r * 64 + lane; pre[r] = f < nf4 ? x4[f] : float4{0.f, 0.f, 0.f, 0.f}; }
+    }
+    double csum = 0.0;
+    for (; tile < ntiles; tile += tstride) {
+#pragma unroll
+        for (int r = 0; r < C4; ++r) {
+            const int f = r * 64 + lane;
+            *(float4*)(xt + (f / C4) * XS + 4 * (f % C4)) = pre[r];
+        }
+        const long nt_ = tile + tstride;
+        if (nt_ < ntiles) {
+#pragma unroll
+            for (int r = 0; r < C4; ++r) { const long f = nt_ * 64 * C4 + r * 64 + lane; pre[r] = f < nf4 ? x4[f] : float4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const long p = tile * 64 + lane;
+        const bool active = p < Npix;
+        float xv[DT];
+#pragma unroll
+        for (int d4 = 0; d4 < C4; ++d4) {
+            const float4 v = *(const float4*)(xt + lane * XS + 4 * d4);
+            xv[4 * d4] = v.x; xv[4 * d4 + 1] = v.y; xv[4 * d4 + 2] = v.z; xv[4 * d4 + 3] = v.w;
+        }
+        float x2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) x2 = fmaf(xv[d], xv[d], x2);
+        float best = -INFINITY;
+        int bi = 0;
+        for (int k = 0; k < K; ++k) {
+            const float* e = s_cb + k * D;
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) dot = fmaf(e[d], xv[d], dot);
+            const float sc = (2.f * dot - s_nrm[k]) - x2;
+            if (sc > best) { best = sc; bi = k; }
+        }
+        if (active) ids[p] = (int64_t)(bi + id_base);
+        if constexpr (NT > 0) if (want_stats) {
+            // sums[d][k] += sum_p X[p][d] * [id_p == k]: A = 16 channels x 4 pixels from the tile, B = 4 pixels x 16 codes
+            // (one-hot built in registers), 16 steps of 4 pixels; channel row D of A is all ones -> counts
+            const int code = active ? bi : -1;
+            const int lm = lane & 15, lg = lane >> 4;
+            const float ones = lm == 0 ? 1.f : 0.f;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const int pid = __shfl(code, 4 * s + lg, 64);
+                float bm[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bm[j] = pid == j * 16 + lm ? 1.f : 0.f;
+                const float* ar = xt + (4 * s + lg) * XS + lm;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const float a = i < MT - 1 ? ar[i * 16] : ones;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = MFMA16(a, bm[j], acc[i][j]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float* e = s_cb + bi * D;                     // gather into the lane's own row of the tile
+        float c = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < C4; ++d4) {
+            const float4 o = *(const float4*)(e + 4 * d4);
+            *(float4*)(xt + lane * XS + 4 * d4) = o;
+            const float a0 = xv[4 * d4] - o.x, a1 = xv[4 * d4 + 1] - o.y, a2 = xv[4 * d4 + 2] - o.z, a3 = xv[4 * d4 + 3] - o.w;
+            c = fmaf(a0, a0, c); c = fmaf(a1, a1, c); c = fmaf(a2, a2, c); c = fmaf(a3, a3, c);
+        }
+        if (active) csum += (double)c;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < C4; ++r) {
+            const int f = r * 64 + lane;
+            const long gf = tile * 64 * C4 + f;
+            const float4 v = *(const float4*)(xt + (f / C4) * XS + 4 * (f % C4));
+            if (gf < nf4) q4[gf] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    csum = wave_sum_d(csum);
+    if (lane == 0) s_red[wv] = csum;
+    __syncthreads();
+    if (t == 0) {
+        double a = 0.0;
+        for (int w = 0; w < VQ_BLOCK / 64; ++w) a += s_red[w];
+        commit_part[blockIdx.x] = a;
+    }
+    if constexpr (NT > 0) if (want_stats) {
+        const int KD1 = K * (D + 1);
+        float* slab = s_x + wv * KD1;          // layout of `stats`: counts[K] then sums[d][k]
+        const int lm = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * i + 4 * lg + r, n = 16 * j + lm;
+                    if (n < K) {
+                        if (m < D) slab[K + m * K + n] = acc[i][j][r];
+                        else if (m == D) slab[n] = acc[i][j][r];
+                    }
+                }
+        __syncthreads();
+        float* o = stat_part + (long)blockIdx.x * KD1;
+        for (int i = t; i < KD1; i += VQ_BLOCK) {      // fold the wave slabs in wave order
+            float a = s_x[i];
+            for (int w = 1; w < VQ_BLOCK / 64; ++w) a += s_x[w * KD1 + i];
+            o[i] = a;
+        }
+    }
+}
+
 // commit = sum(commit_part) / numel
 __global__ void k_vq_finalize(const double* __restrict__ commit_part, long nblocks, float* __restrict__ commit, double inv_numel) {
     __shared__ double s_red[4];
@@ -644,14 +801,24 @@ static int launch_vq_mfma(const float* x, const float* embed, const float* enorm
     return VQW_OK;
 }
 
-template <int DT, bool LDS_CB>
-static void launch_vq_small(int nt, int nb, size_t lds, hipStream_t st, const float* x, const float* embed, int64_t* ids, float* q,
-                            double* cpart, float* spart, long Npix, int D, int K, int want, int id_base) {
-    if (DT > 0 && nt == 1) k_vq_fwd<DT, LDS_CB, (DT > 0 ? 1 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
-    else if (DT > 0 && nt == 2) k_vq_fwd<DT, LDS_CB, (DT > 0 ? 2 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
-    else if (DT > 0 && DT <= 32 && nt == 4) k_vq_fwd<DT, LDS_CB, (DT > 0 && DT <= 32 ? 4 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
-    else if (DT == 16 && nt == 8) k_vq_fwd<DT, LDS_CB, (DT == 16 ? 8 : 0)><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
-    else k_vq_fwd<DT, LDS_CB, 0><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, D, K, want, id_base);
+template <int DT, int NT>
+static int launch_vq_tile_nt(int nb, size_t lds, hipStream_t st, const float* x, const float* embed, int64_t* ids, float* q,
+                             double* cpart, float* spart, long Npix, int K, int want, int id_base) {
+    if (lds > 65536 && hipFuncSetAttribute((const void*)k_vq_tile<DT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        vqw_set_error("vqw_vq_fwd: cannot reserve %zu bytes of LDS", lds);      // D = 64 tiles next to a large codebook
+        return VQW_ERR_HIP;
+    }
+    k_vq_tile<DT, NT><<<nb, VQ_BLOCK, lds, st>>>(x, embed, ids, q, cpart, spart, Npix, K, want, id_base);
+    return VQW_OK;
+}
+template <int DT>
+static int launch_vq_tile(int nt, int nb, size_t lds, hipStream_t st, const float* x, const float* embed, int64_t* ids, float* q,
+                          double* cpart, float* spart, long Npix, int K, int want, int id_base) {
+    if (nt == 1) return launch_vq_tile_nt<DT, 1>(nb, lds, st, x, embed, ids, q, cpart, spart, Npix, K, want, id_base);
+    if (nt == 2) return launch_vq_tile_nt<DT, 2>(nb, lds, st, x, embed, ids, q, cpart, spart, Npix, K, want, id_base);
+    if (DT <= 32 && nt == 4) return launch_vq_tile_nt<DT, (DT <= 32 ? 4 : 0)>(nb, lds, st, x, embed, ids, q, cpart, spart, Npix, K, want, id_base);
+    if (DT == 16 && nt == 8) return launch_vq_tile_nt<DT, (DT == 16 ? 8 : 0)>(nb, lds, st, x, embed, ids, q, cpart, spart, Npix, K, want, id_base);
+    return launch_vq_tile_nt<DT, 0>(nb, lds, st, x, embed, ids, q, cpart, spart, Npix, K, want, id_base);
 }
 
 extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int id_base, float* q, float* commit, double* stats,
@@ -690,18 +857,21 @@ extern "C" int vqw_vq_fwd(const float* x, const float* embed, int64_t* ids, int 
     const int nb = vq_blocks(Npix);
     const int KD1 = K * (D + 1);
     const bool lds_cb = vq_lds_codebook(D, K);
+    const bool tiled = lds_cb && (D == 16 || D == 32 || D == 64);
     const int nt = plan == VQ_PLAN_SMALL_MFMA_STATS ? vq_small_nt(D, K) : 0;
     size_t lds_floats = (size_t)((K + 3) & ~3) + (lds_cb ? (size_t)K * D : 0);
-    if (nt > 0) {
-        const size_t tiles = (size_t)(VQ_BLOCK / 64) * 64 * (D + 4), slabs = (size_t)(VQ_BLOCK / 64) * KD1;
+    if (tiled) {
+        const size_t tiles = (size_t)(VQ_BLOCK / 64) * 64 * (D + 4), slabs = nt > 0 ? (size_t)(VQ_BLOCK / 64) * KD1 : 0;
         lds_floats += tiles > slabs ? tiles : slabs;
     }
     const size_t lb = lds_floats * sizeof(float);
-    if (D == 16 && lds_cb) launch_vq_small<16, true>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
-    else if (D == 32 && lds_cb) launch_vq_small<32, true>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
-    else if (D == 64 && lds_cb) launch_vq_small<64, true>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
-    else if (lds_cb) launch_vq_small<0, true>(0, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
-    else launch_vq_small<0, false>(0, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
+    int rc = VQW_OK;
+    if (tiled && D == 16) rc = launch_vq_tile<16>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, K, want, id_base);
+    else if (tiled && D == 32) rc = launch_vq_tile<32>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, K, want, id_base);
+    else if (tiled) rc = launch_vq_tile<64>(nt, nb, lb, st, x, embed, ids, q, w.cpart, w.spart, Npix, K, want, id_base);
+    else if (lds_cb) k_vq_fwd<0, true, 0><<<nb, VQ_BLOCK, lb, st>>>(x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
+    else k_vq_fwd<0, false, 0><<<nb, VQ_BLOCK, lb, st>>>(x, embed, ids, q, w.cpart, w.spart, Npix, D, K, want, id_base);
+    if (rc) return rc;
     VQW_LAUNCH_CHECK("vqw_vq_fwd");
     if (want && nt == 0) { int rc = vq_sorted_stats(x, ids, id_base, stats, w, Npix, D, K, st); if (rc) return rc; }
     k_vq_finalize<<<1, 256, 0, st>>>(w.cpart, nb, commit, inv_numel);
