@@ -1,5 +1,6 @@
 // C-ABI entry points for convolution: argument validation and kernel selection.
 #include "common.h"
+#include <stdlib.h>
 #include "conv_common.h"
 #include "../../include/vqwnet_hip.h"
 
@@ -18,6 +19,8 @@ static hipEvent_t* g_prof_ev = nullptr;   // 2 * PROF_MAX events
 static double g_prof_flops[PROF_MAX];
 static double g_prof_bytes[PROF_MAX];
 static int g_prof_family[PROF_MAX];
+
+static const int g_pw_wgrad = []{ const char* e = getenv("VQW_PW_WGRAD"); return e ? atoi(e) : 1; }();      // 0: 1x1 weight gradients on the split-K GEMM kernel (A/B)
 
 extern "C" int vqw_profile_begin(void) {
     if (!g_prof_ev) {
@@ -177,6 +180,7 @@ extern "C" size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W,
     size_t f = direct > mfma ? direct : mfma;
     size_t thin = conv_stem_wgrad_ws_floats(Cout) + conv_head_wgrad_ws_floats(Cin);
     if (thin > f) f = thin;
+    if (ksize == 1 && (long)Cin * Cout <= 4096 && conv_pw_wgrad_ws_floats(Cin, Cout) > f) f = conv_pw_wgrad_ws_floats(Cin, Cout);
     return (f + bias_grad_ws_floats(Cout)) * sizeof(float) + 256;
 }
 
@@ -213,6 +217,14 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     if (g_conv_backend == 0 && conv_head_ok(in, Cout, ksize)) {
         ProfScope ps(3, flops, st, bytes);
         return conv_head_wgrad(in, dy, dw_ohwi, dbias, wsf, (long)N * H * W, accumulate, st);
+    }
+    if (g_conv_backend == 0 && g_pw_wgrad && conv_pw_wgrad_ok(in, Cout, ksize, (long)N * H * W)) {
+        ProfScope ps(1, flops, st, bytes);
+        if (dbias) {
+            rc = bias_grad(dy, dbias, wsf, (long)N * H * W, Cout, st, accumulate);
+            if (rc) return rc;
+        }
+        return conv_pw_wgrad(in, dy, dw_ohwi, wsf + bias_grad_ws_floats(Cout), (long)N * H * W, Cout, accumulate, st);
     }
     if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
         ProfScope ps(1, flops, st, bytes);

@@ -77,6 +77,10 @@ int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
 size_t conv_stem_wgrad_ws_floats(int Cout);
 int conv_stem_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, float* ws, int N, int H, int W, int Cout, int ks,
                     int dil, int acc, hipStream_t st);
+// streaming 1x1 weight gradient of thin layers on large maps (conv_thin.hip)
+bool conv_pw_wgrad_ok(const ConvIn& in, int Cout, int ks, long P);
+size_t conv_pw_wgrad_ws_floats(int Cin, int Cout);
+int conv_pw_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, long P, int Cout, int acc, hipStream_t st);
 bool conv_head_ok(const ConvIn& in, int Cout, int ks);
 int conv_head_fwd(const ConvIn& in, const float* w, const float* bias, float* y, long P, int relu, hipStream_t st);
 size_t conv_head_wgrad_ws_floats(int Cin);

@@ -2,6 +2,7 @@
 // These are HBM-bound streams, not GEMMs: one thread per pixel, weights in registers/LDS, float4 I/O.
 #include "common.h"
 #include "conv_common.h"
+#include "mfma_util.h"
 
 // ---------------------------------------------------------------------------------------------
 // stem forward: y[p][0..Cout) = b + sum_t x[p + shift(t)] * w[co][t]          (Cin == 1, Cout % 4 == 0, Cout <= 64)
@@ -326,4 +327,101 @@ int conv_head_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
     k_head_wgrad_finalize<<<in.C0 + 1, 256, 0, st>>>(ws, dw, dbias, nb, in.C0, acc);
     VQW_LAUNCH_CHECK("conv_head_wgrad");
     return VQW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// streaming 1x1 weight gradient for thin layers on large maps (ResBlock downsample / ASPP 1x1 branch at the full-resolution
+// levels: 16->32, 32->32 @256x256 ...): dW[co][ci] = sum_p dY[p][co] * X[p][ci] is a (Cout x Cin) result over millions of
+// pixels - an HBM stream (N*H*W*(Cin+Cout)*4 bytes once), not a GEMM to tile.  Every wave walks its own share of pixel
+// pairs: one fp32 MFMA per pair with dY as the A operand (M = co) and X as B (N = ci), K = the two pixels (half-wave
+// each), operands loaded straight from global (a wave instruction = the two pixels' contiguous rows), 8 pairs = 8 x
+// (TM + TN) loads in flight per wave.  Workgroup slabs folded in wave order, slabs summed by reduce_rows: deterministic.
+// (The split-K implicit-GEMM kernel reached 1.1-1.4 TB/s on these shapes.)
+#define PW_BLOCKS 1024
+template <int TM, int TN>
+__global__ void __launch_bounds__(256) k_pw_wgrad(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                  long P, int Cin, int Cout) {
+    extern __shared__ float s_slab[];             // [4 waves][Cout][Cin]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l5 = lane & 31, h = lane >> 5;
+    const long gw = (long)blockIdx.x * 4 + wv, nw = (long)gridDim.x * 4;
+    const long chunks = (P / 2 + 7) / 8;          // 8 pixel pairs per chunk
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // raw buffer loads: an offset past the tensor (pixels beyond P, channels beyond Cin) returns 0 - no exec-masked branches
+    const __amdgpu_buffer_rsrc_t rdy = make_rsrc(dy, (unsigned)(P * Cout * 4)), rx = make_rsrc(x, (unsigned)(P * Cin * 4));
+    const unsigned OOB = 0xffffff00u;
+    unsigned xo[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) xo[j] = 32 * j + l5 < Cin ? (unsigned)(32 * j + l5) * 4u : OOB;
+    auto load = [&](long c, float (&a)[8][TM], float (&b)[8][TN]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long p = 2 * (c * 8 + u) + h;
+            const unsigned pa = p < P ? (unsigned)(p * Cout) * 4u : OOB, pb = p < P ? (unsigned)(p * Cin) * 4u : OOB;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[u][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdy, (int)sel_u32(pa != OOB, pa + (32 * i + l5) * 4u, OOB), 0, 0));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[u][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)sel_u32((pb != OOB) & (xo[j] != OOB), pb + xo[j], OOB), 0, 0));
+        }
+    };
+    float a0[8][TM], b0[8][TN], a1[8][TM], b1[8][TN];
+    long c = gw;
+    if (c < chunks) load(c, a0, b0);
+    for (; c < chunks; c += 2 * nw) {        // two register sets: the next chunk's loads are in flight under this chunk's MFMAs
+        if (c + nw < chunks) load(c + nw, a1, b1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MFMA32(a0[u][i], b0[u][j], acc[i][j]);
+        if (c + nw < chunks) {
+            if (c + 2 * nw < chunks) load(c + 2 * nw, a0, b0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MFMA32(a1[u][i], b1[u][j], acc[i][j]);
+        }
+    }
+    float* slab = s_slab + (size_t)wv * Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * i + 8 * (r >> 2) + 4 * h + (r & 3), ci = 32 * j + l5;
+                if (ci < Cin) slab[co * Cin + ci] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int n = Cout * Cin;
+    for (int k = threadIdx.x; k < n; k += 256)
+        part[(size_t)blockIdx.x * n + k] = (s_slab[k] + s_slab[n + k]) + (s_slab[2 * n + k] + s_slab[3 * n + k]);
+}
+bool conv_pw_wgrad_ok(const ConvIn& in, int Cout, int ks, long P) {
+    const int Cin = in.C0;
+    return ks == 1 && in.C1 == 0 && !in.up0 && (Cin == 16 || Cin == 32 || Cin == 64) && (Cout == 32 || Cout == 64 || Cout == 128) &&
+           (long)Cin * Cout <= 4096 && (P & 1) == 0 && P >= 131072 && P * (long)(Cin > Cout ? Cin : Cout) * 4 < 0xffffff00L;
+}
+size_t conv_pw_wgrad_ws_floats(int Cin, int Cout) { return (size_t)PW_BLOCKS * Cin * Cout; }
+int conv_pw_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, long P, int Cout, int acc, hipStream_t st) {
+    const int Cin = in.C0, TM = Cout / 32, TN = (Cin + 31) / 32;
+    const long chunks = (P / 2 + 7) / 8;
+    const int nb = (int)(chunks / 4 < PW_BLOCKS ? (chunks + 3) / 4 : PW_BLOCKS);
+    const size_t lds = (size_t)4 * Cin * Cout * sizeof(float);       // <= 64 KB by conv_pw_wgrad_ok
+#define PW_CASE(TM_, TN_) if (TM == TM_ && TN == TN_) k_pw_wgrad<TM_, TN_><<<nb, 256, lds, st>>>(in.src0, dy, ws, P, Cin, Cout)
+    PW_CASE(1, 1); else PW_CASE(2, 1); else PW_CASE(4, 1); else PW_CASE(1, 2); else PW_CASE(2, 2);
+    else { vqw_set_error("conv_pw_wgrad: unsupported tile %d x %d", TM, TN); return VQW_ERR_ARG; }
+#undef PW_CASE
+    VQW_LAUNCH_CHECK("conv_pw_wgrad");
+    return reduce_rows(ws, dw, (long)Cin * Cout, nb, st, acc);
 }

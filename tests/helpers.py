@@ -110,3 +110,28 @@ def check_grads_vs_fp64(g, grads, factor=2.0, what=""):
     assert len(over) <= max(2, int(0.10 * len(ratios))), "\n".join(over)
     assert float(np.median(ratios)) <= factor, "median error ratio %.2f" % float(np.median(ratios))
     return float(np.median(ratios)), float(np.max(ratios))
+
+
+def grad_gate(truth, variants, test, factor=2.0, what="", max_over_frac=0.10):
+    """The same gate on whole tensors: `truth` {name: fp64 gradient}, `variants` list of {name: fp32 gradient} from
+    mathematically equivalent evaluations of the reference / oracle, `test` {name: gradient under test}.
+    Returns (median, max) of err_test / max(spread, median spread)."""
+    gmax = max(float(g.norm()) for g in truth.values() if g is not None)
+    live = [k for k, g in truth.items() if g is not None and float(g.norm()) >= 1e-6 * gmax]
+
+    def err(g, k):
+        return float((g.detach().double().cpu() - truth[k]).norm() / truth[k].norm())
+    spread = {k: max(err(v[k], k) for v in variants) for k in live}
+    floor = float(np.median(list(spread.values())))
+    ratios, over = [], []
+    for k in live:
+        e = err(test[k], k)
+        ref_e = max(spread[k], floor)
+        ratios.append(e / ref_e)
+        msg = "%s grad %s: %.3e from the fp64 gradient, fp32 spread of the oracle %.3e (median %.3e)" % (what, k, e, spread[k], floor)
+        assert e <= 3 * factor * ref_e, msg
+        if e > factor * ref_e:
+            over.append(msg)
+    assert len(over) <= max(2, int(max_over_frac * len(ratios))), "\n".join(over)
+    assert float(np.median(ratios)) <= factor, "median error ratio %.2f" % float(np.median(ratios))
+    return float(np.median(ratios)), float(np.max(ratios))

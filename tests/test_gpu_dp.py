@@ -18,7 +18,7 @@ sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "medical-image-e
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
-from trainers import FirstStepTrainer, FlipViews
+from trainers import FirstStepTrainer, FlipViews, LossWeights
 from networks import UNetEncoder, UNetDecoder
 from oracle.vqwnet_ref import synthetic_slices
 torch.manual_seed(5)
@@ -30,7 +30,7 @@ with torch.no_grad():
     enc.vq.embed.mul_(0.7); enc.vq.cluster_size.fill_(B * S * S / K)
     enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
 tr = FirstStepTrainer(dict_size=K, momentum=0.99, views=FlipViews(border=2), encoder=enc, decoder=dec, device="cuda:0",
-                      data_parallel=world > 1)
+                      data_parallel=world > 1, loss_weight=LossWeights(cross=float(os.environ.get("VQW_TEST_CROSS_W", "1"))))
 img, noise = synthetic_slices(B, S, 11)
 lo, hi = (rank * B // world, (rank + 1) * B // world)
 o = tr.training_step({"image": img[lo:hi].cuda()}, noise=noise[lo:hi].cuda())
@@ -46,13 +46,14 @@ if world > 1:
 '''
 
 
-def _run(world, tmp_path, tag, port):
+def _run(world, tmp_path, tag, port, cross_w=1.0):
     script = tmp_path / "dpw.py"
     script.write_text(WORKER)
     out = str(tmp_path / tag)
     procs = []
     for r in range(world):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r))
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r),
+                   VQW_TEST_CROSS_W=str(cross_w))
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:
@@ -85,6 +86,28 @@ def test_two_rank_dp_matches_single_process(tmp_path):
     assert max(errs) < 0.15 and sorted(errs)[len(errs) // 2] < 0.05, errs
     mean_total = 0.5 * (dp[0]["total"] + dp[1]["total"])
     assert abs(mean_total - single["total"]) <= 0.05 * abs(single["total"])
+
+
+def test_two_rank_dp_gradients_equal_single_process_without_cross_loss(tmp_path):
+    """The tight form of the gradient check above.  The cross-view loss is a mean over the (sample, code) pairs PRESENT on a
+    rank, so the mean of the per-rank losses is a different function from the global-batch loss (DDP semantics, as in the
+    reference) and a few per cent apart in gradient.  With its weight at zero every remaining term (commit, reconstruction;
+    SyncBN and VQ statistics are global) is an equal-size mean, and the averaged data-parallel gradients ARE the
+    single-process gradients: fp32 rounding and the occasional ReLU / max-pool flip are all that is left - a mis-scaled
+    bucket or a lost gradient would be orders of magnitude above this bound."""
+    single = _run(1, tmp_path, "single0", 29623, cross_w=0.0)[0]
+    dp = _run(2, tmp_path, "dp0", 29624, cross_w=0.0)
+    assert torch.equal(torch.cat([dp[0]["ids_1"], dp[1]["ids_1"]]), single["ids_1"])
+    errs = []
+    gmax = max(float(g.norm()) for g in single["g"].values())
+    for k, g in single["g"].items():
+        if float(g.norm()) < 1e-4 * gmax:
+            continue
+        assert torch.equal(dp[0]["g"][k], dp[1]["g"][k]), "ranks hold different averaged gradients for " + k
+        errs.append(float((dp[0]["g"][k] - g).norm() / g.norm()))
+    assert max(errs) < 2e-2 and sorted(errs)[len(errs) // 2] < 2e-3, errs
+    mean_total = 0.5 * (dp[0]["total"] + dp[1]["total"])
+    assert abs(mean_total - single["total"]) <= 1e-4 * abs(single["total"])
 
 
 WORKER2 = r'''

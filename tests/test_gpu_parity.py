@@ -14,7 +14,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import assert_close, build_models, check_init, step_cfg, check_grads_vs_fp64
+from helpers import assert_close, build_models, check_init, step_cfg, check_grads_vs_fp64, grad_gate
 from test_oracle_golden import check_step, GRAD_TOL, apply_warm_state
 
 pytestmark = pytest.mark.gpu
@@ -78,6 +78,12 @@ CONV_CASES = [
     (2, 16, 16, 1, 0, False, 128, 3, 1, True, True),
     (2, 16, 16, 1, 0, False, 64, 3, 1, True, False),
     (1, 20, 12, 1, 0, False, 192, 3, 2, False, False),
+    # thin 1x1 layers on large maps: the streaming weight gradient (pixel pairs through one MFMA per pair)
+    (2, 256, 256, 16, 0, False, 32, 1, 1, False, False),
+    (2, 256, 256, 32, 0, False, 32, 1, 1, True, False),
+    (3, 208, 212, 32, 0, False, 64, 1, 1, False, False),
+    (8, 128, 128, 64, 0, False, 64, 1, 1, False, False),
+    (4, 192, 192, 16, 0, False, 128, 1, 1, False, False),
 ]
 
 
@@ -744,6 +750,8 @@ def test_step_vs_oracle_128(B, S):
         enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
     PE = {k: v.detach().clone().contiguous() for k, v in enc.state_dict().items()}
     PD = {k: v.detach().clone().contiguous() for k, v in dec.state_dict().items()}
+    PE0 = {k: v.clone() for k, v in PE.items()}
+    PD0 = {k: v.clone() for k, v in PD.items()}
     cfg = dict(dict_size=K, margin=0.5, border=2, momentum=0.999,
                weights=dict(commit=1.0, cross=1.0, dist=1.0, reg=1.0, recon=1.0),
                optim=dict(lr=1e-4, betas=(0.5, 0.999), weight_decay=0.0))
@@ -763,17 +771,35 @@ def test_step_vs_oracle_128(B, S):
         clear = gap > 1e-3 * (1 + np.abs(gap))
         assert np.array_equal(out["ids_" + v].cpu().numpy()[clear], ref["ids_" + v].numpy()[clear])
         assert_close(out["recon_" + v], ref["recon_" + v], 5e-3, "recon_" + v)
-    errs = []
-    for pre, mod, grads in (("enc", tr.encoder, ref["grads_enc"]), ("dec", tr.decoder, ref["grads_dec"])):
-        gmax = max(float(gr.norm()) for gr in grads.values() if gr is not None)
-        for k, p in mod.named_parameters():
-            gr = grads[k]
-            if gr is None or float(gr.norm()) < 1e-6 * gmax:
-                continue
-            errs.append(float((p.grad.cpu() - gr).norm() / gr.norm()))
-    errs = np.array(errs)
-    assert np.median(errs) < 2e-2 and np.quantile(errs, 0.9) < 0.1 and errs.max() < 0.5, \
-        "grad errors: median %.3e p90 %.3e max %.3e" % (np.median(errs), np.quantile(errs, 0.9), errs.max())
+    # gradients: at most twice as far from the oracle's fp64 gradient as the oracle's own fp32 evaluations are (default
+    # threads, one thread, batch reversed) - the gate of tests/helpers.py, here with the oracle as the reference
+    def oracle_grads(dtype, threads, flip):
+        n0 = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        try:
+            P1 = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in PE0.items()}
+            P2 = {k: (v.detach().clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in PD0.items()}
+            img, noi = (image.flip(0), noise.flip(0)) if flip else (image, noise)
+            o = O.FirstStepTrainer(P1, P2, cfg).step(img.to(dtype), noi.to(dtype))
+        finally:
+            torch.set_num_threads(n0)
+        g = {"enc." + k: v for k, v in o["grads_enc"].items()}
+        g.update({"dec." + k: v for k, v in o["grads_dec"].items()})
+        return g
+    truth = {k: (v.double() if v is not None else None) for k, v in oracle_grads(torch.float64, torch.get_num_threads(), False).items()}
+    first = {"enc." + k: v for k, v in ref["grads_enc"].items()}
+    first.update({"dec." + k: v for k, v in ref["grads_dec"].items()})
+    variants = [first, oracle_grads(torch.float32, 1, False), oracle_grads(torch.float32, torch.get_num_threads(), True)]
+    if S <= 96:      # cheap here: sample the oracle's spread more densely (planes of 25-36 elements flip easily)
+        variants += [oracle_grads(torch.float32, 2, False), oracle_grads(torch.float32, 4, True), oracle_grads(torch.float32, 1, True),
+                     oracle_grads(torch.float32, 3, False), oracle_grads(torch.float32, 5, True)]
+    test = {"enc." + k: p.grad for k, p in tr.encoder.named_parameters()}
+    test.update({"dec." + k: p.grad for k, p in tr.decoder.named_parameters()})
+    # 80x80 has 5x5 planes at the bottom: ONE ReLU / max-pool decision there that differs from the oracle's moves the
+    # gradient of every layer upstream of it (the whole down path, a third of the parameters) to ~2.5x the spread - the
+    # per-parameter cap (6x the spread) and the median (2x) still hold
+    print("B%d S%d HIP grad error / oracle fp32 spread (median, max):" % (B, S),
+          grad_gate(truth, variants, test, 2.0, "HIP", max_over_frac=0.10 if S >= 96 else 0.40))
 
 
 def test_full_size_properties():
