@@ -42,3 +42,49 @@ class NCCLungDataset(data.Dataset):
             image = window_normalize(image, *self.window)
         sample['image'] = image
         return self.transform(sample) if self.transform else sample
+
+
+class MICCAIBraTSDataset(data.Dataset):
+    """dataio/miccai_dataset.py:15-68: `<patient>/<x>_<modality>_<slice>.npy` MR slices (intensities 0..255; the loader's
+    NormalizeIntensity maps them to [-1, 1]); the file list keeps directory order (no shuffle at construction, as upstream)."""
+
+    def __init__(self, root_dir_path, modality, transform=None):
+        super().__init__()
+        assert modality in {'t1', 't1ce', 't2', 'flair'}
+        self.root_dir_path, self.modality, self.transform = str(root_dir_path), modality, transform
+        self.files = []
+        for patient_id in os.listdir(self.root_dir_path):
+            for path in sorted(glob.glob(os.path.join(self.root_dir_path, patient_id, '*_{}_*'.format(modality)))):
+                stem = os.path.splitext(os.path.basename(path))[0]
+                self.files.append({'patient_id': patient_id, 'slice_num': int(stem.split('_')[-1]), 'modality': modality,
+                                   'image_path': path})
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, index):
+        sample = dict(self.files[index])
+        sample['image'] = np.load(sample['image_path']).astype(np.float32)
+        return self.transform(sample) if self.transform else sample
+
+
+class CRCDataset(data.Dataset):
+    """dataio/crc_dataset.py:17-67: `<patient>/<slice>.npy`; the file list is shuffled once at construction (:31)."""
+
+    def __init__(self, root_dir_path, transform=None):
+        super().__init__()
+        self.root_dir_path, self.transform = str(root_dir_path), transform
+        self.files = []
+        for patient_id in os.listdir(self.root_dir_path):
+            for path in sorted(glob.glob(os.path.join(self.root_dir_path, patient_id, '*.npy'))):
+                self.files.append({'patient_id': patient_id, 'slice_num': int(os.path.splitext(os.path.basename(path))[0]),
+                                   'image_path': path})
+        random.shuffle(self.files)
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, index):
+        sample = dict(self.files[index])
+        sample['image'] = np.load(sample['image_path']).astype(np.float32)
+        return self.transform(sample) if self.transform else sample

@@ -379,4 +379,31 @@ def test_ct_windows_and_dataset(tmp_path):
     batches = list(dl)
     assert [tuple(b["image"].shape) for b in batches] == [(2, 1, 8, 8), (1, 1, 8, 8)] and batches[0]["image"].dtype == torch.float32
     with pytest.raises(NotImplementedError):
-        get_data_loader('train', 'CRCDataset', str(tmp_path), 2, 0)
+        get_data_loader('train', 'NCCLungDataset', str(tmp_path), 2, 0, augmentations=['RandomAffineTransform'])
+
+
+def test_brats_and_crc_dataset_branches(tmp_path):
+    """dataio/data_loader.py:31-64,107-139: the MICCAIBraTSDataset (modality-filtered files) and CRCDataset branches with
+    NormalizeIntensity (clamp to [0, 255] -> [-1, 1], dataio/transforms.py:53-72)."""
+    from dataio import get_data_loader, MICCAIBraTSDataset, CRCDataset, NormalizeIntensity
+    brats, crc = tmp_path / "brats", tmp_path / "crc"
+    for pid in ("a01", "a02"):
+        os.makedirs(brats / pid); os.makedirs(crc / pid)
+        for n in (5, 2):
+            for mod in ("t1", "flair"):
+                np.save(brats / pid / ("%s_%s_%03d.npy" % (pid, mod, n)), np.full((8, 8), 25.5 * n + (100 if mod == "flair" else 0)))
+            np.save(crc / pid / ("%d.npy" % n), np.full((8, 8), 300.0 if n == 5 else 51.0))
+    ds = MICCAIBraTSDataset(str(brats), "flair")
+    assert len(ds) == 4 and all(f["modality"] == "flair" and "_flair_" in f["image_path"] for f in ds.files)
+    assert [f["slice_num"] for f in ds.files if f["patient_id"] == "a01"] == [2, 5]            # sorted per patient, not shuffled
+    x = NormalizeIntensity()({"image": torch.tensor([[-5.0, 0.0, 127.5, 255.0, 300.0]])})["image"]
+    assert torch.allclose(x, torch.tensor([[-1.0, -1.0, 0.0, 1.0, 1.0]]))
+    b = next(iter(get_data_loader('test', 'MICCAIBraTSDataset', str(brats), 4, 0, modality='t1')))
+    assert tuple(b["image"].shape) == (4, 1, 8, 8) and float(b["image"].min()) >= -1.0 and float(b["image"].max()) <= 1.0
+    assert sorted(b["slice_num"].tolist()) == [2, 2, 5, 5]
+    assert torch.allclose(b["image"][b["slice_num"] == 2], torch.tensor(2 * 51.0 / 255.0 - 1.0))
+    cd = CRCDataset(str(crc))
+    assert len(cd) == 4 and sorted(f["slice_num"] for f in cd.files) == [2, 2, 5, 5]
+    b = next(iter(get_data_loader('train', 'CRCDataset', str(crc), 4, 0, drop_last=True)))
+    assert tuple(b["image"].shape) == (4, 1, 8, 8)
+    assert torch.allclose(b["image"][b["slice_num"] == 5], torch.tensor(1.0)) and torch.allclose(b["image"][b["slice_num"] == 2], torch.tensor(-0.6))
