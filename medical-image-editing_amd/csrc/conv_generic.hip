@@ -197,7 +197,10 @@ int conv_direct_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, i
 
 // ---------------------------------------------------------------------------------------------
 // dbias[co] = sum_p dy[p][co]; two-stage, deterministic
-#define BG_ROWS 512
+#define BG_ROWS 2048
+// a workgroup sums a slice of pixels: threads = (channel lane, pixel lane), eight independent partial sums per thread keep
+// eight loads in flight (one dependent load after the other made this launch take 91 us whatever the tensor size: 32
+// workgroups walking 256 pixels each at P = 8192); lanes and partials are folded in a fixed order
 __global__ void __launch_bounds__(256) k_bias_grad_partial(const float* __restrict__ dy, float* __restrict__ part, long P, int C) {
     __shared__ float sa[256];
     const int tcn = C < 256 ? C : 256;
@@ -208,8 +211,16 @@ __global__ void __launch_bounds__(256) k_bias_grad_partial(const float* __restri
     for (int cb = 0; cb < C; cb += tcn) {
         int c = cb + tc;
         float a = 0.f;
-        if (tr < rows && c < C)
-            for (long p = p0 + tr; p < p1; p += rows) a += dy[p * C + c];
+        if (tr < rows && c < C) {
+            float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            long p = p0 + tr;
+            for (; p + 7L * rows < p1; p += 8L * rows) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += dy[(p + (long)u * rows) * C + c];
+            }
+            for (; p < p1; p += rows) s[0] += dy[p * C + c];
+            a = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        }
         sa[t] = a;
         __syncthreads();
         if (tr == 0 && c < C) {
@@ -221,7 +232,9 @@ __global__ void __launch_bounds__(256) k_bias_grad_partial(const float* __restri
 }
 size_t bias_grad_ws_floats(int C) { return (size_t)BG_ROWS * C; }
 int bias_grad(const float* dy, float* dbias, float* ws, long P, int C, hipStream_t st, int acc) {
-    int rows = (int)imin(BG_ROWS, imax(1, (int)(P / 256)));
+    // ~64 pixels per pixel lane of a workgroup, at most BG_ROWS workgroups
+    const int lanes = 256 / (C < 256 ? C : 256);
+    int rows = (int)imin(BG_ROWS, imax(1, (int)(P / (64L * (lanes > 0 ? lanes : 1)))));
     k_bias_grad_partial<<<rows, 256, 0, st>>>(dy, ws, P, C);
     VQW_LAUNCH_CHECK("bias_grad");
     return reduce_rows(ws, dbias, C, rows, st, acc);
