@@ -73,6 +73,7 @@ extern "C" int vqw_set_conv_backend(int mode) {
     g_conv_backend = mode == 1 ? 1 : 0;
     g_halo_mode = mode == 2 ? 1 : 0;
     g_wgrad_tile_mode = mode == 2 ? 1 : 0;
+    g_dil_mode = mode == 2 ? 1 : 0;
     return old;
 }
 
@@ -133,6 +134,7 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
     if (g_conv_backend == 0 && conv_mfma_fwd_ok(in, Cout, ksize)) {
         ProfScope ps(0, flops, st, bytes);
         if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, relu, st);
+        if (conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_dil_fwd(in, w_ohwi, bias, y, N, H, W, Cout, dil, relu, st);
         return conv_mfma_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
     }
     ProfScope ps(2, flops, st, bytes);
@@ -147,6 +149,7 @@ extern "C" int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H,
     if (g_conv_backend != 0 || N <= 0 || conv_stem_ok(in, Cout, ksize) || conv_head_ok(in, Cout, ksize) || !conv_mfma_fwd_ok(in, Cout, ksize)) return 0;
     if (conv_batch_group(N, H, W, C0 + C1, Cout) < N) return 0;
     if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_stat_tiles(in, H, W, Cout);
+    if (conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_dil_stat_tiles(H);
     return conv_mfma_stat_tiles(in, N, H, W, Cout, dil);        // implicit-GEMM kernel: 1x1, dilated, ragged widths
 }
 extern "C" int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const float* src1, int C1, const float* w_ohwi,
@@ -164,6 +167,7 @@ extern "C" int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const fl
     const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
     ProfScope ps(0, flops, st, bytes);
     if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, 0, st, part);
+    if (conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_dil_fwd(in, w_ohwi, bias, y, N, H, W, Cout, dil, 0, st, part);
     return conv_mfma_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, 0, st, part);
 }
 

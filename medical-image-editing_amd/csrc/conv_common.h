@@ -37,6 +37,15 @@ bool conv_halo_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, i
 int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
                   hipStream_t st, float* stats = nullptr);
 int conv_halo_stat_tiles(const ConvIn& in, int H, int W, int Cout);     // partials per plane written when `stats` is set
+// dilated 3x3 layers on LDS-resident rows walked along the dilation's residue chains (conv_dil.hip)
+extern int g_dil_mode;
+bool conv_dil_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
+int conv_dil_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int dil, int relu,
+                 hipStream_t st, float* stats = nullptr);
+int conv_dil_stat_tiles(int H);
+bool conv_dil_wgrad_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
+int conv_dil_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int max_slabs, int N, int H, int W, int Cout, int dil,
+                   int acc, hipStream_t st);     // partials per plane written when `stats` is set
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
 bool conv_up2_ok(int Cin, int Cout, long Plow);
 size_t conv_up2_ws_floats(int Cin, int Cout);

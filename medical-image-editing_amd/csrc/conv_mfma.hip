@@ -1158,6 +1158,9 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
                     int Cout, int ks, int dil, hipStream_t st, int acc) {
     *bias_done = 0;
     if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout)) return conv_direct_wgrad(in, dy, dw, ws, N, H, W, Cout, ks, dil, st, acc);
+    if (g_wgrad_variant != 1 && wg9_ok(in.C0, in.C1, Cout, ks, W, dil, (long)N * H * W) &&
+        conv_dil_wgrad_ok(in, N, H, W, Cout, ks, dil))       // dilated 32-channel layers: rows walked along the residue chains
+        return conv_dil_wgrad(in, dy, dw, ws, wg9_split_blocks(in.C0, Cout, (long)N * H * W), N, H, W, Cout, dil, acc, st);
     if (g_wgrad_variant != 1 && wg9_ok(in.C0, in.C1, Cout, ks, W, dil, (long)N * H * W)) {
         *bias_done = dbias != nullptr;
         const int Cin = in.C0 + in.C1;

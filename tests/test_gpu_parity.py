@@ -72,6 +72,14 @@ CONV_CASES = [
     (1, 64, 64, 48, 0, False, 24, 3, 12, True, False),
     (2, 16, 16, 64, 0, False, 128, 3, 1, True, False),
     (3, 24, 40, 16, 0, False, 96, 3, 2, True, False),
+    # dilated 32-channel layers on LDS-resident rows walked along the residue chains (conv_dil.hip): full 256-pixel rows,
+    # ragged H, fewer than 32 couts, dilation == H, several positions per workgroup, narrow rows (idle waves)
+    (2, 37, 256, 32, 0, False, 32, 3, 18, True, True),
+    (3, 40, 64, 32, 0, False, 24, 3, 2, True, False),
+    (2, 24, 128, 32, 0, False, 32, 3, 12, False, False),
+    (1, 8, 32, 32, 0, False, 32, 3, 8, True, False),
+    (4, 130, 64, 32, 0, False, 32, 3, 7, False, False),
+    (2, 200, 32, 32, 0, False, 32, 3, 5, True, True),
     # wide 1-channel stem (BASELINE config 4's first block 1 -> 256): lanes over the output channels
     (2, 24, 20, 1, 0, False, 256, 3, 1, True, False),
     (1, 32, 32, 1, 0, False, 256, 1, 1, False, False),
@@ -255,6 +263,9 @@ STATS_CASES_GEMM = [
     (2, 16, 16, 64, 128, 1, 1, False),
     (1, 32, 32, 32, 32, 3, 6, False),
     (2, 16, 16, 32, 160, 3, 2, False),
+    (2, 64, 256, 32, 32, 3, 18, False),   # row-chain kernel: one partial per output row
+    (3, 48, 64, 32, 24, 3, 2, False),
+    (2, 150, 96, 32, 32, 3, 12, False),
     (2, 32, 32, 64, 32, 3, 1, True),      # collapsed: four parity launches, each a quarter of every plane
     (1, 32, 64, 128, 64, 3, 1, True),
 ]
