@@ -93,6 +93,20 @@ int vqw_conv3x3_up2_wgrad_supported(int Cin, int Cout, int N, int h, int w);
 size_t vqw_conv3x3_up2_wgrad_ws_bytes(int Cin, int Cout, int N, int h, int w);
 int vqw_conv3x3_up2_wgrad(const float* x_low, const float* dy, float* dw_ohwi, float* dbias, void* ws, size_t ws_bytes,
                           int N, int h, int w, int Cin, int Cout, int accumulate, void* stream);
+/* Plain 3x3 stride-1 convolution (every F.conv2d(x, w, padding=1) of blocks.py / unet_*.py on >= 16 input and >= 32
+ * output channels) in Winograd F(2x2, 3x3) form: 4/9 of the direct form's matrix work, same fp32 arithmetic type; the
+ * result differs from the direct form by a few ulps of the accumulated magnitude (a different product / summation order).
+ * prepare() writes U = G w G^T [16][Cout][Cin] into ws (valid while w is unchanged).  The input gradient is the same
+ * call on dy with the U of the packed dgrad weights (vqw_pack_dgrad_weights), roles of Cin / Cout swapped.
+ * ..._fwd_stats: also leaves the following norm's statistics partials (see vqw_conv2d_fwd_stats); parts = 0: not served. */
+int vqw_conv3x3_wino_supported(int Cin, int Cout, int N, int H, int W);
+size_t vqw_conv3x3_wino_ws_bytes(int Cin, int Cout);
+int vqw_conv3x3_wino_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream);
+int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+                         int relu, void* stream);
+int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W);
+int vqw_conv3x3_wino_fwd_stats(const float* x, const void* ws, const float* bias, float* y, float* part, int N, int H, int W,
+                               int Cin, int Cout, void* stream);
 /* Gradient of the virtual input: g_full is [N,H,W,Ctot]; takes channels
  * [c_off, c_off+C).  up=1: dst[N,H/2,W/2,C] = 2x2 block sums; up=0: plain slice copy.
  * accumulate=1 adds into dst.                                                      */

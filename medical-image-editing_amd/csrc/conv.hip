@@ -74,6 +74,7 @@ extern "C" int vqw_set_conv_backend(int mode) {
     g_halo_mode = mode == 2 ? 1 : 0;
     g_wgrad_tile_mode = mode == 2 ? 1 : 0;
     g_dil_mode = mode == 2 ? 1 : 0;
+    g_wino_mode = mode == 2 ? 1 : 0;
     return old;
 }
 
@@ -291,6 +292,38 @@ extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_
     const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
     ProfScope ps(0, flops, (hipStream_t)stream, bytes);
     return conv_up2_dgrad(dy, (const float*)ws, dx_low, N, h, w, Cin, Cout, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// plain 3x3 convolution in Winograd F(2x2, 3x3) form (conv_wino.hip)
+extern "C" int vqw_conv3x3_wino_supported(int Cin, int Cout, int N, int H, int W) {
+    return g_conv_backend == 0 && conv_wino_ok(Cin, Cout, N, H, W) ? 1 : 0;
+}
+extern "C" size_t vqw_conv3x3_wino_ws_bytes(int Cin, int Cout) { return conv_wino_ws_floats(Cin, Cout) * sizeof(float) + 256; }
+extern "C" int vqw_conv3x3_wino_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream) {
+    VQW_CHECK(w_ohwi && ws && Cin > 0 && Cout > 0, "vqw_conv3x3_wino_prepare: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_conv3x3_wino_ws_bytes(Cin, Cout), "vqw_conv3x3_wino_prepare: workspace too small");
+    return conv_wino_prepare(w_ohwi, (float*)ws, Cin, Cout, (hipStream_t)stream);
+}
+extern "C" int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float* bias, float* y, int N, int H, int W, int Cin,
+                                    int Cout, int relu, void* stream) {
+    VQW_CHECK(x && ws && y && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_fwd: bad arguments");
+    VQW_CHECK(conv_wino_ok(Cin, Cout, N, H, W), "vqw_conv3x3_wino_fwd: unsupported shape (query vqw_conv3x3_wino_supported)");
+    const double px = (double)N * H * W;
+    ProfScope ps(0, 2.0 * px * 9.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + px * Cout + 16.0 * Cout * Cin));
+    return conv_wino_fwd(x, (const float*)ws, bias, y, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
+}
+extern "C" int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W) {
+    if (g_conv_backend != 0 || !conv_wino_ok(Cin, Cout, N, H, W)) return 0;
+    return conv_wino_stat_tiles(H, W);
+}
+extern "C" int vqw_conv3x3_wino_fwd_stats(const float* x, const void* ws, const float* bias, float* y, float* part, int N, int H,
+                                          int W, int Cin, int Cout, void* stream) {
+    VQW_CHECK(x && ws && y && part && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_fwd_stats: bad arguments");
+    VQW_CHECK(vqw_conv3x3_wino_fwd_stats_parts(Cin, Cout, N, H, W) > 0, "vqw_conv3x3_wino_fwd_stats: shape not served");
+    const double px = (double)N * H * W;
+    ProfScope ps(0, 2.0 * px * 9.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + px * Cout + 16.0 * Cout * Cin));
+    return conv_wino_fwd(x, (const float*)ws, bias, y, N, H, W, Cin, Cout, 0, (hipStream_t)stream, part);
 }
 
 extern "C" int vqw_conv3x3_up2_wgrad_supported(int Cin, int Cout, int N, int h, int w) {

@@ -46,6 +46,14 @@ int conv_dil_stat_tiles(int H);
 bool conv_dil_wgrad_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
 int conv_dil_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int max_slabs, int N, int H, int W, int Cout, int dil,
                    int acc, hipStream_t st);     // partials per plane written when `stats` is set
+// Winograd F(2x2, 3x3) forward / dgrad of plain 3x3 layers (conv_wino.hip)
+extern int g_wino_mode;
+bool conv_wino_ok(int Cin, int Cout, int N, int H, int W);
+size_t conv_wino_ws_floats(int Cin, int Cout);
+int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st);
+int conv_wino_stat_tiles(int H, int W);
+int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
+                  hipStream_t st, float* stats = nullptr);
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
 bool conv_up2_ok(int Cin, int Cout, long Plow);
 size_t conv_up2_ws_floats(int Cin, int Cout);

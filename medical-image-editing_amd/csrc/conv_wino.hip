@@ -1,0 +1,409 @@
+// 3x3 stride-1 convolution (forward and dgrad) in Winograd F(2x2, 3x3) form on the fp32 matrix cores, NHWC.
+//
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A      per 4x4 input patch d -> 2x2 outputs, 16 products instead of 36
+//
+// With channels: M[xi][tile][co] = sum_ci V[xi][tile][ci] U[xi][co][ci] for the 16 positions xi of the transformed patch,
+// i.e. 16 GEMMs that share nothing but their shapes: 4/9 of the direct form's matrix work.  U = G g G^T is computed once
+// per weight (k_wino_weights, in double, rounded once) and cached by the caller; V = B^T d B is never stored:
+//
+//   * a workgroup (8 waves) owns a 16 x 32 pixel output region x 32 couts and walks the input channels in chunks of 8.
+//     Wave w takes tile row w (output rows 2w, 2w+1 = 16 Winograd tiles) on v_mfma_f32_16x16x4_f32: M = 16 tiles,
+//     N = 16 couts (two N blocks), K = 4 channel pairs -> lane (tile m, pair q) holds channels 2q, 2q+1.
+//   * the raw (16+2) x 34 pixel halo of the chunk sits in LDS (10 floats per pixel: ds_read_b64 of 16 tiles x 4 pairs is
+//     conflict-free).  A lane reads the 4 x 4 patch of its tile at its two channels (16 ds_read_b64), transforms it in
+//     registers (32 add / sub per channel) and then owns the A operands of all 16 xi for this chunk: 64 MFMAs per wave
+//     follow from 16 LDS reads + 64 VALU instructions on the A side.  The B operand U[xi][co][ci] is streamed through LDS
+//     per chunk ([16][32 couts][12]: conflict-free ds_read_b64).
+//   * accumulators: 16 xi x 2 N blocks x 4 = 128 registers; the inverse transform A^T M A is lane-local (a lane holds
+//     all 16 xi of its (tile, cout) entries), followed by bias / ReLU / the statistics partials and the stores.
+//   * pipeline as in conv_halo.hip: the next (region, chunk) item is fetched into registers while the matrix cores work
+//     and written to the other LDS buffer in the second half of the item; one barrier per item.
+//
+// Rounding: the products differ from the direct form's (sums of four inputs times sums of weights), the result agrees
+// with it to a few fp32 ulps of the accumulated magnitude - the same class of difference as a changed summation order.
+#include "common.h"
+#include "conv_common.h"
+#include "mfma_util.h"
+#include <cstdlib>
+
+int g_wino_mode = 0;     // 0 auto, 1 off
+
+namespace {
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static const int g_wino_env = env_int("VQW_WINOGRAD", 1);
+static const int g_max_blocks = []{ int v = env_int("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
+
+// U[xi = i*4 + j][co][ci] = sum_{ky,kx} G[i][ky] g[co][ky][kx][ci] G[j][kx],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+__global__ void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+    const long n = (long)Cout * Cin;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(e / Cin), ci = (int)(e % Cin);
+        double g[3][3], t[4][3];
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+        for (int kx = 0; kx < 3; ++kx) {
+            t[0][kx] = g[0][kx];
+            t[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
+            t[2][kx] = 0.5 * (g[0][kx] - g[1][kx] + g[2][kx]);
+            t[3][kx] = g[2][kx];
+        }
+        for (int i = 0; i < 4; ++i) {
+            const double r0 = t[i][0], r1 = 0.5 * (t[i][0] + t[i][1] + t[i][2]), r2 = 0.5 * (t[i][0] - t[i][1] + t[i][2]), r3 = t[i][2];
+            u[((long)(i * 4 + 0) * Cout + co) * Cin + ci] = (float)r0;
+            u[((long)(i * 4 + 1) * Cout + co) * Cin + ci] = (float)r1;
+            u[((long)(i * 4 + 2) * Cout + co) * Cin + ci] = (float)r2;
+            u[((long)(i * 4 + 3) * Cout + co) * Cin + ci] = (float)r3;
+        }
+    }
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WinoArgs {
+    const float* x;
+    const float* u;
+    const float* bias;
+    float* y;
+    int N, H, W, Cin, Cout;
+    int tilesY, tilesX, nsp;   // regions per image column / row, total
+    int ntn, nch;              // cout tiles, channel chunks
+    int kt;                    // consecutive regions per workgroup
+    int relu;
+    unsigned nbx, nbu, nby;
+    float* stats;              // optional [N][tilesY*tilesX][Cout][2]: per-region (sum, M2 about the region mean)
+};
+
+constexpr int WN_KC = 8;                  // channels per chunk
+constexpr int WN_KPH = 10, WN_KPU = 12;   // floats per halo pixel / per U row in LDS
+constexpr int WN_TR = 16;                 // output rows per region
+constexpr int WN_HR = WN_TR + 2, WN_HW = 34;
+
+__global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
+    constexpr int NT = 512;
+    constexpr int HPIX = WN_HR * WN_HW;               // 612 halo pixels
+    constexpr int HF = HPIX * 2;                      // float4 per halo chunk
+    constexpr int LH = (HF + NT - 1) / NT;            // 3
+    constexpr int WF = 16 * 32 * 2;                   // float4 per U chunk
+    constexpr int LW = WF / NT;                       // 2
+    constexpr int HBUF = HPIX * WN_KPH;               // floats
+    constexpr int UBUF = 16 * 32 * WN_KPU;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                     // [2][HBUF]
+    float* Us = smem + 2 * HBUF;          // [2][UBUF]
+    float* Rs = Us + 2 * UBUF;            // [2][8 waves][32 couts][2] statistics of the waves' tile rows
+    float* Ds = Rs + 2 * 8 * 32 * 2;      // [512][4] parking space of the loader slots past the end of the halo
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
+
+    const int ntn = a.ntn, nch = a.nch;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % ntn;
+    const int sp0 = (lb / ntn) * a.kt;
+    const int co_base = tile_n * 32;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int nitems = my_tiles * nch;
+    const int per_img = a.tilesY * a.tilesX;
+    if (nitems <= 0) return;           // uniform per workgroup
+
+    // loader slots (fixed for the whole kernel): halo float4 f -> pixel f / 2, channel quad f % 2
+    int h_lds[LH], h_st[LH];
+    short h_y[LH], h_x[LH];
+    bool h_ok[LH];
+    const unsigned h_c = (unsigned)(tid & 1) * 4u;
+#pragma unroll
+    for (int j = 0; j < LH; ++j) {
+        const int f = tid + j * NT;
+        const bool ok = f < HF;
+        const int hp = ok ? f >> 1 : 0;
+        h_ok[j] = ok;
+        h_lds[j] = ok ? hp * WN_KPH + (int)h_c : (int)(Ds - Hs) + tid * 4;      // offset from Hs in buffer 0
+        h_st[j] = ok ? HBUF : 0;                                                 // ... + buf * h_st in buffer buf
+        h_y[j] = (short)(hp / WN_HW);
+        h_x[j] = (short)(hp % WN_HW);
+    }
+    unsigned u_off[LW];
+    int u_lds[LW];
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        const int f = tid + j * NT;
+        const int row = f >> 1, c4 = f & 1;          // row = xi * 32 + n
+        const int xi = row >> 5, n = row & 31;
+        const int co = co_base + n;
+        u_lds[j] = row * WN_KPU + c4 * 4;
+        u_off[j] = co < Cout ? (((unsigned)xi * Cout + co) * (unsigned)Cin + c4 * 4) * 4u : 0xFFFFFFFFu;
+    }
+
+    float4 rh[LH], ru[LW];
+    unsigned i_img = 0, i_cc4 = 0;
+    int i_y0 = 0, i_x0 = 0;
+    auto issue_setup = [&](int n, int tx, int ty, int ch) {
+        i_img = (unsigned)n * H * W;
+        i_y0 = ty * WN_TR - 1;
+        i_x0 = tx * 32 - 1;
+        i_cc4 = (unsigned)(ch * WN_KC) * 4u;
+    };
+    auto issue_h = [&](int j) {
+        const int yy = i_y0 + h_y[j], xx = i_x0 + h_x[j];
+        const bool ok = h_ok[j] & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+        const unsigned pix = i_img + (unsigned)(yy * W + xx);
+        rh[j] = buf_ld4(rsx, sel_u32(ok, pix * (unsigned)Cin * 4u + i_cc4 + h_c * 4u, a.nbx));
+    };
+    auto issue_u = [&](int j) { ru[j] = buf_ld4(rsu, sel_u32(u_off[j] == 0xFFFFFFFFu, a.nbu, u_off[j] + i_cc4)); };
+    auto commit_h = [&](int j, int buf) {       // a halo pixel is 40 bytes: two 8-byte-aligned halves
+        float* p = &Hs[buf * h_st[j] + h_lds[j]];
+        f32x2 lo, hi;
+        lo.x = rh[j].x; lo.y = rh[j].y; hi.x = rh[j].z; hi.y = rh[j].w;
+        *(f32x2*)p = lo;
+        *(f32x2*)(p + 2) = hi;
+    };
+    auto commit_u = [&](int j, int buf) { *(float4*)&Us[buf * UBUF + u_lds[j]] = ru[j]; };
+
+    int cn, ctx, cty, ch = 0;
+    {
+        cn = sp0 / per_img;
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    issue_setup(cn, ctx, cty, 0);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) issue_h(j);
+#pragma unroll
+    for (int j = 0; j < LW; ++j) issue_u(j);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) commit_h(j, 0);
+#pragma unroll
+    for (int j = 0; j < LW; ++j) commit_u(j, 0);
+    __syncthreads();
+
+    // fragment bases: lane (tile m = lane & 15, channel pair q = lane >> 4)
+    const int m = lane & 15, q = lane >> 4;
+    const int a_base = ((2 * wv) * WN_HW + 2 * m) * WN_KPH + 2 * q;      // patch (r, c) adds (r * 34 + c) * KPH
+    const int b_base = m * WN_KPU + 2 * q;                               // (xi, nb) adds (xi * 32 + nb * 16) * KPU
+
+    float bvv[2];
+    unsigned co_off[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int co = co_base + nb * 16 + m;
+        bvv[nb] = (a.bias && co < Cout) ? a.bias[co] : 0.f;
+        co_off[nb] = co < Cout ? (unsigned)co : 0xFFFFFFFFu;
+    }
+    const float lo = a.relu ? 0.f : -__builtin_inff();
+
+    f32x4 acc[16][2];
+    int cur = 0, spar = 0;
+    int fold_t = -1;
+    auto fold_stats = [&]() {          // after the barrier that follows a finished region
+        if (fold_t < 0) return;        // uniform
+        if (tid < 32 && co_base + tid < Cout) {
+            const float* R = Rs + spar * (8 * 32 * 2) + tid * 2;
+            float s1 = R[0], s2 = R[1];          // tile rows of 64 pixels, merged in row order
+#pragma unroll
+            for (int r = 1; r < 8; ++r) stat_merge(s1, s2, (float)(64 * r), R[r * 64], R[r * 64 + 1], 64.f);
+            float* o = a.stats + ((size_t)fold_t * Cout + co_base + tid) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+        fold_t = -1;
+        spar ^= 1;
+    };
+
+    for (int item = 0; item < nitems; ++item) {
+        if (ch == 0) {
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[xi][nb][r] = 0.f;
+        }
+        const int nxch = ch + 1 == nch ? 0 : ch + 1;
+        const int adv = ch + 1 == nch ? 1 : 0;
+        const int ty1 = cty + adv, wy = ty1 == a.tilesY ? 1 : 0;
+        const int nty = wy ? 0 : ty1;
+        const int tx1 = ctx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        const int ntx = wx ? 0 : tx1;
+        const int nn = cn + wx;
+        issue_setup(nn, ntx, nty, nxch);
+        const float* Hc = Hs + cur * HBUF + a_base;
+        const float* Uc = Us + cur * UBUF + b_base;
+
+        // raw patch of the lane's tile at its two channels, then V = B^T d B in place (rows, then columns)
+        f32x2 d[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[r][c] = *(const f32x2*)&Hc[(r * WN_HW + c) * WN_KPH];
+        // the next item's loads go out while the patch is on its way
+#pragma unroll
+        for (int j = 0; j < LH; ++j) issue_h(j);
+#pragma unroll
+        for (int j = 0; j < LW; ++j) issue_u(j);
+        float v[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float e[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = d[0][c][t], d1 = d[1][c][t], d2 = d[2][c][t], d3 = d[3][c][t];
+                e[0][c] = d0 - d2; e[1][c] = d1 + d2; e[2][c] = d2 - d1; e[3][c] = d1 - d3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[t][r * 4 + 0] = e[r][0] - e[r][2];
+                v[t][r * 4 + 1] = e[r][1] + e[r][2];
+                v[t][r * 4 + 2] = e[r][2] - e[r][1];
+                v[t][r * 4 + 3] = e[r][1] - e[r][3];
+            }
+        }
+        // 16 xi x 2 N blocks x 2 channels of the pair; the B fragments run one xi ahead
+        f32x2 bf[2][2];
+        auto ldb = [&](int xi, int s) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) bf[s][nb] = *(const f32x2*)&Uc[(xi * 32 + nb * 16) * WN_KPU];
+        };
+        ldb(0, 0);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const int s = xi & 1;
+            if (xi + 1 < 16) ldb(xi + 1, s ^ 1);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                acc[xi][nb] = MFMA16(v[0][xi], bf[s][nb].x, acc[xi][nb]);
+                acc[xi][nb] = MFMA16(v[1][xi], bf[s][nb].y, acc[xi][nb]);
+            }
+            if (xi == 9) {         // second half of the item: the prefetched item goes to the other LDS buffer
+#pragma unroll
+                for (int j = 0; j < LH; ++j) commit_h(j, cur ^ 1);
+#pragma unroll
+                for (int j = 0; j < LW; ++j) commit_u(j, cur ^ 1);
+            }
+        }
+
+        if (ch == nch - 1) {
+            // Y = A^T M A per (tile, cout) entry: lane-local over the 16 xi; then bias / ReLU, statistics, stores
+            const int yrow0 = cty * WN_TR + 2 * wv;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float yv[16];      // [r][a][b]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sj[2][4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float m0 = acc[0 * 4 + j][nb][r], m1 = acc[1 * 4 + j][nb][r], m2 = acc[2 * 4 + j][nb][r], m3 = acc[3 * 4 + j][nb][r];
+                        sj[0][j] = (m0 + m1) + m2;
+                        sj[1][j] = (m1 - m2) - m3;
+                    }
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa) {
+                        yv[r * 4 + aa * 2 + 0] = fmaxf(((sj[aa][0] + sj[aa][1]) + sj[aa][2]) + bvv[nb], lo);
+                        yv[r * 4 + aa * 2 + 1] = fmaxf(((sj[aa][1] - sj[aa][2]) - sj[aa][3]) + bvv[nb], lo);
+                    }
+                }
+                // C/D layout (16x16): col = lane & 15 (cout), row = 4 (lane >> 4) + r (tile): pixels (2 wv + a, 2 tile + b)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) {
+                    const int yy = yrow0 + aa;
+                    const bool ok = (co_off[nb] != 0xFFFFFFFFu) & (yy < H);
+                    const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)(ctx * 32 + 8 * q)) * (unsigned)Cout + co_off[nb];
+                    const int voff = (int)sel_u32(ok, base * 4u, a.nby);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+                }
+                if (a.stats) {     // uniform: H % 16 == 0 whenever statistics are requested
+                    float t1, t2;
+                    lane_stats<16>(yv, t1, t2);
+                    stat_merge_eq(t1, t2, __shfl_xor(t1, 16, 64), __shfl_xor(t2, 16, 64), 1.f / 32.f);
+                    stat_merge_eq(t1, t2, __shfl_xor(t1, 32, 64), __shfl_xor(t2, 32, 64), 1.f / 64.f);
+                    if (lane < 16) {
+                        float* R = Rs + spar * (8 * 32 * 2);
+                        R[(wv * 32 + nb * 16 + lane) * 2] = t1;
+                        R[(wv * 32 + nb * 16 + lane) * 2 + 1] = t2;
+                    }
+                }
+            }
+            if (a.stats) fold_t = (cn * a.tilesX + ctx) * a.tilesY + cty;
+        }
+        ch = nxch; cn = nn; ctx = ntx; cty = nty;
+        __syncthreads();               // the item committed buffer cur^1
+        cur ^= 1;
+        fold_stats();
+    }
+}
+
+}  // namespace
+
+// 3x3, dilation 1, one source at full resolution, whole 32-pixel column strips, channels in chunks of 8
+bool conv_wino_ok(int Cin, int Cout, int N, int H, int W) {
+    if (g_wino_mode != 0 || !g_wino_env) return false;
+    if (Cin % 8 != 0 || Cin < 16 || Cout < 32 || Cout % 4 != 0 || W % 32 != 0 || H < 2 || N < 1) return false;
+    // (a batch beyond the 32-bit descriptor range runs as image groups: one image must fit)
+    return (long)H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L && 16L * Cout * Cin * 4 <= 0xFFFFFFE0L;
+}
+size_t conv_wino_ws_floats(int Cin, int Cout) { return (size_t)16 * Cout * Cin; }
+int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st) {
+    const long n = (long)Cout * Cin;
+    k_wino_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, u, Cout, Cin);
+    VQW_LAUNCH_CHECK("wino_weights");
+    return VQW_OK;
+}
+int conv_wino_stat_tiles(int H, int W) { return H % WN_TR == 0 ? (H / WN_TR) * (W / 32) : 0; }
+
+int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
+                  hipStream_t st, float* stats) {
+    {   // images per launch such that no tensor exceeds the 32-bit descriptor range (as vqw_conv2d_fwd does)
+        const long per_image = (long)H * W * (Cin > Cout ? Cin : Cout) * 4;
+        const long g = 0xFFFFFFE0L / per_image;
+        if (g < N) {
+            const int parts = stats ? conv_wino_stat_tiles(H, W) : 0;
+            for (int n0 = 0; n0 < N; n0 += (int)g) {
+                const int nn = N - n0 < g ? N - n0 : (int)g;
+                const size_t px = (size_t)n0 * H * W;
+                const int rc = conv_wino_fwd(x + px * Cin, u, bias, y + px * Cout, nn, H, W, Cin, Cout, relu, st,
+                                             stats ? stats + (size_t)n0 * parts * Cout * 2 : nullptr);
+                if (rc) return rc;
+            }
+            return VQW_OK;
+        }
+    }
+    constexpr size_t lds = (size_t)(2 * WN_HR * WN_HW * WN_KPH + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "Winograd buffers do not fit the 160 KB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            vqw_set_error("conv_wino: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    WinoArgs a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = ceil_div(H, WN_TR); a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
+    a.ntn = ceil_div(Cout, 32); a.nch = Cin / WN_KC;
+    a.relu = relu;
+    a.stats = stats;
+    const long P = (long)N * H * W;
+    a.nbx = (unsigned)(P * Cin * 4);
+    a.nbu = (unsigned)(16L * Cout * Cin * 4);
+    a.nby = (unsigned)(P * Cout * 4);
+    int groups = g_max_blocks / a.ntn;
+    if (groups < 1) groups = 1;
+    const int even = ceil_div(a.nsp, groups);
+    a.kt = even < 1 ? 1 : even;
+    k_conv_wino<<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino");
+    return VQW_OK;
+}

@@ -38,6 +38,12 @@ SIGNATURES = {
     "vqw_conv3x3_up2_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_up2_fwd_stats": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_conv3x3_wino_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "vqw_conv3x3_wino_ws_bytes": (c_sz, [c_i, c_i]),
+    "vqw_conv3x3_wino_prepare": (c_i, [c_p, c_p, c_sz, c_i, c_i, c_p]),
+    "vqw_conv3x3_wino_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_conv3x3_wino_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i]),
+    "vqw_conv3x3_wino_fwd_stats": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_wgrad_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_up2_wgrad_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_up2_wgrad": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -119,7 +125,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def load():

@@ -340,6 +340,13 @@ def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, 
 # ----------------------------------------------------------------------------------------------
 # convolution
 # ----------------------------------------------------------------------------------------------
+def _wino_weights(L, w_ohwi, Cin, Cout):
+    """U = G w G^T [16][Cout][Cin] of a 3x3 layer (vqw_conv3x3_wino_prepare) in a fresh buffer."""
+    buf = _ws(L.vqw_conv3x3_wino_ws_bytes(Cin, Cout), w_ohwi)
+    _lib.check(L.vqw_conv3x3_wino_prepare(_p(w_ohwi), _p(buf), buf.numel(), Cin, Cout, _st()), "vqw_conv3x3_wino_prepare")
+    return buf
+
+
 def _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dil, relu=False):
     y = empty_nhwc(N, Cout, H, W, x0)
     _lib.check(_L().vqw_conv2d_fwd(_p(x0), x0.shape[1], int(up0), _p(x1), 0 if x1 is None else x1.shape[1],
@@ -348,6 +355,13 @@ def _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dil, relu=False):
 
 
 CONV_STATS = os.environ.get("VQW_CONV_STATS", "1") != "0"      # 0: InstanceNorm always reduces itself (A/B timing)
+# Winograd F(2x2, 3x3) form of plain 3x3 layers.  The INPUT GRADIENT takes it whenever the library serves the shape
+# (VQW_WINOGRAD=0 turns the kernels off altogether): that convolution is linear in dy, so its rounding difference (a few ulps
+# of the accumulated magnitude) reaches the parameter gradients unamplified.  The FORWARD does not by default: forward
+# activations decide discrete events (ReLU masks, pooling arg-max, code ids), and on the reference's step fixtures the
+# Winograd forward moved the parameter gradients 3-5x the reference's own fp32 spread away from its fp64 gradient
+# (direct form: within it) - DESIGN.md section 2.  VQW_WINOGRAD_FWD=1 opts in (forward-only uses, throughput runs).
+WINOGRAD_FWD = os.environ.get("VQW_WINOGRAD_FWD", "0") == "1"
 
 
 class _Conv2d(torch.autograd.Function):
@@ -388,6 +402,23 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
                            "vqw_conv3x3_up2_fwd")
+        elif WINOGRAD_FWD and not up0 and x1 is None and ks == 3 and dilation == 1 and \
+                _L().vqw_conv3x3_wino_supported(Cin, Cout, N, H, W) and \
+                (not (want_stats and not relu) or _L().vqw_conv3x3_wino_fwd_stats_parts(Cin, Cout, N, H, W) > 0
+                 or _L().vqw_conv2d_fwd_stats_parts(Cin, 0, 0, N, H, W, Cout, ks, dilation) == 0):
+            # (wanted statistics that only the direct form can leave for this height keep the direct form)
+            # plain 3x3 layer: Winograd F(2x2, 3x3), 4/9 of the matrix work; U = G w G^T is kept while w is unchanged
+            L = _L()
+            u = _cached(weight, "wino", lambda: _wino_weights(L, w, Cin, Cout))
+            y = empty_nhwc(N, Cout, H, W, x0)
+            nparts = L.vqw_conv3x3_wino_fwd_stats_parts(Cin, Cout, N, H, W) if (want_stats and not relu) else 0
+            if nparts > 0:
+                part = torch.empty(N * nparts * Cout * 2, dtype=torch.float32, device=x0.device)
+                _lib.check(L.vqw_conv3x3_wino_fwd_stats(_p(x0), _p(u), _p(bias), _p(y), _p(part), N, H, W, Cin, Cout, _st()),
+                           "vqw_conv3x3_wino_fwd_stats")
+            else:
+                _lib.check(L.vqw_conv3x3_wino_fwd(_p(x0), _p(u), _p(bias), _p(y), N, H, W, Cin, Cout, int(relu), _st()),
+                           "vqw_conv3x3_wino_fwd")
         else:
             nparts = 0
             if want_stats and not relu:
@@ -456,8 +487,13 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             return buf
         wt = _cached(w, "dgrad", _pack)
         g_full = empty_nhwc(N, Cin, H, W, gy)
-        _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
-                   "vqw_conv2d_fwd(dgrad)")
+        if ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W):
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+            _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(g_full), N, H, W, Cout, Cin, 0, _st()),
+                       "vqw_conv3x3_wino_fwd(dgrad)")
+        else:
+            _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
+                       "vqw_conv2d_fwd(dgrad)")
         if not up0 and x1 is None:
             g0 = g_full
         else:

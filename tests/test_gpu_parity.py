@@ -80,6 +80,13 @@ CONV_CASES = [
     (1, 8, 32, 32, 0, False, 32, 3, 8, True, False),
     (4, 130, 64, 32, 0, False, 32, 3, 7, False, False),
     (2, 200, 32, 32, 0, False, 32, 3, 5, True, True),
+    # Winograd F(2x2, 3x3) form of plain 3x3 layers (conv_wino.hip): ragged H (not a multiple of the 16-row region, odd),
+    # several 32-pixel strips, two cout tiles with a partial one, 2 .. 16 channel chunks, bias + ReLU epilogue
+    (2, 16, 32, 16, 0, False, 32, 3, 1, True, True),
+    (1, 23, 64, 24, 0, False, 48, 3, 1, True, False),
+    (3, 40, 32, 64, 0, False, 64, 3, 1, False, False),
+    (1, 16, 96, 128, 0, False, 32, 3, 1, True, True),
+    (2, 7, 32, 32, 0, False, 96, 3, 1, True, False),
     # wide 1-channel stem (BASELINE config 4's first block 1 -> 256): lanes over the output channels
     (2, 24, 20, 1, 0, False, 256, 3, 1, True, False),
     (1, 32, 32, 1, 0, False, 256, 1, 1, False, False),
@@ -104,6 +111,23 @@ def _conv_ref(x0, x1, w, b, up, dil, relu):
     k = w.shape[-1]
     y = F.conv2d(xin, w, b, padding=dil * (k // 2), dilation=dil)
     return torch.relu(y) if relu else y
+
+
+@pytest.fixture
+def winograd_forward():
+    """The Winograd form also for the FORWARD of plain 3x3 layers (opt-in in the product: VQW_WINOGRAD_FWD=1; the input
+    gradient takes it by default)."""
+    ops = _ops()
+    old = ops.WINOGRAD_FWD
+    ops.WINOGRAD_FWD = True
+    yield ops
+    ops.WINOGRAD_FWD = old
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[7] == 3 and c[8] == 1 and not c[5] and not c[4] and c[2] % 32 == 0
+                                  and c[3] >= 16 and c[6] >= 32])
+def test_conv2d_winograd_forward(case, winograd_forward):
+    test_conv2d(case, 0)
 
 
 @pytest.mark.parametrize("backend", [0, 1, 2])     # auto, generic VALU kernels, implicit-GEMM MFMA without halo tiles
@@ -254,6 +278,8 @@ STATS_CASES = [
     (1, 24, 64, 64, 0, False, 32),     # streamed chunks, three tile rows
     (2, 16, 32, 64, 0, False, 48),     # two cout tiles, the second one partial
     (2, 16, 32, 16, 0, False, 16),     # 16-wide MFMA variant
+    (2, 48, 64, 24, 0, False, 96),     # Winograd form: three regions per strip, three cout tiles
+    (1, 16, 32, 128, 0, False, 48),    # Winograd form: 16 chunks, partial cout tile
     (2, 32, 32, 32, 16, True, 16),     # up-sampled + concat source, 16 couts
     (1, 32, 64, 64, 32, True, 32),     # two sources, 32 couts
 ]
@@ -297,6 +323,11 @@ def test_conv_epilogue_statistics_implicit_gemm(case):
     assert_close(ops.instance_norm(y, relu=True, part=part), ops.instance_norm(y, relu=True), 2e-6, "instance norm from conv partials")
 
 
+@pytest.mark.parametrize("case", [c for c in STATS_CASES if not c[4] and not c[5] and c[3] >= 16 and c[6] >= 32])
+def test_conv_epilogue_statistics_winograd_forward(case, winograd_forward):
+    test_conv_epilogue_statistics(case)
+
+
 @pytest.mark.parametrize("case", STATS_CASES)
 def test_conv_epilogue_statistics(case):
     """conv2d(..., want_stats=True): the per-tile (sum, M2) partials of the halo kernel's epilogue combine to the plane sums
@@ -311,7 +342,13 @@ def test_conv_epilogue_statistics(case):
     y, part = ops.conv2d(x0, w, b, up2x=up, skip=x1, want_stats=True)
     assert part is not None, "shape should be served by the halo kernel"
     y_ref = ops.conv2d(x0, w, b, up2x=up, skip=x1)
-    assert torch.equal(y, y_ref)
+    # the same kernel with and without the statistics epilogue, unless only one of the two forms serves the statistics for
+    # the shape (a plain layer whose H is not a multiple of the Winograd region keeps the direct form when they are wanted)
+    same_kernel = not ops.WINOGRAD_FWD or up or C1 or H % 16 == 0 or not ops._L().vqw_conv3x3_wino_supported(C0, Cout, N, H, W)
+    if same_kernel:
+        assert torch.equal(y, y_ref)
+    else:
+        assert_close(y, y_ref, 2e-6, "direct vs Winograd form")
     s1, s2 = _plane_sums_from_partials(part, N, Cout, H * W)
     yd = y.double().cpu()
     assert_close(s1, yd.sum((2, 3)), 2e-6, "sum", atol=1e-4)

@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--filter", default="", help="substring filter on the shape label")
+    ap.add_argument("--no-wino", action="store_true", help="direct form for every layer")
     ap.add_argument("--backend", type=int, default=0, help="vqw_set_conv_backend mode (2 = no halo-tile kernel)")
     args = ap.parse_args()
     dev = "cuda"
@@ -97,11 +98,30 @@ def main():
         ws = torch.empty(L.vqw_conv2d_wgrad_ws_bytes(c0, c1, N, h, h, co, ks), dtype=torch.uint8, device=dev)
         flops = 2.0 * N * h * h * co * ks * ks * cin
 
+        # plain 3x3 layers take the Winograd form where the library serves it (as hipops.ops does); TFLOP/s stay the
+        # direct form's FLOPs over the time ("effective")
+        plain = ks == 3 and dil == 1 and not args.no_wino
+        wino_f = plain and not up and not c1 and L.vqw_conv3x3_wino_supported(cin, co, N, h, h)
+        wino_d = plain and L.vqw_conv3x3_wino_supported(co, cin, N, h, h)
+        uf = torch.empty(L.vqw_conv3x3_wino_ws_bytes(cin, co), dtype=torch.uint8, device=dev)
+        ud = torch.empty(L.vqw_conv3x3_wino_ws_bytes(co, cin), dtype=torch.uint8, device=dev)
+        if wino_f:
+            _lib.check(L.vqw_conv3x3_wino_prepare(p(w), p(uf), uf.numel(), cin, co, st()))
+        if wino_d:
+            _lib.check(L.vqw_pack_dgrad_weights(p(w), p(wt), co, cin, ks, st()))
+            _lib.check(L.vqw_conv3x3_wino_prepare(p(wt), p(ud), ud.numel(), co, cin, st()))
+
         def fwd():
-            _lib.check(L.vqw_conv2d_fwd(p(x0), c0, int(up), p(x1), c1, p(w), p(b), p(y), N, h, h, co, ks, dil, 0, st()))
+            if wino_f:
+                _lib.check(L.vqw_conv3x3_wino_fwd(p(x0), p(uf), p(b), p(y), N, h, h, cin, co, 0, st()))
+            else:
+                _lib.check(L.vqw_conv2d_fwd(p(x0), c0, int(up), p(x1), c1, p(w), p(b), p(y), N, h, h, co, ks, dil, 0, st()))
 
         def dgrad():
-            _lib.check(L.vqw_conv2d_fwd(p(dy), co, 0, None, 0, p(wt), None, p(gfull), N, h, h, cin, ks, dil, 0, st()))
+            if wino_d:
+                _lib.check(L.vqw_conv3x3_wino_fwd(p(dy), p(ud), None, p(gfull), N, h, h, co, cin, 0, st()))
+            else:
+                _lib.check(L.vqw_conv2d_fwd(p(dy), co, 0, None, 0, p(wt), None, p(gfull), N, h, h, cin, ks, dil, 0, st()))
 
         def wgrad():
             _lib.check(L.vqw_conv2d_wgrad(p(x0), c0, int(up), p(x1), c1, p(dy), p(dw), p(db), p(ws), ws.numel(), N, h, h, co, ks,
