@@ -25,6 +25,7 @@
 #include "conv_common.h"
 #include "mfma_util.h"
 #include <cstdlib>
+#include <type_traits>
 
 int g_wino_mode = 0;     // 0 auto, 1 off
 
@@ -81,6 +82,9 @@ constexpr int WN_KC = 8;                  // channels per chunk
 constexpr int WN_KPH = 10, WN_KPU = 12;   // floats per halo pixel / per U row in LDS
 constexpr int WN_TR = 16;                 // output rows per region
 constexpr int WN_HR = WN_TR + 2, WN_HW = 34;
+#ifndef WN_CP
+#define WN_CP 22                         // MFMA position of the first LDS commit of the prefetched item
+#endif
 
 __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     constexpr int NT = 512;
@@ -93,8 +97,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     constexpr int UBUF = 16 * 32 * WN_KPU;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Hs = smem;                     // [2][HBUF]
-    float* Us = smem + 2 * HBUF;          // [2][UBUF]
+    float* Hs = smem;                     // [3][HBUF]: ring of the items i, i+1, i+2
+    float* Us = smem + 3 * HBUF;          // [2][UBUF]
     float* Rs = Us + 2 * UBUF;            // [2][8 waves][32 couts][2] statistics of the waves' tile rows
     float* Ds = Rs + 2 * 8 * 32 * 2;      // [512][4] parking space of the loader slots past the end of the halo
 
@@ -157,7 +161,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     };
     auto issue_u = [&](int j) { ru[j] = buf_ld4(rsu, sel_u32(u_off[j] == 0xFFFFFFFFu, a.nbu, u_off[j] + i_cc4)); };
     auto commit_h = [&](int j, int buf) {       // a halo pixel is 40 bytes: two 8-byte-aligned halves
-        float* p = &Hs[buf * h_st[j] + h_lds[j]];
+        float* p = &Hs[(h_st[j] ? buf : 0) + h_lds[j]];
         f32x2 lo, hi;
         lo.x = rh[j].x; lo.y = rh[j].y; hi.x = rh[j].z; hi.y = rh[j].w;
         *(f32x2*)p = lo;
@@ -165,6 +169,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     };
     auto commit_u = [&](int j, int buf) { *(float4*)&Us[buf * UBUF + u_lds[j]] = ru[j]; };
 
+    // item cursors: (image, strip, region row, chunk) of items i, i+1, i+2
     int cn, ctx, cty, ch = 0;
     {
         cn = sp0 / per_img;
@@ -172,6 +177,22 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
         ctx = rem / a.tilesY;
         cty = rem - ctx * a.tilesY;
     }
+    auto advance = [&](int& n, int& tx, int& ty, int& c) {     // the item after (n, tx, ty, c)
+        const int adv = c + 1 == nch ? 1 : 0;
+        c = adv ? 0 : c + 1;
+        const int ty1 = ty + adv, wy = ty1 == a.tilesY ? 1 : 0;
+        ty = wy ? 0 : ty1;
+        const int tx1 = tx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        tx = wx ? 0 : tx1;
+        n += wx;
+    };
+    int n1 = cn, tx1 = ctx, ty1 = cty, ch1 = 0;
+    advance(n1, tx1, ty1, ch1);
+    int n2 = n1, tx2 = tx1, ty2 = ty1, ch2 = ch1;
+    advance(n2, tx2, ty2, ch2);
+
+    // prologue: halo of items 0 and 1 into halo buffers 0 and 1, U chunk of item 0 into U buffer 0.  (Items past the
+    // workgroup's share read another region or nothing - out-of-range offsets return 0 - and are never consumed.)
     issue_setup(cn, ctx, cty, 0);
 #pragma unroll
     for (int j = 0; j < LH; ++j) issue_h(j);
@@ -181,6 +202,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     for (int j = 0; j < LH; ++j) commit_h(j, 0);
 #pragma unroll
     for (int j = 0; j < LW; ++j) commit_u(j, 0);
+    issue_setup(n1, tx1, ty1, ch1);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) issue_h(j);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) commit_h(j, HBUF);
     __syncthreads();
 
     // fragment bases: lane (tile m = lane & 15, channel pair q = lane >> 4)
@@ -199,7 +225,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     const float lo = a.relu ? 0.f : -__builtin_inff();
 
     f32x4 acc[16][2];
-    int cur = 0, spar = 0;
+    int spar = 0;
     int fold_t = -1;
     auto fold_stats = [&]() {          // after the barrier that follows a finished region
         if (fold_t < 0) return;        // uniform
@@ -216,8 +242,63 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
         spar ^= 1;
     };
 
-    for (int item = 0; item < nitems; ++item) {
-        if (ch == 0) {
+    // V = B^T d B of the lane's tile at its two channels.  The 64 add / sub of an item's transform are single VALU
+    // instructions placed two per MFMA in the second half of the PREVIOUS item (inline asm: the compiler's SLP pass would
+    // pair them into v_pk_add_f32, which holds the vector issue port twice as long beside MFMAs), column by column as the
+    // patch columns arrive from LDS, then row by row: row r overwrites the operands xi = 4r..4r+3 the matrix cores have
+    // just consumed.
+    auto fadd = [](float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto fsub = [](float x, float y) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    f32x2 dcol[2][4];                  // two patch columns in flight
+    float e[2][4][4];                  // [channel][row][column] after the column pass
+    float v[2][2][16];                 // [parity of the item][channel of the pair][xi]
+    // LDS fragment reads must stay plain ds_read_b64 (32-lane groups over 64 banks: conflict-free with these strides, 2 LDS
+    // cycles).  Two reads off one base register get merged into ds_read2_b64, which is served in 16-lane groups over 32
+    // banks: 8 cycles and 2-way conflicts on these layouts - the LDS, not the matrix cores, then paces the item.  Each read
+    // of a pair / quad therefore goes through a base register of its own that the compiler cannot relate to the others.
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    const int a_row0 = opaque(a_base), a_row1 = opaque(a_base + WN_HW * WN_KPH), a_row2 = opaque(a_base + 2 * WN_HW * WN_KPH),
+              a_row3 = opaque(a_base + 3 * WN_HW * WN_KPH);
+    const int b_nb0 = opaque(b_base), b_nb1 = opaque(b_base + 16 * WN_KPU);
+    auto read_col = [&](int hbuf, int c) {
+        const float* Hc = Hs + hbuf + c * WN_KPH;
+        dcol[c & 1][0] = *(const f32x2*)&Hc[a_row0];
+        dcol[c & 1][1] = *(const f32x2*)&Hc[a_row1];
+        dcol[c & 1][2] = *(const f32x2*)&Hc[a_row2];
+        dcol[c & 1][3] = *(const f32x2*)&Hc[a_row3];
+    };
+    auto col_op = [&](int c, int k) {          // k = 0..7: channel k / 4, output row k % 4 of column c
+        const int t = k >> 2, rr = k & 3;
+        const float d0 = dcol[c & 1][0][t], d1 = dcol[c & 1][1][t], d2 = dcol[c & 1][2][t], d3 = dcol[c & 1][3][t];
+        e[t][rr][c] = rr == 0 ? fsub(d0, d2) : rr == 1 ? fadd(d1, d2) : rr == 2 ? fsub(d2, d1) : fsub(d1, d3);
+    };
+    auto row_op = [&](int par, int r, int k) { // k = 0..7: channel k / 4, output column k % 4 of row r
+        const int t = k >> 2, cc = k & 3;
+        const float e0 = e[t][r][0], e1 = e[t][r][1], e2 = e[t][r][2], e3 = e[t][r][3];
+        v[par][t][r * 4 + cc] = cc == 0 ? fsub(e0, e2) : cc == 1 ? fadd(e1, e2) : cc == 2 ? fsub(e2, e1) : fsub(e1, e3);
+    };
+    {   // item 0: nothing to hide behind yet
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            read_col(0, c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) col_op(c, k);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) row_op(0, r, k);
+    }
+
+    int hA = 0, hB = HBUF, hC = 2 * HBUF;      // halo buffers (float offsets) of items i, i+1, i+2
+    int ucur = 0;
+
+    // One item; PAR = parity of the item (selects which half of v holds its operands; the other half receives the next
+    // item's).  Everything but the MFMAs is cut into slots behind single MFMAs (sched_barrier keeps them there).
+    auto body = [&](auto PAR, auto FIRST) {
+        constexpr int par = decltype(PAR)::value;
+        constexpr bool first = decltype(FIRST)::value;      // first chunk of a region: the accumulators start from 0
+        if (!first && ch == 0) {
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
@@ -225,67 +306,48 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[xi][nb][r] = 0.f;
         }
-        const int nxch = ch + 1 == nch ? 0 : ch + 1;
-        const int adv = ch + 1 == nch ? 1 : 0;
-        const int ty1 = cty + adv, wy = ty1 == a.tilesY ? 1 : 0;
-        const int nty = wy ? 0 : ty1;
-        const int tx1 = ctx + wy, wx = tx1 == a.tilesX ? 1 : 0;
-        const int ntx = wx ? 0 : tx1;
-        const int nn = cn + wx;
-        issue_setup(nn, ntx, nty, nxch);
-        const float* Hc = Hs + cur * HBUF + a_base;
-        const float* Uc = Us + cur * UBUF + b_base;
-
-        // raw patch of the lane's tile at its two channels, then V = B^T d B in place (rows, then columns)
-        f32x2 d[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[r][c] = *(const f32x2*)&Hc[(r * WN_HW + c) * WN_KPH];
-        // the next item's loads go out while the patch is on its way
-#pragma unroll
-        for (int j = 0; j < LH; ++j) issue_h(j);
-#pragma unroll
-        for (int j = 0; j < LW; ++j) issue_u(j);
-        float v[2][16];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float e[4][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float d0 = d[0][c][t], d1 = d[1][c][t], d2 = d[2][c][t], d3 = d[3][c][t];
-                e[0][c] = d0 - d2; e[1][c] = d1 + d2; e[2][c] = d2 - d1; e[3][c] = d1 - d3;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[t][r * 4 + 0] = e[r][0] - e[r][2];
-                v[t][r * 4 + 1] = e[r][1] + e[r][2];
-                v[t][r * 4 + 2] = e[r][2] - e[r][1];
-                v[t][r * 4 + 3] = e[r][1] - e[r][3];
-            }
-        }
-        // 16 xi x 2 N blocks x 2 channels of the pair; the B fragments run one xi ahead
-        f32x2 bf[2][2];
+        const float* Uc = Us + ucur * UBUF;
+        f32x2 bf[3][2];                // B fragments run two xi ahead of the MFMAs that consume them
         auto ldb = [&](int xi, int s) {
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) bf[s][nb] = *(const f32x2*)&Uc[(xi * 32 + nb * 16) * WN_KPU];
+            bf[s][0] = *(const f32x2*)&Uc[b_nb0 + xi * 32 * WN_KPU];
+            bf[s][1] = *(const f32x2*)&Uc[b_nb1 + xi * 32 * WN_KPU];
+        };
+        auto slot = [&](int p) {       // p = 0..63: MFMA position (compile-time after unrolling)
+            // loads (address arithmetic included) behind the first MFMAs: halo of item i+2, U chunk of item i+1
+            if (p == 0) issue_setup(n2, tx2, ty2, ch2);
+            if (p >= 1 && p < 1 + LH) issue_h(p - 1);
+            if (p == 1 + LH) i_cc4 = (unsigned)(ch1 * WN_KC) * 4u;
+            if (p >= 2 + LH && p < 2 + LH + LW) issue_u(p - 2 - LH);
+            if (p >= WN_CP && p < WN_CP + LH) commit_h(p - WN_CP, hC);
+            if (p >= WN_CP + 4 && p < WN_CP + 4 + LW) commit_u(p - WN_CP - 4, ucur ^ 1);
+            if (p == 29) read_col(hB, 0);
+            if (p >= 32 && p < 48) {   // column pass: column c = (p - 32) / 4, two operations per position
+                const int c = (p - 32) >> 2, k = ((p - 32) & 3) * 2;
+                if (k == 0 && c < 3) read_col(hB, c + 1);
+                col_op(c, k);
+                col_op(c, k + 1);
+            }
+            if (p >= 48) {             // row pass: row r = (p - 48) / 4
+                const int r = (p - 48) >> 2, k = ((p - 48) & 3) * 2;
+                row_op(par ^ 1, r, k);
+                row_op(par ^ 1, r, k + 1);
+            }
         };
         ldb(0, 0);
+        ldb(1, 1);
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            const int s = xi & 1;
-            if (xi + 1 < 16) ldb(xi + 1, s ^ 1);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                acc[xi][nb] = MFMA16(v[0][xi], bf[s][nb].x, acc[xi][nb]);
-                acc[xi][nb] = MFMA16(v[1][xi], bf[s][nb].y, acc[xi][nb]);
-            }
-            if (xi == 9) {         // second half of the item: the prefetched item goes to the other LDS buffer
-#pragma unroll
-                for (int j = 0; j < LH; ++j) commit_h(j, cur ^ 1);
-#pragma unroll
-                for (int j = 0; j < LW; ++j) commit_u(j, cur ^ 1);
-            }
+            const int s = xi % 3;
+            if (xi + 2 < 16) ldb(xi + 2, (xi + 2) % 3);
+            acc[xi][0] = MFMA16(v[par][0][xi], bf[s][0].x, first ? zero4 : acc[xi][0]);
+            slot(4 * xi); __builtin_amdgcn_sched_barrier(0);
+            acc[xi][1] = MFMA16(v[par][0][xi], bf[s][1].x, first ? zero4 : acc[xi][1]);
+            slot(4 * xi + 1); __builtin_amdgcn_sched_barrier(0);
+            acc[xi][0] = MFMA16(v[par][1][xi], bf[s][0].y, acc[xi][0]);
+            slot(4 * xi + 2); __builtin_amdgcn_sched_barrier(0);
+            acc[xi][1] = MFMA16(v[par][1][xi], bf[s][1].y, acc[xi][1]);
+            slot(4 * xi + 3); __builtin_amdgcn_sched_barrier(0);
         }
 
         if (ch == nch - 1) {
@@ -336,10 +398,19 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
             }
             if (a.stats) fold_t = (cn * a.tilesX + ctx) * a.tilesY + cty;
         }
-        ch = nxch; cn = nn; ctx = ntx; cty = nty;
-        __syncthreads();               // the item committed buffer cur^1
-        cur ^= 1;
+        cn = n1; ctx = tx1; cty = ty1; ch = ch1;
+        n1 = n2; tx1 = tx2; ty1 = ty2; ch1 = ch2;
+        advance(n2, tx2, ty2, ch2);
+        __syncthreads();               // publishes the halo of item i+2 and the U chunk of item i+1
+        const int t = hA; hA = hB; hB = hC; hC = t;
+        ucur ^= 1;
         fold_stats();
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    for (int item = 0; item < nitems; item += 2) {      // every branch is uniform per workgroup
+        body(P0{}, std::false_type{});
+        if (item + 1 < nitems) body(P1{}, std::false_type{});
     }
 }
 
@@ -378,7 +449,7 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
             return VQW_OK;
         }
     }
-    constexpr size_t lds = (size_t)(2 * WN_HR * WN_HW * WN_KPH + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
+    constexpr size_t lds = (size_t)(3 * WN_HR * WN_HW * WN_KPH + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
     static_assert(lds <= 160 * 1024, "Winograd buffers do not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
