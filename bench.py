@@ -190,13 +190,13 @@ def main():
         print("[bench] %d timed steps: %.1f ms/step; device segments allocated inside the timed region: %d (+%.2f GB reserved)"
               % (args.steps, dt / args.steps * 1e3, ms1["segment.all.allocated"] - ms0["segment.all.allocated"],
                  (ms1["reserved_bytes.all.current"] - ms0["reserved_bytes.all.current"]) / 2**30), file=sys.stderr, flush=True)
-    prof = (ctypes.c_double * 16)()
+    prof = (ctypes.c_double * 20)()
     if timing:
         _lib.check(L.vqw_profile_end(prof), "vqw_profile_end")
     # Second, untimed look at the same kernels WITHOUT concurrency: in the timed region the weight-gradient kernels run
     # on a side stream next to the chain kernels, which stretches every kernel's own duration.  Two extra steps with
     # the side stream off give the kernels' exclusive durations (reported as roofline.exclusive).
-    prof_x = (ctypes.c_double * 16)()
+    prof_x = (ctypes.c_double * 20)()
     from hipops import ops as _ops
     if timing and _ops.WGRAD_ASYNC:
         _ops.WGRAD_ASYNC = False
@@ -220,7 +220,9 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         imgs = args.batch * world * args.steps / dt
-        fam = ["conv_mfma_fwd_dgrad", "conv_mfma_wgrad", "conv_generic_fwd", "conv_generic_wgrad"]
+        # (the Winograd family's FLOPs are the 4/9 of the direct form's that the matrix cores execute: its TFLOP/s is
+        # hardware utilisation like the others'; x 2.25 = the rate in direct-form FLOPs)
+        fam = ["conv_mfma_fwd_dgrad", "conv_mfma_wgrad", "conv_generic_fwd", "conv_generic_wgrad", "conv_winograd_fwd_dgrad"]
 
         def families(pr, nsteps):
             out = {}
@@ -270,9 +272,9 @@ def main():
                          "is what the concurrency buys")
         per_gpu = imgs / world
         scale = (args.size / 256.0) ** 2
-        # FLOPs the kernels actually executed per step (collapsed up-sampled convs at 4/9 of the reference's count), from the
+        # FLOPs the kernels actually executed per step (collapsed up-sampled and Winograd-form convs at 4/9 of the reference's count), from the
         # same launch records: hardware utilisation; the algorithmic figure prices the step at the reference's conv FLOPs
-        executed = sum(prof[4 * f + 2] for f in range(4)) / args.steps if timing else None
+        executed = sum(prof[4 * f + 2] for f in range(5)) / args.steps if timing else None
         rcfg = list(g.enc_filters) == [16, 32, 64, 128, 256] and list(g.dec_filters) == [32, 64, 128, 256, 512]
         line = {
             "metric": "images/sec (train step, 256x256 2D slices)", "value": imgs, "unit": "images/sec",
@@ -283,7 +285,7 @@ def main():
                                    % (list(g.enc_filters), list(g.dec_filters), g.dict_size, args.size, args.size, os.path.basename(args.config)),
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             # whole step against the two rooflines.  "algorithmic" = the reference's conv FLOPs / bytes, i.e.
-            # credit for work avoided (collapsed up-sampled layers); "executed" = FLOPs the kernels ran = hardware utilisation
+            # credit for work avoided (collapsed up-sampled and Winograd-form layers); "executed" = FLOPs the kernels ran = hardware utilisation
             "step_fraction_of_fp32_mfma_roofline": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA if rcfg else None,
             "step_fraction_of_fp32_mfma_roofline_algorithmic": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA if rcfg else None,
             "step_fraction_of_fp32_mfma_roofline_executed": executed / (ms_per_step * 1e-3) / PEAK_FP32_MFMA if executed else None,

@@ -10,9 +10,9 @@ static int g_conv_backend = 0;  // 0 auto, 1 generic only
 // Optional per-launch timing of the convolution kernels (bench.py roofline): HIP events recorded on the SAME
 // stream right around each conv kernel family.  Off by default; nothing is recorded, allocated or synchronised
 // unless vqw_profile_begin() was called.  Families: 0 = MFMA fwd/dgrad, 1 = MFMA wgrad (incl. slab reduce),
-// 2 = generic fwd, 3 = generic wgrad.
+// 2 = generic fwd, 3 = generic wgrad, 4 = Winograd-form fwd/dgrad (FLOPs = the 4/9 the matrix cores execute).
 #define PROF_MAX 16384
-#define PROF_FAMILIES 4
+#define PROF_FAMILIES 5
 static bool g_prof_on = false;
 static int g_prof_n = 0;
 static hipEvent_t* g_prof_ev = nullptr;   // 2 * PROF_MAX events
@@ -310,7 +310,7 @@ extern "C" int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float*
     VQW_CHECK(x && ws && y && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_fwd: bad arguments");
     VQW_CHECK(conv_wino_ok(Cin, Cout, N, H, W), "vqw_conv3x3_wino_fwd: unsupported shape (query vqw_conv3x3_wino_supported)");
     const double px = (double)N * H * W;
-    ProfScope ps(0, 2.0 * px * 9.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + px * Cout + 16.0 * Cout * Cin));
+    ProfScope ps(4, 2.0 * px * 4.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + px * Cout + 16.0 * Cout * Cin));
     return conv_wino_fwd(x, (const float*)ws, bias, y, N, H, W, Cin, Cout, relu, (hipStream_t)stream);
 }
 extern "C" int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W) {
@@ -322,7 +322,7 @@ extern "C" int vqw_conv3x3_wino_fwd_stats(const float* x, const void* ws, const 
     VQW_CHECK(x && ws && y && part && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_fwd_stats: bad arguments");
     VQW_CHECK(vqw_conv3x3_wino_fwd_stats_parts(Cin, Cout, N, H, W) > 0, "vqw_conv3x3_wino_fwd_stats: shape not served");
     const double px = (double)N * H * W;
-    ProfScope ps(0, 2.0 * px * 9.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + px * Cout + 16.0 * Cout * Cin));
+    ProfScope ps(4, 2.0 * px * 4.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + px * Cout + 16.0 * Cout * Cin));
     return conv_wino_fwd(x, (const float*)ws, bias, y, N, H, W, Cin, Cout, 0, (hipStream_t)stream, part);
 }
 

@@ -861,6 +861,7 @@ k_conv_wgrad9(ConvIn in, const float* __restrict__ dy, float* __restrict__ part,
 }
 
 // shapes the wg9 kernel takes, and its split count (shared by the workspace query and the launcher)
+static const int g_wino_wgrad = []{ const char* e = getenv("VQW_WINOGRAD_WGRAD"); return e ? atoi(e) : 1; }();      // 0: direct-form weight gradients (A/B)
 static inline bool wg9_ok(int C0, int C1, int Cout, int ks, int W, int dil, long P) {
     return ks == 3 && (W % 32 == 0) && (C0 % 4 == 0) && (C1 % 4 == 0) && (Cout % 4 == 0) && dil <= 24 && P >= 32 &&
            (C1 == 0 || C0 % 32 == 0);
@@ -1173,6 +1174,18 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
         const long nout = (long)Cout * 9 * Cin;
         const unsigned nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
         const unsigned nbd = (unsigned)(P * Cout * 4);
+        if (g_wino_wgrad && dil == 1 && in.C1 == 0 && !in.up0 && conv_wino_wgrad_ok(Cin, Cout, N, H, W)) {     // Winograd form (conv_wino.hip)
+            int kt = 1;
+            const int nsbw = conv_wino_wgrad_blocks(Cin, Cout, N, H, W, nsb, &kt);
+            float* bp = dbias ? ws + (size_t)nsbw * nout : nullptr;
+            int rc = conv_wino_wgrad(in.src0, dy, ws, bp, N, H, W, Cin, Cout, nsbw, kt, st);
+            if (rc) return rc;
+            if (dbias) {
+                rc = reduce_rows(bp, dbias, Cout, nsbw, st, acc);
+                if (rc) return rc;
+            }
+            return reduce_rows(ws, dw, nout, nsbw, st, acc);
+        }
         if (conv_wgrad_tile_ok(in.C0, in.C1, Cout, ks, W, dil)) {           // block-shared tiles (conv_halo.hip)
             int kt = 1;
             const int nsbt = conv_wgrad_tile_blocks(Cin, Cout, N, H, W, nsb, &kt);

@@ -478,3 +478,293 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
     VQW_LAUNCH_CHECK("conv_wino");
     return VQW_OK;
 }
+
+// =====================================================================================================================
+// Weight gradient of the same layers in Winograd form
+// =====================================================================================================================
+//   dU[xi][co][ci] = sum over tiles of dM[xi][tile][co] V[xi][tile][ci],   dM = A dY A^T (2x2 -> 4x4),  V = B^T d B
+//   dW = G^T dU G (4x4 -> 3x3)
+// 16 GEMMs with K = tiles: 4/9 of the direct form's matrix work.  A workgroup owns a (32 co x 16 ci) block of dU for a run
+// of 8 x 32 pixel regions; its 8 waves split K: wave (tile row tr, half h) takes the tiles 8h..8h+7 of tile row tr in two
+// k-steps of 4 tiles on v_mfma_f32_16x16x4_f32 (M = co: two 16-blocks, N = ci, K = tile within the k-step).  Per k-step a
+// lane reads the 2x2 dY patch of its tile at its two couts and the 4x4 X patch at its ci (24 ds_read_b32: lanes =
+// channels, conflict-free with 40 / 24 floats per pixel), transforms them in registers (2 x 12 + 32 add / sub) and feeds
+// 32 MFMAs; the two waves of a SIMD take turns (one transforms while the other holds the matrix pipe).  The dY tile and
+// the X halo are double-buffered in LDS like the forward kernel's.  At the end the 8 waves' partial sums are folded through
+// LDS, every thread applies G^T . G to one (co, ci) entry and the workgroup writes one slab [Cout][9][Cin] (+ the fused
+// bias partial); reduce_rows sums the slabs in a fixed order (deterministic, no float atomics).
+namespace {
+
+struct WinoWgArgs {
+    const float* x;
+    const float* dy;
+    float* part;
+    float* bias_part;
+    int N, H, W, Cin, Cout;
+    int tilesY, tilesX, nsp;
+    int n_ci_b, nblk, kt;
+    unsigned nbx, nbd;
+};
+
+constexpr int WW_TR = 8;                              // output rows per region
+constexpr int WW_DP = 40, WW_XP = 24;                 // floats per dY pixel (32 co + 8) / per X pixel (16 ci + 8) in LDS
+constexpr int WW_D = WW_TR * 32 * WW_DP;              // floats per dY tile
+constexpr int WW_X = (WW_TR + 2) * 34 * WW_XP;        // floats per X halo
+
+__global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
+    constexpr int NT = 512;
+    constexpr int LD = WW_TR * 32 * 8 / NT;                   // 4 dY float4 per thread
+    constexpr int XF = (WW_TR + 2) * 34 * 4;                  // 1360 X float4 per halo
+    constexpr int LX = (XF + NT - 1) / NT;                    // 3
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ds = smem;                     // [2][WW_D]
+    float* Xs = smem + 2 * WW_D;          // [2][WW_X]
+    float* Pk = Xs + 2 * WW_X;            // [512][4] parking space of the loader slots past the end of the halo
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const int blk = blockIdx.x % a.nblk, sblk = blockIdx.x / a.nblk;
+    const int co_base = (blk / a.n_ci_b) * 32, ci_base = (blk % a.n_ci_b) * 16;
+    const int sp0 = sblk * a.kt;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int per_img = a.tilesY * a.tilesX;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsd = make_rsrc(a.dy, a.nbd);
+
+    // loader: dY float4 f -> pixel f / 8, cout quad f % 8; X float4 f -> halo pixel f / 4, ci quad f % 4
+    const int d_c = co_base + (tid & 7) * 4;
+    const bool d_ok = d_c < Cout;
+    const int x_c = ci_base + (tid & 3) * 4;
+    const bool x_cok = x_c < Cin;
+    const bool do_bias = a.bias_part != nullptr && ci_base == 0;
+    float4 rd[LD], rx[LX];
+    float4 bsum;
+    bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
+    int i_n = 0, i_y0 = 0, i_x0 = 0;
+    auto issue_setup = [&](int n, int tx, int ty) { i_n = n; i_y0 = ty * WW_TR; i_x0 = tx * 32; };
+    auto issue_d = [&](int j) {
+        const int pix = (tid >> 3) + 64 * j;            // 0..255
+        const int yy = i_y0 + (pix >> 5), xx = i_x0 + (pix & 31);
+        const bool ok = d_ok & (yy < H);
+        const unsigned p = ((unsigned)i_n * H + (unsigned)yy) * W + (unsigned)xx;
+        rd[j] = buf_ld4(rsd, sel_u32(ok, (p * (unsigned)Cout + d_c) * 4u, a.nbd));
+    };
+    auto issue_x = [&](int j) {
+        const int hp = (tid >> 2) + 128 * j;            // 0..339 valid
+        const int hy = hp / 34, hx = hp - hy * 34;
+        const int yy = i_y0 - 1 + hy, xx = i_x0 - 1 + hx;
+        const bool ok = (hp < (WW_TR + 2) * 34) & x_cok & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+        const unsigned pix = ((unsigned)i_n * H + (unsigned)yy) * W + (unsigned)xx;
+        rx[j] = buf_ld4(rsx, sel_u32(ok, (pix * (unsigned)Cin + x_c) * 4u, a.nbx));
+    };
+    // `once`: 1 when the committed tile is one of this workgroup's (the prefetch behind the last tile runs off its share)
+    auto commit_d = [&](int j, int buf, float once) {
+        const int pix = (tid >> 3) + 64 * j;
+        *(float4*)&Ds[buf * WW_D + pix * WW_DP + (tid & 7) * 4] = rd[j];
+        bsum.x += once * rd[j].x; bsum.y += once * rd[j].y; bsum.z += once * rd[j].z; bsum.w += once * rd[j].w;   // fused bias gradient
+    };
+    auto commit_x = [&](int j, int buf) {
+        const int hp = (tid >> 2) + 128 * j;
+        float* dst = hp < (WW_TR + 2) * 34 ? &Xs[buf * WW_X + hp * WW_XP + (tid & 3) * 4] : &Pk[tid * 4];
+        *(float4*)dst = rx[j];
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[xi][mb][r] = 0.f;
+
+    int cn = sp0 / per_img, ctx, cty;
+    {
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    if (my_tiles > 0) {
+        issue_setup(cn, ctx, cty);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) issue_d(j);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) issue_x(j);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) commit_d(j, 0, 1.f);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) commit_x(j, 0);
+    }
+    __syncthreads();
+
+    // fragment addressing: lane (channel idx = lane & 15, tile q = lane >> 4 of the k-step); wave (tile row tr, half hh)
+    const int idx = lane & 15, q = lane >> 4;
+    const int tr = wv >> 1, hh = wv & 1;
+    // (plain C here, unlike the forward kernel: the transform's last results feed the k-step's first MFMAs directly, and
+    // the compiler's hazard recogniser does not see a VALU write inside inline asm - v_sub_f32 in asm followed by the MFMA
+    // that reads its result gave a stale B operand)
+    auto fadd = [](float x, float y) { return x + y; };
+    auto fsub = [](float x, float y) { return x - y; };
+    int cur = 0;
+    float once = 0.f;
+    for (int t = 0; t < my_tiles; ++t) {
+        {   // next region (past the last one the loads read another region or nothing; their LDS copy is never consumed)
+            const int ty1 = cty + 1, wy = ty1 == a.tilesY ? 1 : 0;
+            cty = wy ? 0 : ty1;
+            const int tx1 = ctx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+            ctx = wx ? 0 : tx1;
+            cn += wx;
+            issue_setup(cn, ctx, cty);
+            once = t + 1 < my_tiles ? 1.f : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int tile = hh * 8 + ks * 4 + q;                 // tile column 0..15 of the region
+            // dM = A dY A^T for the lane's two couts, A = [1 0; 1 1; 1 -1; 0 -1]
+            float dm[2][16];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const float* Dp = Ds + cur * WW_D + ((2 * tr) * 32 + 2 * tile) * WW_DP + mb * 16 + idx;
+                const float y00 = Dp[0], y01 = Dp[WW_DP], y10 = Dp[32 * WW_DP], y11 = Dp[33 * WW_DP];
+                // rows: r0 = y0., r1 = y0. + y1., r2 = y0. - y1., r3 = -y1.   (the sign of r3 is folded into the columns)
+                const float r10 = fadd(y00, y10), r11 = fadd(y01, y11), r20 = fsub(y00, y10), r21 = fsub(y01, y11);
+                const float rr[4][2] = {{y00, y01}, {r10, r11}, {r20, r21}, {y10, y11}};     // row 3 holds +y1.
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float p0 = rr[i][0], p1 = rr[i][1];
+                    if (i < 3) {
+                        dm[mb][i * 4 + 0] = p0;
+                        dm[mb][i * 4 + 1] = fadd(p0, p1);
+                        dm[mb][i * 4 + 2] = fsub(p0, p1);
+                        dm[mb][i * 4 + 3] = -p1;
+                    } else {               // row 3 = -y1.: negate every entry
+                        dm[mb][12] = -p0;
+                        dm[mb][13] = -fadd(p0, p1);
+                        dm[mb][14] = fsub(p1, p0);
+                        dm[mb][15] = p1;
+                    }
+                }
+            }
+            // V = B^T d B for the lane's ci
+            float vv[16];
+            {
+                const float* Xp = Xs + cur * WW_X + ((2 * tr) * 34 + 2 * tile) * WW_XP + idx;
+                float e[4][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float d0 = Xp[c * WW_XP], d1 = Xp[(34 + c) * WW_XP], d2 = Xp[(68 + c) * WW_XP], d3 = Xp[(102 + c) * WW_XP];
+                    e[0][c] = fsub(d0, d2); e[1][c] = fadd(d1, d2); e[2][c] = fsub(d2, d1); e[3][c] = fsub(d1, d3);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vv[r * 4 + 0] = fsub(e[r][0], e[r][2]);
+                    vv[r * 4 + 1] = fadd(e[r][1], e[r][2]);
+                    vv[r * 4 + 2] = fsub(e[r][2], e[r][1]);
+                    vv[r * 4 + 3] = fsub(e[r][1], e[r][3]);
+                }
+            }
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                acc[xi][0] = MFMA16(dm[0][xi], vv[xi], acc[xi][0]);
+                if (ks == 0) { if (xi < LD) issue_d(xi); else if (xi < LD + LX) issue_x(xi - LD); }
+                else { if (xi >= 4 && xi < 4 + LD) commit_d(xi - 4, cur ^ 1, once); else if (xi >= 4 + LD && xi < 4 + LD + LX) commit_x(xi - 4 - LD, cur ^ 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[xi][1] = MFMA16(dm[1][xi], vv[xi], acc[xi][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();               // the region's slots committed buffer cur^1
+        cur ^= 1;
+    }
+
+    // fold the 8 waves' partial sums through LDS, one xi at a time: thread e = (co, ci) of the 32 x 16 block keeps dU[xi]
+    float* red = smem;                    // [8 waves][32 co][16 ci]
+    float du[16];
+    if (do_bias) {                        // threads with equal (tid & 7) hold the same 4 couts
+        *(float4*)&red[tid * 4] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            const int g = tid >> 2, comp = tid & 3;
+            float s = 0.f;
+            for (int i = 0; i < 64; ++i) s += red[(i * 8 + g) * 4 + comp];
+            if (co_base + tid < Cout) a.bias_part[(size_t)sblk * Cout + co_base + tid] = s;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        // C/D layout (16x16): col = lane & 15 (ci), row = 4 (lane >> 4) + r (co within the 16-block)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wv * 512 + (mb * 16 + 4 * q + r) * 16 + idx] = acc[xi][mb][r];
+        __syncthreads();
+        du[xi] = ((red[tid] + red[512 + tid]) + (red[1024 + tid] + red[1536 + tid])) +
+                 ((red[2048 + tid] + red[2560 + tid]) + (red[3072 + tid] + red[3584 + tid]));
+        __syncthreads();
+    }
+    // dW = G^T dU G, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+    {
+        const int co = co_base + (tid >> 4), ci = ci_base + (tid & 15);
+        float tcol[3][4];       // G^T applied down the rows: [ky][j]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u0 = du[j], u1 = du[4 + j], u2 = du[8 + j], u3 = du[12 + j];
+            tcol[0][j] = u0 + 0.5f * (u1 + u2);
+            tcol[1][j] = 0.5f * (u1 - u2);
+            tcol[2][j] = u3 + 0.5f * (u1 + u2);
+        }
+        if (co < Cout && ci < Cin) {
+            float* o = a.part + (size_t)sblk * Cout * 9 * Cin + ((size_t)co * 9) * Cin + ci;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float t0 = tcol[ky][0], t1 = tcol[ky][1], t2 = tcol[ky][2], t3 = tcol[ky][3];
+                o[(ky * 3 + 0) * Cin] = t0 + 0.5f * (t1 + t2);
+                o[(ky * 3 + 1) * Cin] = 0.5f * (t1 - t2);
+                o[(ky * 3 + 2) * Cin] = t3 + 0.5f * (t1 + t2);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W) {
+    if (g_wino_mode != 0 || !g_wino_env) return false;
+    if (Cin % 16 != 0 || Cout % 32 != 0 || W % 32 != 0 || H < 2 || N < 1) return false;
+    return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
+}
+// slabs for a given upper bound
+int conv_wino_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
+    const int nblk = (Cout / 32) * (Cin / 16);
+    const int nsp = N * ceil_div(H, WW_TR) * (W / 32);
+    int nsb = g_max_blocks / nblk;
+    if (nsb > max_slabs) nsb = max_slabs;
+    if (nsb > nsp) nsb = nsp;
+    if (nsb < 1) nsb = 1;
+    const int kt = ceil_div(nsp, nsb);
+    if (kt_out) *kt_out = kt;
+    return ceil_div(nsp, kt);
+}
+int conv_wino_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+                    hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * (WW_D + WW_X) + 512 * 4) * sizeof(float);
+    static_assert(lds <= 160 * 1024 && lds >= 8 * 512 * sizeof(float), "Winograd wgrad tiles do not fit the LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            vqw_set_error("conv_wino_wgrad: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const long P = (long)N * H * W;
+    WinoWgArgs a;
+    a.x = x; a.dy = dy; a.part = ws; a.bias_part = bpart;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = ceil_div(H, WW_TR); a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
+    a.n_ci_b = Cin / 16; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
+    a.nbx = (unsigned)(P * Cin * 4);
+    a.nbd = (unsigned)(P * Cout * 4);
+    k_conv_wino_wgrad<<<a.nblk * nsb, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino_wgrad");
+    return VQW_OK;
+}
