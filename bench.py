@@ -222,7 +222,7 @@ def main():
         imgs = args.batch * world * args.steps / dt
         # (the Winograd family's FLOPs are the 4/9 of the direct form's that the matrix cores execute: its TFLOP/s is
         # hardware utilisation like the others'; x 2.25 = the rate in direct-form FLOPs)
-        fam = ["conv_mfma_fwd_dgrad", "conv_mfma_wgrad", "conv_generic_fwd", "conv_generic_wgrad", "conv_winograd_fwd_dgrad"]
+        fam = ["conv_mfma_fwd_dgrad", "conv_mfma_wgrad", "conv_generic_fwd", "conv_generic_wgrad", "conv_winograd"]
 
         def families(pr, nsteps):
             out = {}

@@ -39,7 +39,7 @@ int vqw_set_conv_backend(int mode);
 /* Measurement aid (bench.py roofline): HIP events recorded on the launch stream around every convolution kernel
  * family between begin and end.  end() synchronises on those events and fills out[5][4] =
  * {launches, total ms, total FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA wgrad, generic fwd, generic wgrad,
- * Winograd-form fwd/dgrad}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of
+ * Winograd-form fwd/dgrad/wgrad}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of
  * the direct form's).
  * Not meant for graph capture; off by default.                                                              */
 int vqw_profile_begin(void);

@@ -10,7 +10,7 @@ static int g_conv_backend = 0;  // 0 auto, 1 generic only
 // Optional per-launch timing of the convolution kernels (bench.py roofline): HIP events recorded on the SAME
 // stream right around each conv kernel family.  Off by default; nothing is recorded, allocated or synchronised
 // unless vqw_profile_begin() was called.  Families: 0 = MFMA fwd/dgrad, 1 = MFMA wgrad (incl. slab reduce),
-// 2 = generic fwd, 3 = generic wgrad, 4 = Winograd-form fwd/dgrad (FLOPs = the 4/9 the matrix cores execute).
+// 2 = generic fwd, 3 = generic wgrad, 4 = Winograd-form fwd/dgrad/wgrad (FLOPs = the 4/9 the matrix cores execute).
 #define PROF_MAX 16384
 #define PROF_FAMILIES 5
 static bool g_prof_on = false;
@@ -232,7 +232,8 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
         return conv_pw_wgrad(in, dy, dw_ohwi, wsf + bias_grad_ws_floats(Cout), (long)N * H * W, Cout, accumulate, st);
     }
     if (g_conv_backend == 0 && conv_mfma_wgrad_ok(in, Cout, ksize)) {
-        ProfScope ps(1, flops, st, bytes);
+        const bool wino = conv_mfma_wgrad_is_wino(in, N, H, W, Cout, ksize, dil);
+        ProfScope ps(wino ? 4 : 1, wino ? flops * (4.0 / 9.0) : flops, st, bytes);
         int bias_done = 0;
         rc = conv_mfma_wgrad(in, dy, dw_ohwi, dbias, &bias_done, wsf + bias_grad_ws_floats(Cout), N, H, W, Cout, ksize, dil, st,
                              accumulate);

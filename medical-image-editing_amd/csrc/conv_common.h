@@ -70,6 +70,7 @@ size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w);
 int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,
                    int acc, hipStream_t st);
 size_t conv_mfma_wgrad_ws_floats(int Cin, int Cout, int ks, long P);
+bool conv_mfma_wgrad_is_wino(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc);
 

@@ -1155,6 +1155,12 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
 }
 
 // dbias != nullptr asks the kernel to produce the bias gradient too; returns 1 (not an error) in *bias_done when it did.
+// true when conv_mfma_wgrad takes the Winograd form for the layer (the profile scope prices it at the FLOPs it executes)
+bool conv_mfma_wgrad_is_wino(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil) {
+    return g_wgrad_variant != 1 && g_wino_wgrad && ks == 3 && dil == 1 && in.C1 == 0 && !in.up0 &&
+           fits_u32((long)N * H * W, in.C0, Cout) && wg9_ok(in.C0, 0, Cout, ks, W, dil, (long)N * H * W) &&
+           conv_wino_wgrad_ok(in.C0, Cout, N, H, W);
+}
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc) {
     *bias_done = 0;
@@ -1174,7 +1180,7 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
         const long nout = (long)Cout * 9 * Cin;
         const unsigned nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
         const unsigned nbd = (unsigned)(P * Cout * 4);
-        if (g_wino_wgrad && dil == 1 && in.C1 == 0 && !in.up0 && conv_wino_wgrad_ok(Cin, Cout, N, H, W)) {     // Winograd form (conv_wino.hip)
+        if (conv_mfma_wgrad_is_wino(in, N, H, W, Cout, ks, dil)) {     // Winograd form (conv_wino.hip)
             int kt = 1;
             const int nsbw = conv_wino_wgrad_blocks(Cin, Cout, N, H, W, nsb, &kt);
             float* bp = dbias ? ws + (size_t)nsbw * nout : nullptr;

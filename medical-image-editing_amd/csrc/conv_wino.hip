@@ -16,8 +16,12 @@
 //     per chunk ([16][32 couts][12]: conflict-free ds_read_b64).
 //   * accumulators: 16 xi x 2 N blocks x 4 = 128 registers; the inverse transform A^T M A is lane-local (a lane holds
 //     all 16 xi of its (tile, cout) entries), followed by bias / ReLU / the statistics partials and the stores.
-//   * pipeline as in conv_halo.hip: the next (region, chunk) item is fetched into registers while the matrix cores work
-//     and written to the other LDS buffer in the second half of the item; one barrier per item.
+//   * pipeline: an item = (region, chunk).  The halo buffers form a ring of three (items i, i+1, i+2), the U chunks a pair:
+//     during item i the halo of item i+2 and the U chunk of item i+1 are fetched into registers behind the first MFMAs
+//     and written to LDS behind later ones, and the patch of item i+1 (published by the previous barrier) is read and
+//     transformed two VALU instructions per MFMA in the second half - so an item starts with its A operands in registers
+//     and needs one barrier.  Measured steps (profiles/r02_*): plain ds_read_b64 instead of the merged ds_read2_b64 took
+//     the large layers from 214 to 232 effective TFLOP/s, the ring + hidden transform from 190 to 214.
 //
 // Rounding: the products differ from the direct form's (sums of four inputs times sums of weights), the result agrees
 // with it to a few fp32 ulps of the accumulated magnitude - the same class of difference as a changed summation order.
@@ -245,8 +249,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     // V = B^T d B of the lane's tile at its two channels.  The 64 add / sub of an item's transform are single VALU
     // instructions placed two per MFMA in the second half of the PREVIOUS item (inline asm: the compiler's SLP pass would
     // pair them into v_pk_add_f32, which holds the vector issue port twice as long beside MFMAs), column by column as the
-    // patch columns arrive from LDS, then row by row: row r overwrites the operands xi = 4r..4r+3 the matrix cores have
-    // just consumed.
+    // patch columns arrive from LDS, then row by row.  Their results are first read by MFMAs of the next item, a barrier
+    // later: the compiler's hazard recogniser does not see VALU writes inside inline asm, so an MFMA must never read
+    // one within a few instructions (k_conv_wino_wgrad below keeps its transform in plain C for that reason).
     auto fadd = [](float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
     auto fsub = [](float x, float y) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
     f32x2 dcol[2][4];                  // two patch columns in flight
@@ -523,7 +528,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
-    const int blk = blockIdx.x % a.nblk, sblk = blockIdx.x / a.nblk;
+    // the (co, ci) blocks of one spatial split read the same dY / X regions: keep them on one XCD's L2
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = lb % a.nblk, sblk = lb / a.nblk;
     const int co_base = (blk / a.n_ci_b) * 32, ci_base = (blk % a.n_ci_b) * 16;
     const int sp0 = sblk * a.kt;
     const int my_tiles = min(a.kt, a.nsp - sp0);

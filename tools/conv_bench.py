@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--filter", default="", help="substring filter on the shape label")
     ap.add_argument("--no-wino", action="store_true", help="direct form for every layer")
+    ap.add_argument("--wino-fwd", action="store_true", help="Winograd form also for the forward (product: VQW_WINOGRAD_FWD=1)")
     ap.add_argument("--backend", type=int, default=0, help="vqw_set_conv_backend mode (2 = no halo-tile kernel)")
     args = ap.parse_args()
     dev = "cuda"
@@ -98,10 +99,10 @@ def main():
         ws = torch.empty(L.vqw_conv2d_wgrad_ws_bytes(c0, c1, N, h, h, co, ks), dtype=torch.uint8, device=dev)
         flops = 2.0 * N * h * h * co * ks * ks * cin
 
-        # plain 3x3 layers take the Winograd form where the library serves it (as hipops.ops does); TFLOP/s stay the
-        # direct form's FLOPs over the time ("effective")
+        # plain 3x3 layers take the Winograd form for dgrad / wgrad where the library serves it, for the forward only
+        # with --wino-fwd (as hipops.ops does); TFLOP/s stay the direct form's FLOPs over the time ("effective")
         plain = ks == 3 and dil == 1 and not args.no_wino
-        wino_f = plain and not up and not c1 and L.vqw_conv3x3_wino_supported(cin, co, N, h, h)
+        wino_f = plain and args.wino_fwd and not up and not c1 and L.vqw_conv3x3_wino_supported(cin, co, N, h, h)
         wino_d = plain and L.vqw_conv3x3_wino_supported(co, cin, N, h, h)
         uf = torch.empty(L.vqw_conv3x3_wino_ws_bytes(cin, co), dtype=torch.uint8, device=dev)
         ud = torch.empty(L.vqw_conv3x3_wino_ws_bytes(co, cin), dtype=torch.uint8, device=dev)

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 FAMILIES = {"conv_mfma_fwd_dgrad": ("k_conv_mfma_fwd", "k_conv_halo", "k_conv_dilrow<"),
             "conv_mfma_wgrad": ("k_conv_wgrad9", "k_conv_wgrad_up", "k_conv_mfma_wgrad", "k_conv_wgrad_tile", "k_conv_dilrow_wgrad"),
-            "conv_winograd_fwd_dgrad": ("k_conv_wino",),
+            "conv_winograd": ("k_conv_wino",),
             "conv_generic_fwd": ("k_conv_direct_fwd", "k_stem_fwd", "k_head_fwd"),
             "conv_generic_wgrad": ("k_conv_direct_wgrad", "k_stem_wgrad", "k_head_wgrad")}
 
