@@ -599,7 +599,13 @@ class _ConvCat(torch.autograd.Function):
         if x.shape[1] != Cin or tuple(wb.shape[1:]) != (Cin, ks, ks):
             raise RuntimeError("conv2d_cat: shapes %s / %s / %s do not match" % (tuple(x.shape), tuple(wa.shape), tuple(wb.shape)))
         w, b = _cat_weights(wa, ba, wb, bb)
-        y = _conv_fwd_raw(x, False, None, w, b, N, H, W, Ca + Cb, ks, 1, False)
+        if WINOGRAD_FWD and ks == 3 and _L().vqw_conv3x3_wino_supported(Cin, Ca + Cb, N, H, W):
+            L = _L()
+            u = _cached(wa, "cat_wino", lambda: _wino_weights(L, w, Cin, Ca + Cb), deps=(wb,))
+            y = empty_nhwc(N, Ca + Cb, H, W, x)
+            _lib.check(L.vqw_conv3x3_wino_fwd(_p(x), _p(u), _p(b), _p(y), N, H, W, Cin, Ca + Cb, 0, _st()), "vqw_conv3x3_wino_fwd")
+        else:
+            y = _conv_fwd_raw(x, False, None, w, b, N, H, W, Ca + Cb, ks, 1, False)
         ctx.save_for_backward(x, w)
         ctx.cfg = (ks, N, H, W, Ca, Cb)
         ctx.params = (wa, ba, wb, bb)
@@ -625,8 +631,13 @@ class _ConvCat(torch.autograd.Function):
                 return buf
             wt = _cached(wa, "cat_dgrad", _pack, deps=(wb,))
             gx = empty_nhwc(N, Cin, H, W, gy)
-            _lib.check(L.vqw_conv2d_fwd(_p(gy), Ct, 0, None, 0, _p(wt), None, _p(gx), N, H, W, Cin, ks, 1, 0, _st()),
-                       "vqw_conv2d_fwd(dgrad)")
+            if ks == 3 and L.vqw_conv3x3_wino_supported(Ct, Cin, N, H, W):
+                ut = _cached(wa, "cat_wino_dgrad", lambda: _wino_weights(L, wt, Ct, Cin), deps=(wb,))
+                _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(gx), N, H, W, Ct, Cin, 0, _st()),
+                           "vqw_conv3x3_wino_fwd(dgrad)")
+            else:
+                _lib.check(L.vqw_conv2d_fwd(_p(gy), Ct, 0, None, 0, _p(wt), None, _p(gx), N, H, W, Cin, ks, 1, 0, _st()),
+                           "vqw_conv2d_fwd(dgrad)")
         if ctx.defer:
             _deferred_wgrad_cat(wa, ba, wb, bb, x, gy, ks, N, H, W)
         elif any(ctx.needs_input_grad[1:5]):
