@@ -1157,14 +1157,28 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
 // dbias != nullptr asks the kernel to produce the bias gradient too; returns 1 (not an error) in *bias_done when it did.
 // true when conv_mfma_wgrad takes the Winograd form for the layer (the profile scope prices it at the FLOPs it executes)
 bool conv_mfma_wgrad_is_wino(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil) {
-    return g_wgrad_variant != 1 && g_wino_wgrad && ks == 3 && dil == 1 && in.C1 == 0 && !in.up0 &&
-           fits_u32((long)N * H * W, in.C0, Cout) && wg9_ok(in.C0, 0, Cout, ks, W, dil, (long)N * H * W) &&
-           conv_wino_wgrad_ok(in.C0, Cout, N, H, W);
+    return g_wgrad_variant != 1 && g_wino_wgrad && ks == 3 && dil == 1 && in.C1 == 0 && !in.up0 && (long)N * H * W >= 32 &&
+           fits_u32((long)N * H * W, in.C0, Cout) && conv_wino_wgrad_ok(in.C0, Cout, N, H, W);
 }
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc) {
     *bias_done = 0;
     if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout)) return conv_direct_wgrad(in, dy, dw, ws, N, H, W, Cout, ks, dil, st, acc);
+    if (conv_mfma_wgrad_is_wino(in, N, H, W, Cout, ks, dil)) {     // Winograd form (conv_wino.hip): widths that are multiples of 16
+        const int Cin = in.C0;
+        const long nout = (long)Cout * 9 * Cin;
+        *bias_done = dbias != nullptr;
+        int kt = 1;
+        const int nsbw = conv_wino_wgrad_blocks(Cin, Cout, N, H, W, wg9_split_blocks(Cin, Cout, (long)N * H * W), &kt);
+        float* bp = dbias ? ws + (size_t)nsbw * nout : nullptr;
+        int rc = conv_wino_wgrad(in.src0, dy, ws, bp, N, H, W, Cin, Cout, nsbw, kt, st);
+        if (rc) return rc;
+        if (dbias) {
+            rc = reduce_rows(bp, dbias, Cout, nsbw, st, acc);
+            if (rc) return rc;
+        }
+        return reduce_rows(ws, dw, nout, nsbw, st, acc);
+    }
     if (g_wgrad_variant != 1 && wg9_ok(in.C0, in.C1, Cout, ks, W, dil, (long)N * H * W) &&
         conv_dil_wgrad_ok(in, N, H, W, Cout, ks, dil))       // dilated 32-channel layers: rows walked along the residue chains
         return conv_dil_wgrad(in, dy, dw, ws, wg9_split_blocks(in.C0, Cout, (long)N * H * W), N, H, W, Cout, dil, acc, st);
@@ -1180,18 +1194,6 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
         const long nout = (long)Cout * 9 * Cin;
         const unsigned nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4), nb1 = (unsigned)(P * in.C1 * 4);
         const unsigned nbd = (unsigned)(P * Cout * 4);
-        if (conv_mfma_wgrad_is_wino(in, N, H, W, Cout, ks, dil)) {     // Winograd form (conv_wino.hip)
-            int kt = 1;
-            const int nsbw = conv_wino_wgrad_blocks(Cin, Cout, N, H, W, nsb, &kt);
-            float* bp = dbias ? ws + (size_t)nsbw * nout : nullptr;
-            int rc = conv_wino_wgrad(in.src0, dy, ws, bp, N, H, W, Cin, Cout, nsbw, kt, st);
-            if (rc) return rc;
-            if (dbias) {
-                rc = reduce_rows(bp, dbias, Cout, nsbw, st, acc);
-                if (rc) return rc;
-            }
-            return reduce_rows(ws, dw, nout, nsbw, st, acc);
-        }
         if (conv_wgrad_tile_ok(in.C0, in.C1, Cout, ks, W, dil)) {           // block-shared tiles (conv_halo.hip)
             int kt = 1;
             const int nsbt = conv_wgrad_tile_blocks(Cin, Cout, N, H, W, nsb, &kt);

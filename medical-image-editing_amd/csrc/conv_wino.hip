@@ -84,20 +84,30 @@ struct WinoArgs {
 
 constexpr int WN_KC = 8;                  // channels per chunk
 constexpr int WN_KPH = 10, WN_KPU = 12;   // floats per halo pixel / per U row in LDS
-constexpr int WN_TR = 16;                 // output rows per region
-constexpr int WN_HR = WN_TR + 2, WN_HW = 34;
+// Region geometry, RW = region width: 16 rows x 32 columns (halo 18 x 34), or - for maps whose width is a multiple of 16
+// only (the 16 x 16 level) - 32 rows x 16 columns (halo 34 x 18, LDS row stride 24 pixels: the two tile rows a wave then
+// covers land on complementary banks).  Either way 128 tiles per region and 612 halo pixels per chunk.
+template <int RW> struct WinoGeo {
+    static constexpr int TR = RW == 32 ? 16 : 32;          // output rows per region
+    static constexpr int HR = TR + 2, HWV = RW + 2;        // halo rows / valid halo columns
+    static constexpr int HWS = RW == 32 ? 34 : 24;         // LDS row stride in pixels
+    static constexpr int HBUF = HR * HWS * WN_KPH;         // floats per halo buffer
+};
 #ifndef WN_CP
 #define WN_CP 22                         // MFMA position of the first LDS commit of the prefetched item
 #endif
 
+template <int RW>
 __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
+    using G = WinoGeo<RW>;
     constexpr int NT = 512;
-    constexpr int HPIX = WN_HR * WN_HW;               // 612 halo pixels
+    constexpr int WN_TR = G::TR, WN_HW = G::HWS;
+    constexpr int HPIX = G::HR * G::HWV;              // 612 halo pixels
     constexpr int HF = HPIX * 2;                      // float4 per halo chunk
     constexpr int LH = (HF + NT - 1) / NT;            // 3
     constexpr int WF = 16 * 32 * 2;                   // float4 per U chunk
     constexpr int LW = WF / NT;                       // 2
-    constexpr int HBUF = HPIX * WN_KPH;               // floats
+    constexpr int HBUF = G::HBUF;                     // floats
     constexpr int UBUF = 16 * 32 * WN_KPU;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -131,10 +141,10 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
         const bool ok = f < HF;
         const int hp = ok ? f >> 1 : 0;
         h_ok[j] = ok;
-        h_lds[j] = ok ? hp * WN_KPH + (int)h_c : (int)(Ds - Hs) + tid * 4;      // offset from Hs in buffer 0
+        h_lds[j] = ok ? ((hp / G::HWV) * WN_HW + hp % G::HWV) * WN_KPH + (int)h_c : (int)(Ds - Hs) + tid * 4;      // offset from Hs in buffer 0
         h_st[j] = ok ? HBUF : 0;                                                 // ... + buf * h_st in buffer buf
-        h_y[j] = (short)(hp / WN_HW);
-        h_x[j] = (short)(hp % WN_HW);
+        h_y[j] = (short)(hp / G::HWV);
+        h_x[j] = (short)(hp % G::HWV);
     }
     unsigned u_off[LW];
     int u_lds[LW];
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     auto issue_setup = [&](int n, int tx, int ty, int ch) {
         i_img = (unsigned)n * H * W;
         i_y0 = ty * WN_TR - 1;
-        i_x0 = tx * 32 - 1;
+        i_x0 = tx * RW - 1;
         i_cc4 = (unsigned)(ch * WN_KC) * 4u;
     };
     auto issue_h = [&](int j) {
@@ -215,7 +225,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
 
     // fragment bases: lane (tile m = lane & 15, channel pair q = lane >> 4)
     const int m = lane & 15, q = lane >> 4;
-    const int a_base = ((2 * wv) * WN_HW + 2 * m) * WN_KPH + 2 * q;      // patch (r, c) adds (r * 34 + c) * KPH
+    // tile of the lane: RW = 32: tile row wv, column m; RW = 16: tile row 2 wv + (m >> 3), column m & 7
+    const int a_base = RW == 32 ? ((2 * wv) * WN_HW + 2 * m) * WN_KPH + 2 * q
+                                : ((2 * (2 * wv + (m >> 3))) * WN_HW + 2 * (m & 7)) * WN_KPH + 2 * q;      // patch (r, c) adds (r * HWS + c) * KPH
     const int b_base = m * WN_KPU + 2 * q;                               // (xi, nb) adds (xi * 32 + nb * 16) * KPU
 
     float bvv[2];
@@ -357,7 +369,10 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
 
         if (ch == nch - 1) {
             // Y = A^T M A per (tile, cout) entry: lane-local over the 16 xi; then bias / ReLU, statistics, stores
-            const int yrow0 = cty * WN_TR + 2 * wv;
+            // C/D rows of a lane = tiles 4 q + r: RW = 32: tile row wv, columns 4 q + r; RW = 16: tile row 2 wv + (q >> 1),
+            // columns 4 (q & 1) + r
+            const int yrow0 = cty * WN_TR + (RW == 32 ? 2 * wv : 2 * (2 * wv + (q >> 1)));
+            const int xcol0 = ctx * RW + (RW == 32 ? 8 * q : 8 * (q & 1));
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 float yv[16];      // [r][a][b]
@@ -381,13 +396,17 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
                 for (int aa = 0; aa < 2; ++aa) {
                     const int yy = yrow0 + aa;
                     const bool ok = (co_off[nb] != 0xFFFFFFFFu) & (yy < H);
-                    const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)(ctx * 32 + 8 * q)) * (unsigned)Cout + co_off[nb];
+                    const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cout + co_off[nb];
                     const int voff = (int)sel_u32(ok, base * 4u, a.nby);
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
+#ifndef WN_EXP_NO_STORE          // timing-only A/B builds (tools/wino_ab.sh): results are wrong by construction
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+#else
+                            if (yv[r * 4 + aa * 2 + b] == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+#endif
                 }
                 if (a.stats) {     // uniform: H % 16 == 0 whenever statistics are requested
                     float t1, t2;
@@ -424,7 +443,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
 // 3x3, dilation 1, one source at full resolution, whole 32-pixel column strips, channels in chunks of 8
 bool conv_wino_ok(int Cin, int Cout, int N, int H, int W) {
     if (g_wino_mode != 0 || !g_wino_env) return false;
-    if (Cin % 8 != 0 || Cin < 16 || Cout < 32 || Cout % 4 != 0 || W % 32 != 0 || H < 2 || N < 1) return false;
+    if (Cin % 8 != 0 || Cin < 16 || Cout < 32 || Cout % 4 != 0 || W % 16 != 0 || H < 2 || N < 1) return false;
     // (a batch beyond the 32-bit descriptor range runs as image groups: one image must fit)
     return (long)H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L && 16L * Cout * Cin * 4 <= 0xFFFFFFE0L;
 }
@@ -435,7 +454,10 @@ int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t s
     VQW_LAUNCH_CHECK("wino_weights");
     return VQW_OK;
 }
-int conv_wino_stat_tiles(int H, int W) { return H % WN_TR == 0 ? (H / WN_TR) * (W / 32) : 0; }
+int conv_wino_stat_tiles(int H, int W) {
+    const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? 16 : 32;
+    return H % tr == 0 ? (H / tr) * (W / rw) : 0;
+}
 
 int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
                   hipStream_t st, float* stats) {
@@ -454,11 +476,13 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
             return VQW_OK;
         }
     }
-    constexpr size_t lds = (size_t)(3 * WN_HR * WN_HW * WN_KPH + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
-    static_assert(lds <= 160 * 1024, "Winograd buffers do not fit the 160 KB LDS");
+    const bool wide = W % 32 == 0;
+    const size_t lds = (size_t)(3 * (wide ? WinoGeo<32>::HBUF : WinoGeo<16>::HBUF) + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
+    static_assert((size_t)(3 * WinoGeo<16>::HBUF + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float) <= 160 * 1024, "Winograd buffers do not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_wino, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_wino<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             vqw_set_error("conv_wino: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
@@ -467,7 +491,7 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
     WinoArgs a;
     a.x = x; a.u = u; a.bias = bias; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.tilesY = ceil_div(H, WN_TR); a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
+    a.tilesY = ceil_div(H, wide ? 16 : 32); a.tilesX = W / (wide ? 32 : 16); a.nsp = N * a.tilesY * a.tilesX;
     a.ntn = ceil_div(Cout, 32); a.nch = Cin / WN_KC;
     a.relu = relu;
     a.stats = stats;
@@ -479,7 +503,8 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
     if (groups < 1) groups = 1;
     const int even = ceil_div(a.nsp, groups);
     a.kt = even < 1 ? 1 : even;
-    k_conv_wino<<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    if (wide) k_conv_wino<32><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    else k_conv_wino<16><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino");
     return VQW_OK;
 }
@@ -511,15 +536,18 @@ struct WinoWgArgs {
     unsigned nbx, nbd;
 };
 
-constexpr int WW_TR = 8;                              // output rows per region
 constexpr int WW_DP = 40, WW_XP = 24;                 // floats per dY pixel (32 co + 8) / per X pixel (16 ci + 8) in LDS
-constexpr int WW_D = WW_TR * 32 * WW_DP;              // floats per dY tile
-constexpr int WW_X = (WW_TR + 2) * 34 * WW_XP;        // floats per X halo
+constexpr int WW_D = 256 * WW_DP;                     // floats per dY tile (256 pixels: 8 x 32 or 16 x 16)
+constexpr int WW_X = 10 * 34 * WW_XP;                 // floats per X halo buffer (10 x 34 >= 18 x 18 pixels)
 
+// RW = region width: 8 rows x 32 columns, or 16 x 16 for maps whose width is a multiple of 16 only (the 16 x 16 level)
+template <int RW>
 __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
     constexpr int NT = 512;
-    constexpr int LD = WW_TR * 32 * 8 / NT;                   // 4 dY float4 per thread
-    constexpr int XF = (WW_TR + 2) * 34 * 4;                  // 1360 X float4 per halo
+    constexpr int WW_TR = 256 / RW;                           // output rows per region
+    constexpr int XW = RW + 2, XPIX = (WW_TR + 2) * XW;       // halo columns / pixels
+    constexpr int LD = 256 * 8 / NT;                          // 4 dY float4 per thread
+    constexpr int XF = XPIX * 4;                              // X float4 per halo
     constexpr int LX = (XF + NT - 1) / NT;                    // 3
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ds = smem;                     // [2][WW_D]
@@ -547,19 +575,19 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
     float4 bsum;
     bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
     int i_n = 0, i_y0 = 0, i_x0 = 0;
-    auto issue_setup = [&](int n, int tx, int ty) { i_n = n; i_y0 = ty * WW_TR; i_x0 = tx * 32; };
+    auto issue_setup = [&](int n, int tx, int ty) { i_n = n; i_y0 = ty * WW_TR; i_x0 = tx * RW; };
     auto issue_d = [&](int j) {
         const int pix = (tid >> 3) + 64 * j;            // 0..255
-        const int yy = i_y0 + (pix >> 5), xx = i_x0 + (pix & 31);
+        const int yy = i_y0 + pix / RW, xx = i_x0 + pix % RW;
         const bool ok = d_ok & (yy < H);
         const unsigned p = ((unsigned)i_n * H + (unsigned)yy) * W + (unsigned)xx;
         rd[j] = buf_ld4(rsd, sel_u32(ok, (p * (unsigned)Cout + d_c) * 4u, a.nbd));
     };
     auto issue_x = [&](int j) {
-        const int hp = (tid >> 2) + 128 * j;            // 0..339 valid
-        const int hy = hp / 34, hx = hp - hy * 34;
+        const int hp = (tid >> 2) + 128 * j;            // 0..XPIX-1 valid
+        const int hy = hp / XW, hx = hp - hy * XW;
         const int yy = i_y0 - 1 + hy, xx = i_x0 - 1 + hx;
-        const bool ok = (hp < (WW_TR + 2) * 34) & x_cok & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+        const bool ok = (hp < XPIX) & x_cok & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
         const unsigned pix = ((unsigned)i_n * H + (unsigned)yy) * W + (unsigned)xx;
         rx[j] = buf_ld4(rsx, sel_u32(ok, (pix * (unsigned)Cin + x_c) * 4u, a.nbx));
     };
@@ -571,7 +599,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
     };
     auto commit_x = [&](int j, int buf) {
         const int hp = (tid >> 2) + 128 * j;
-        float* dst = hp < (WW_TR + 2) * 34 ? &Xs[buf * WW_X + hp * WW_XP + (tid & 3) * 4] : &Pk[tid * 4];
+        float* dst = hp < XPIX ? &Xs[buf * WW_X + hp * WW_XP + (tid & 3) * 4] : &Pk[tid * 4];
         *(float4*)dst = rx[j];
     };
 
@@ -604,7 +632,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
 
     // fragment addressing: lane (channel idx = lane & 15, tile q = lane >> 4 of the k-step); wave (tile row tr, half hh)
     const int idx = lane & 15, q = lane >> 4;
-    const int tr = wv >> 1, hh = wv & 1;
+    const int tr = RW == 32 ? wv >> 1 : wv, col0 = RW == 32 ? (wv & 1) * 8 : 0;      // tile row, first tile column of the wave
     // (plain C here, unlike the forward kernel: the transform's last results feed the k-step's first MFMAs directly, and
     // the compiler's hazard recogniser does not see a VALU write inside inline asm - v_sub_f32 in asm followed by the MFMA
     // that reads its result gave a stale B operand)
@@ -624,13 +652,13 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int tile = hh * 8 + ks * 4 + q;                 // tile column 0..15 of the region
+            const int tile = col0 + ks * 4 + q;                   // tile column of the region
             // dM = A dY A^T for the lane's two couts, A = [1 0; 1 1; 1 -1; 0 -1]
             float dm[2][16];
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
-                const float* Dp = Ds + cur * WW_D + ((2 * tr) * 32 + 2 * tile) * WW_DP + mb * 16 + idx;
-                const float y00 = Dp[0], y01 = Dp[WW_DP], y10 = Dp[32 * WW_DP], y11 = Dp[33 * WW_DP];
+                const float* Dp = Ds + cur * WW_D + ((2 * tr) * RW + 2 * tile) * WW_DP + mb * 16 + idx;
+                const float y00 = Dp[0], y01 = Dp[WW_DP], y10 = Dp[RW * WW_DP], y11 = Dp[(RW + 1) * WW_DP];
                 // rows: r0 = y0., r1 = y0. + y1., r2 = y0. - y1., r3 = -y1.   (the sign of r3 is folded into the columns)
                 const float r10 = fadd(y00, y10), r11 = fadd(y01, y11), r20 = fsub(y00, y10), r21 = fsub(y01, y11);
                 const float rr[4][2] = {{y00, y01}, {r10, r11}, {r20, r21}, {y10, y11}};     // row 3 holds +y1.
@@ -653,11 +681,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
             // V = B^T d B for the lane's ci
             float vv[16];
             {
-                const float* Xp = Xs + cur * WW_X + ((2 * tr) * 34 + 2 * tile) * WW_XP + idx;
+                const float* Xp = Xs + cur * WW_X + ((2 * tr) * XW + 2 * tile) * WW_XP + idx;
                 float e[4][4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float d0 = Xp[c * WW_XP], d1 = Xp[(34 + c) * WW_XP], d2 = Xp[(68 + c) * WW_XP], d3 = Xp[(102 + c) * WW_XP];
+                    const float d0 = Xp[c * WW_XP], d1 = Xp[(XW + c) * WW_XP], d2 = Xp[(2 * XW + c) * WW_XP], d3 = Xp[(3 * XW + c) * WW_XP];
                     e[0][c] = fsub(d0, d2); e[1][c] = fadd(d1, d2); e[2][c] = fsub(d2, d1); e[3][c] = fsub(d1, d3);
                 }
 #pragma unroll
@@ -736,13 +764,14 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
 
 bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W) {
     if (g_wino_mode != 0 || !g_wino_env) return false;
-    if (Cin % 16 != 0 || Cout % 32 != 0 || W % 32 != 0 || H < 2 || N < 1) return false;
+    if (Cin % 16 != 0 || Cout % 32 != 0 || W % 16 != 0 || H < 2 || N < 1) return false;
     return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
 }
 // slabs for a given upper bound
 int conv_wino_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
     const int nblk = (Cout / 32) * (Cin / 16);
-    const int nsp = N * ceil_div(H, WW_TR) * (W / 32);
+    const int rw = W % 32 == 0 ? 32 : 16;
+    const int nsp = N * ceil_div(H, 256 / rw) * (W / rw);
     int nsb = g_max_blocks / nblk;
     if (nsb > max_slabs) nsb = max_slabs;
     if (nsb > nsp) nsb = nsp;
@@ -757,7 +786,8 @@ int conv_wino_wgrad(const float* x, const float* dy, float* ws, float* bpart, in
     static_assert(lds <= 160 * 1024 && lds >= 8 * 512 * sizeof(float), "Winograd wgrad tiles do not fit the LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_wino_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino_wgrad<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_wino_wgrad<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             vqw_set_error("conv_wino_wgrad: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
@@ -767,11 +797,13 @@ int conv_wino_wgrad(const float* x, const float* dy, float* ws, float* bpart, in
     WinoWgArgs a;
     a.x = x; a.dy = dy; a.part = ws; a.bias_part = bpart;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.tilesY = ceil_div(H, WW_TR); a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
+    const int rw = W % 32 == 0 ? 32 : 16;
+    a.tilesY = ceil_div(H, 256 / rw); a.tilesX = W / rw; a.nsp = N * a.tilesY * a.tilesX;
     a.n_ci_b = Cin / 16; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
     a.nbx = (unsigned)(P * Cin * 4);
     a.nbd = (unsigned)(P * Cout * 4);
-    k_conv_wino_wgrad<<<a.nblk * nsb, 512, lds, st>>>(a);
+    if (rw == 32) k_conv_wino_wgrad<32><<<a.nblk * nsb, 512, lds, st>>>(a);
+    else k_conv_wino_wgrad<16><<<a.nblk * nsb, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino_wgrad");
     return VQW_OK;
 }

@@ -87,6 +87,10 @@ CONV_CASES = [
     (3, 40, 32, 64, 0, False, 64, 3, 1, False, False),
     (1, 16, 96, 128, 0, False, 32, 3, 1, True, True),
     (2, 7, 32, 32, 0, False, 96, 3, 1, True, False),
+    # ... on maps whose width is a multiple of 16 only (32 x 16 regions: the 16 x 16 level; three strips, ragged H)
+    (2, 16, 16, 64, 0, False, 64, 3, 1, True, True),
+    (3, 16, 16, 256, 0, False, 256, 3, 1, False, False),
+    (1, 40, 48, 32, 0, False, 64, 3, 1, True, False),
     # wide 1-channel stem (BASELINE config 4's first block 1 -> 256): lanes over the output channels
     (2, 24, 20, 1, 0, False, 256, 3, 1, True, False),
     (1, 32, 32, 1, 0, False, 256, 1, 1, False, False),
@@ -124,8 +128,8 @@ def winograd_forward():
     ops.WINOGRAD_FWD = old
 
 
-@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[7] == 3 and c[8] == 1 and not c[5] and not c[4] and c[2] % 32 == 0
-                                  and c[3] >= 16 and c[6] >= 32])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[7] == 3 and c[8] == 1 and not c[5] and not c[4] and c[2] % 16 == 0
+                                  and c[3] >= 16 and c[3] % 8 == 0 and c[6] >= 32])
 def test_conv2d_winograd_forward(case, winograd_forward):
     test_conv2d(case, 0)
 
@@ -280,6 +284,7 @@ STATS_CASES = [
     (2, 16, 32, 16, 0, False, 16),     # 16-wide MFMA variant
     (2, 48, 64, 24, 0, False, 96),     # Winograd form: three regions per strip, three cout tiles
     (1, 16, 32, 128, 0, False, 48),    # Winograd form: 16 chunks, partial cout tile
+    (2, 32, 16, 64, 0, False, 64),     # Winograd form on a 16-wide map (32 x 16 regions); direct form: no statistics
     (2, 32, 32, 32, 16, True, 16),     # up-sampled + concat source, 16 couts
     (1, 32, 64, 64, 32, True, 32),     # two sources, 32 couts
 ]
@@ -344,7 +349,8 @@ def test_conv_epilogue_statistics(case):
     y_ref = ops.conv2d(x0, w, b, up2x=up, skip=x1)
     # the same kernel with and without the statistics epilogue, unless only one of the two forms serves the statistics for
     # the shape (a plain layer whose H is not a multiple of the Winograd region keeps the direct form when they are wanted)
-    same_kernel = not ops.WINOGRAD_FWD or up or C1 or H % 16 == 0 or not ops._L().vqw_conv3x3_wino_supported(C0, Cout, N, H, W)
+    same_kernel = not ops.WINOGRAD_FWD or up or C1 or H % (16 if W % 32 == 0 else 32) == 0 or \
+        not ops._L().vqw_conv3x3_wino_supported(C0, Cout, N, H, W)
     if same_kernel:
         assert torch.equal(y, y_ref)
     else:
