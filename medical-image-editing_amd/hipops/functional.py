@@ -33,8 +33,12 @@ def _fake_nhwc(N, C, H, W, like):
 # ---------------------------------------------------------------------------------------------------------------- conv2d
 @torch.library.custom_op("vqw::conv2d", mutates_args=(), device_types="cuda")
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], dilation: int, up2x: bool, skip: Optional[Tensor], relu: bool) -> Tensor:
-    with torch.no_grad():
-        return ops.conv2d(x, weight, bias, dilation=dilation, up2x=up2x, skip=skip, relu=relu)
+    ops._in_custom_op = True       # a training forward below the autograd key, not a forward-only use (ops.WINOGRAD_EVAL)
+    try:
+        with torch.no_grad():
+            return ops.conv2d(x, weight, bias, dilation=dilation, up2x=up2x, skip=skip, relu=relu)
+    finally:
+        ops._in_custom_op = False
 
 
 @conv2d.register_fake

@@ -362,6 +362,16 @@ CONV_STATS = os.environ.get("VQW_CONV_STATS", "1") != "0"      # 0: InstanceNorm
 # Winograd forward moved the parameter gradients 3-5x the reference's own fp32 spread away from its fp64 gradient
 # (direct form: within it) - DESIGN.md section 2.  VQW_WINOGRAD_FWD=1 opts in (forward-only uses, throughput runs).
 WINOGRAD_FWD = os.environ.get("VQW_WINOGRAD_FWD", "0") == "1"
+# Forward-only uses (torch.no_grad(): validation forward, run_recon) have no gradient to disturb and take the Winograd
+# forward by themselves (VQW_WINOGRAD_EVAL=0: direct form there too).
+WINOGRAD_EVAL = os.environ.get("VQW_WINOGRAD_EVAL", "1") != "0"
+_in_custom_op = False          # set by hipops.functional around its no_grad() calls: those are training forwards
+_wino_fwd_call = False         # decided per call by the conv2d / conv2d_cat wrappers, read inside the autograd Functions
+
+
+def _decide_wino_fwd():
+    global _wino_fwd_call
+    _wino_fwd_call = WINOGRAD_FWD or (WINOGRAD_EVAL and not torch.is_grad_enabled() and not _in_custom_op)
 
 
 class _Conv2d(torch.autograd.Function):
@@ -402,7 +412,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
                            "vqw_conv3x3_up2_fwd")
-        elif WINOGRAD_FWD and not up0 and x1 is None and ks == 3 and dilation == 1 and \
+        elif _wino_fwd_call and not up0 and x1 is None and ks == 3 and dilation == 1 and \
                 _L().vqw_conv3x3_wino_supported(Cin, Cout, N, H, W) and \
                 (not (want_stats and not relu) or _L().vqw_conv3x3_wino_fwd_stats_parts(Cin, Cout, N, H, W) > 0
                  or _L().vqw_conv2d_fwd_stats_parts(Cin, 0, 0, N, H, W, Cout, ks, dilation) == 0):
@@ -516,6 +526,7 @@ def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, 
     """'same' conv (k in {1,3}, stride 1) of the virtual input [up2x(x) | skip] (channel concat);
     relu=True fuses nn.ReLU into the epilogue.  want_stats=True returns (y, part): `part` (or None when the shape is not
     served) holds the statistics of y for the InstanceNorm that follows: instance_norm(y, ..., part=part)."""
+    _decide_wino_fwd()
     if want_stats and CONV_STATS:
         return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), True)
     y = _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu))
@@ -599,7 +610,7 @@ class _ConvCat(torch.autograd.Function):
         if x.shape[1] != Cin or tuple(wb.shape[1:]) != (Cin, ks, ks):
             raise RuntimeError("conv2d_cat: shapes %s / %s / %s do not match" % (tuple(x.shape), tuple(wa.shape), tuple(wb.shape)))
         w, b = _cat_weights(wa, ba, wb, bb)
-        if WINOGRAD_FWD and ks == 3 and _L().vqw_conv3x3_wino_supported(Cin, Ca + Cb, N, H, W):
+        if _wino_fwd_call and ks == 3 and _L().vqw_conv3x3_wino_supported(Cin, Ca + Cb, N, H, W):
             L = _L()
             u = _cached(wa, "cat_wino", lambda: _wino_weights(L, w, Cin, Ca + Cb), deps=(wb,))
             y = empty_nhwc(N, Ca + Cb, H, W, x)
@@ -650,6 +661,7 @@ class _ConvCat(torch.autograd.Function):
 
 def conv2d_cat(x, weight_a, bias_a, weight_b, bias_b):
     """[conv(x, weight_a, bias_a) | conv(x, weight_b, bias_b)] along channels (3x3 / 1x1, stride 1, 'same')."""
+    _decide_wino_fwd()
     return _ConvCat.apply(x, weight_a, bias_a, weight_b, bias_b)
 
 

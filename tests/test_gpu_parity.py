@@ -349,7 +349,7 @@ def test_conv_epilogue_statistics(case):
     y_ref = ops.conv2d(x0, w, b, up2x=up, skip=x1)
     # the same kernel with and without the statistics epilogue, unless only one of the two forms serves the statistics for
     # the shape (a plain layer whose H is not a multiple of the Winograd region keeps the direct form when they are wanted)
-    same_kernel = not ops.WINOGRAD_FWD or up or C1 or H % (16 if W % 32 == 0 else 32) == 0 or \
+    same_kernel = not (ops.WINOGRAD_FWD or not torch.is_grad_enabled()) or up or C1 or H % (16 if W % 32 == 0 else 32) == 0 or \
         not ops._L().vqw_conv3x3_wino_supported(C0, Cout, N, H, W)
     if same_kernel:
         assert torch.equal(y, y_ref)
