@@ -274,7 +274,7 @@ extern "C" int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const flo
 }
 extern "C" int vqw_conv3x3_up2_fwd_stats_parts(int Cin, int Cout, int N, int h, int w) {
     if (g_conv_backend != 0 || !conv_up2_ok(Cin, Cout, (long)N * h * w)) return 0;
-    return conv_up2_stat_tiles(Cin, Cout, h, w);
+    return conv_up2_stat_tiles(Cin, Cout, N, h, w);
 }
 extern "C" int vqw_conv3x3_up2_fwd_stats(const float* x_low, const void* ws, const float* bias, float* y, float* part, int N, int h,
                                          int w, int Cin, int Cout, void* stream) {

@@ -25,7 +25,7 @@ bool conv_mfma_fwd_ok(const ConvIn& in, int Cout, int ks);
 int conv_mfma_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,
                   int relu, hipStream_t st, float* stats = nullptr);
 int conv_mfma_stat_tiles(const ConvIn& in, int N, int H, int W, int Cout, int dil);     // partials per plane, 0 = not available
-int conv_up2_stat_tiles(int Cin, int Cout, int h, int w);
+int conv_up2_stat_tiles(int Cin, int Cout, int N, int h, int w);
 bool conv_mfma_wgrad_ok(const ConvIn& in, int Cout, int ks);
 // LDS-resident halo tiles for 3x3 layers with a narrow cout tile (conv_halo.hip)
 extern int g_halo_mode, g_wgrad_tile_mode;
@@ -37,6 +37,10 @@ bool conv_halo_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, i
 int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
                   hipStream_t st, float* stats = nullptr);
 int conv_halo_stat_tiles(const ConvIn& in, int H, int W, int Cout);     // partials per plane written when `stats` is set
+bool conv_halo_up2_ok(int Cin, int Cout, int N, int h, int w);         // collapsed up-sampled forward on the halo kernel
+int conv_halo_up2_stat_tiles(int h, int w);
+int conv_halo_up2_fwd(const float* x_low, const float* wc, const float* bias, float* y, int N, int h, int w, int Cin, int Cout,
+                      int relu, hipStream_t st, float* stats = nullptr);
 // dilated 3x3 layers on LDS-resident rows walked along the dilation's residue chains (conv_dil.hip)
 extern int g_dil_mode;
 bool conv_dil_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);

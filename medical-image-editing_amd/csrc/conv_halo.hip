@@ -48,11 +48,18 @@ struct HaloArgs {
     int relu;
     unsigned nb0, nb1, nbw, nby;
     float* stats;              // optional [N][tilesY*tilesX][Cout][2]: per-tile (sum, M2 about the tile mean) of the output
+    int py, px;                // NTAP == 4 (collapsed 3x3 over a x2 up-sampled input): output parity of this launch
 };
 
-template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC>
+// NTAP = 9: the 3x3 layer.  NTAP = 4: one output parity (py, px) of a 3x3 layer over a nearest x2 up-sampled input, collapsed
+// onto the low-resolution grid (conv_mfma.hip, k_collapse_up_weights): taps (a, b) in {0,1}^2 read the halo at
+// (py + a, px + b), weights [co][4][Cin] of that parity, and output pixel (y, x) of the tile is written to (2y + py, 2x + px)
+// of the [2H, 2W] output.  The same halo, slots and pipeline; an item has 4/9 of the MFMAs.
+template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC, int NTAP = 9>
 __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     constexpr int NT = 64 * NW;
+    constexpr bool UP2 = NTAP == 4;
+    static_assert(NTAP == 9 || (NTAP == 4 && BN != 16 && !TWO_SRC), "tap table: 3x3, or one parity of the collapsed up-sampled form");
     // BN == 16: the 16-cout layers run on v_mfma_f32_16x16x4_f32 (a 32-wide tile would be half padding); a row of 32
     // pixels is two 16-pixel M blocks, rows are padded to 24 floats (conflict-free for its (pixel, k-quarter) lanes)
     constexpr bool M16 = BN == 16;
@@ -66,10 +73,10 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     constexpr int HPIX = (TH + 2) * HALO_W;
     constexpr int HF = HPIX * C4;                 // float4 per halo chunk
     constexpr int LH = (HF + NT - 1) / NT;
-    constexpr int WF = 9 * BN * C4;               // float4 per weight chunk
+    constexpr int WF = NTAP * BN * C4;            // float4 per weight chunk
     constexpr int LW = (WF + NT - 1) / NT;
     constexpr int HBUF = HPIX * KP;               // floats
-    constexpr int WBUF = 9 * BN * KP;
+    constexpr int WBUF = NTAP * BN * KP;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                              // [2][HBUF]
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         int tap = row / BN, n = row % BN;
         int co = co_base + n;
         w_lds[j] = ok ? row * KP + c4 * 4 : DUMMY;
-        w_off[j] = (ok && co < Cout) ? (((unsigned)co * 9 + tap) * Cin + c4 * 4) * 4u : a.nbw;
+        w_off[j] = (ok && co < Cout) ? (((unsigned)co * NTAP + tap) * Cin + c4 * 4) * 4u : a.nbw;
     }
 
     // ---- prefetch of the next (tile, chunk) item: global -> registers, in pieces -----------------------------------
@@ -239,20 +246,21 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
         const int i = M16 ? s : (s >> 1) % TM, j = M16 ? 0 : (s >> 1) / TM, half = s & 1;
         const int yy = dty * TH + wr * TM + i;
         const bool ok = pending & (co_off[j] != 0xFFFFFFFFu) & (yy < H);
-        const unsigned base = (((unsigned)dn * H + (unsigned)yy) * W + (unsigned)(dtx * 32 + col0)) * (unsigned)Cout + co_off[j];
+        const unsigned base = UP2 ? (((unsigned)dn * 2 * H + (unsigned)(2 * yy + a.py)) * 2 * W + (unsigned)(2 * (dtx * 32 + col0) + a.px)) * (unsigned)Cout + co_off[j]
+                                  : (((unsigned)dn * H + (unsigned)yy) * W + (unsigned)(dtx * 32 + col0)) * (unsigned)Cout + co_off[j];
         const int voff = (int)sel_u32(ok, base * 4u, a.nby);       // nothing finished / out of range: dropped by the hardware
         if constexpr (M16) {          // 16x16 C/D layout: col = lane&15 (cout), pixel = blk*16 + 4*(lane>>4) + r
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done4[i][blk][r]), rsy, voff, (blk * 16 + r) * Cout * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done4[i][blk][r]), rsy, voff, (blk * 16 + r) * Cout * 4, 0);     // (never with UP2)
         } else {
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8) {
                 const int r = half * 8 + r8;
                 const int col = (r & 3) + 8 * (r >> 2);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done[i][j][r]), rsy, voff, col * Cout * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(done[i][j][r]), rsy, voff, (UP2 ? 2 : 1) * col * Cout * 4, 0);
             }
         }
     };
@@ -262,7 +270,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     // spread behind MFMAs, in the second half of the item, when the loads have long landed.  At the end of an item only
     // the barrier is left; before, all eight waves wrote their 3-8 float4 there together (LDS write bandwidth:
     // 22-58 KB per item at 128 B/clk) with the matrix pipe empty.
-    constexpr int NMF = M16 ? 8 * 8 * TM : (9 * (KC / 8) - 1) * 4 * TM * TN;     // MFMA positions behind group 0
+    constexpr int NMF = M16 ? 8 * 8 * TM : (NTAP * (KC / 8) - 1) * 4 * TM * TN;     // MFMA positions behind group 0
     constexpr int NCOM = LH + NLW;
     constexpr int CS = (NMF / 2 > NSLOT ? NMF / 2 : NSLOT);
     static_assert(CS + NCOM <= NMF, "more slots than MFMAs to hide them behind");
@@ -359,11 +367,14 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
                 }
             }
         } else {
-            constexpr int KG = KC / 8, NG = 9 * KG;
+            constexpr int KG = KC / 8, NG = NTAP * KG;
             constexpr int GM = 4 * TM * TN;    // MFMAs per group
             float4 av[2][TM], bv[2][TN];
+            // halo offset of a tap: compile-time for the 3x3 table, from the launch's parity for the collapsed form
+            const int tap_py = UP2 ? a.py : 0, tap_px = UP2 ? a.px : 0;
             auto ldfrag = [&](int g, int s) {
-                const int tap = g / KG, kg = g % KG, ky = tap / 3, kx = tap % 3;
+                const int tap = g / KG, kg = g % KG;
+                const int ky = UP2 ? tap_py + tap / 2 : tap / 3, kx = UP2 ? tap_px + tap % 2 : tap % 3;
     #pragma unroll
                 for (int i = 0; i < TM; ++i) av[s][i] = *(const float4*)&Hc[((i + ky) * HALO_W + kx) * KP + kg * 8];
     #pragma unroll
@@ -437,7 +448,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
                         }
                     }
                 }
-                fold_t = (dn * a.tilesX + dtx) * a.tilesY + dty;
+                fold_t = UP2 ? ((dn * 4 + a.py * 2 + a.px) * a.tilesX + dtx) * a.tilesY + dty : (dn * a.tilesX + dtx) * a.tilesY + dty;
             }
         }
         ch = nxch; cn = nn; ctx = ntx; cty = nty;
@@ -449,14 +460,14 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_halo(HaloArgs a) {
     for (int s = 0; s < NFP; ++s) flush_piece(s);
 }
 
-template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC = false>
+template <int NW, int TH, int BN, int KC, bool WPERSIST, bool TWO_SRC = false, int NTAP = 9>
 int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int relu,
-                hipStream_t st, float* stats) {
+                hipStream_t st, float* stats, int py = 0, int px = 0) {
     constexpr int KP = BN == 16 ? 24 : KC + 4;
-    constexpr size_t lds = (size_t)(2 * (TH + 2) * HALO_W * KP + (WPERSIST ? 1 : 2) * 9 * BN * KP + 2 * TH * BN * 2) * sizeof(float);
+    constexpr size_t lds = (size_t)(2 * (TH + 2) * HALO_W * KP + (WPERSIST ? 1 : 2) * NTAP * BN * KP + 2 * TH * BN * 2) * sizeof(float);
     static_assert(lds <= 160 * 1024, "halo tile does not fit the 160 KB LDS");
     static bool attr_set = false;
-    auto kern = k_conv_halo<NW, TH, BN, KC, WPERSIST, TWO_SRC>;
+    auto kern = k_conv_halo<NW, TH, BN, KC, WPERSIST, TWO_SRC, NTAP>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             vqw_set_error("conv_halo: cannot raise the dynamic LDS limit");
@@ -471,11 +482,12 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     a.ntn = ceil_div(Cout, BN); a.nch = (in.C0 + in.C1) / KC;
     a.relu = relu;
     a.stats = stats;
+    a.py = py; a.px = px;
     const long P = (long)N * H * W;
     a.nb0 = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4);
     a.nb1 = (unsigned)(P * in.C1 * 4);
-    a.nbw = (unsigned)((long)Cout * 9 * (in.C0 + in.C1) * 4);
-    a.nby = (unsigned)(P * Cout * 4);
+    a.nbw = (unsigned)((long)Cout * NTAP * (in.C0 + in.C1) * 4);
+    a.nby = (unsigned)((NTAP == 4 ? 4 : 1) * P * Cout * 4);
     // The LDS footprint allows one workgroup per CU: one workgroup per CU, each with an even share of the tiles, so the
     // prologue (weights + first halo, not overlapped with MFMA work) is paid once.  Shorter runs per workgroup
     // (VQW_HALO_KT) would let the dispatcher rebalance when other kernels hold CUs; measured 0.5-1 % slower in the step.
@@ -485,7 +497,7 @@ int launch_halo(const ConvIn& in, const float* w, const float* bias, float* y, i
     int kt = g_halo_kt > 0 ? g_halo_kt : even;
     if (kt > even) kt = even;
     a.kt = kt < 1 ? 1 : kt;
-    k_conv_halo<NW, TH, BN, KC, WPERSIST, TWO_SRC><<<ceil_div(a.nsp, a.kt) * a.ntn, 64 * NW, lds, st>>>(a);
+    k_conv_halo<NW, TH, BN, KC, WPERSIST, TWO_SRC, NTAP><<<ceil_div(a.nsp, a.kt) * a.ntn, 64 * NW, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_halo");
     return VQW_OK;
 }
@@ -539,6 +551,26 @@ int conv_halo_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
     }
     if (wide) return launch_halo<8, 8, 64, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
     return launch_halo<8, 8, 32, 16, false>(in, w, bias, y, N, H, W, Cout, relu, st, stats);
+}
+
+// Collapsed 3x3 over a nearest x2 up-sampled input, forward: four parity launches of the 4-tap form on the low-resolution
+// grid [N, h, w, Cin] -> [N, 2h, 2w, Cout]; wc = [4 parities][Cout][4][Cin] (k_collapse_up_weights).
+static const int g_halo_up2 = env_int("VQW_HALO_UP2", 1);
+bool conv_halo_up2_ok(int Cin, int Cout, int N, int h, int w) {
+    if (g_halo_mode != 0 || !g_halo_up2 || w % 32 != 0 || h < 2 || Cin % 16 != 0 || Cin < 32 || Cout < 32) return false;
+    return 4L * N * h * w * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
+}
+int conv_halo_up2_stat_tiles(int h, int w) { return h % 8 == 0 ? 4 * (h / 8) * (w / 32) : 0; }
+int conv_halo_up2_fwd(const float* x_low, const float* wc, const float* bias, float* y, int N, int h, int w, int Cin, int Cout,
+                      int relu, hipStream_t st, float* stats) {
+    ConvIn in{x_low, nullptr, Cin, 0, 0};
+    for (int par = 0; par < 4; ++par) {
+        const float* wp = wc + (size_t)par * Cout * 4 * Cin;
+        const int rc = Cout > 32 ? launch_halo<8, 8, 64, 16, false, false, 4>(in, wp, bias, y, N, h, w, Cout, relu, st, stats, par >> 1, par & 1)
+                                 : launch_halo<8, 8, 32, 16, false, false, 4>(in, wp, bias, y, N, h, w, Cout, relu, st, stats, par >> 1, par & 1);
+        if (rc) return rc;
+    }
+    return VQW_OK;
 }
 
 // =============================================================================================

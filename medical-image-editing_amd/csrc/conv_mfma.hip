@@ -388,7 +388,8 @@ int conv_mfma_stat_tiles(const ConvIn& in, int N, int H, int W, int Cout, int di
     const int bm = dispatch_bm(in, Cout);
     return ((long)H * W) % bm == 0 ? (int)((long)H * W / bm) : 0;
 }
-int conv_up2_stat_tiles(int Cin, int Cout, int h, int w) {
+int conv_up2_stat_tiles(int Cin, int Cout, int N, int h, int w) {
+    if (conv_halo_up2_ok(Cin, Cout, N, h, w) && conv_halo_up2_stat_tiles(h, w) > 0) return conv_halo_up2_stat_tiles(h, w);
     ConvIn in{nullptr, nullptr, Cin, 0, 0};
     const int bm = dispatch_bm(in, Cout);
     return ((long)h * w) % bm == 0 ? 4 * (int)((long)h * w / bm) : 0;
@@ -449,6 +450,10 @@ int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t s
 }
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
                  hipStream_t st, float* stats) {
+    // LDS-resident halo tiles (conv_halo.hip, 4-tap form): every input element travels L2 -> LDS 1.3 times per parity
+    // instead of 4; only when the statistics partials (if wanted) come in the layout the caller sized for
+    if (conv_halo_up2_ok(Cin, Cout, N, h, w) && (!stats || conv_halo_up2_stat_tiles(h, w) > 0))
+        return conv_halo_up2_fwd(x_low, ws, bias, y, N, h, w, Cin, Cout, relu, st, stats);
     ConvIn in{x_low, nullptr, Cin, 0, 0};
     ConvGeom g{};
     g.ntaps = 4;

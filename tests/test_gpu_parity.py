@@ -91,6 +91,11 @@ CONV_CASES = [
     (2, 16, 16, 64, 0, False, 64, 3, 1, True, True),
     (3, 16, 16, 256, 0, False, 256, 3, 1, False, False),
     (1, 40, 48, 32, 0, False, 64, 3, 1, True, False),
+    # collapsed up-sampled forward on the halo kernel's 4-tap form (low-resolution width a multiple of 32): two cout tile
+    # widths, ragged low-res height, ReLU epilogue
+    (2, 32, 128, 64, 0, True, 32, 3, 1, True, False),
+    (1, 48, 64, 128, 0, True, 96, 3, 1, True, True),
+    (1, 20, 64, 32, 0, True, 64, 3, 1, False, False),
     # wide 1-channel stem (BASELINE config 4's first block 1 -> 256): lanes over the output channels
     (2, 24, 20, 1, 0, False, 256, 3, 1, True, False),
     (1, 32, 32, 1, 0, False, 256, 1, 1, False, False),
@@ -299,6 +304,7 @@ STATS_CASES_GEMM = [
     (2, 150, 96, 32, 32, 3, 12, False),
     (2, 32, 32, 64, 32, 3, 1, True),      # collapsed: four parity launches, each a quarter of every plane
     (1, 32, 64, 128, 64, 3, 1, True),
+    (2, 48, 128, 64, 32, 3, 1, True),     # halo kernel's 4-tap form: 4 x 3 x 2 partials per plane
 ]
 
 

@@ -112,19 +112,36 @@ def main():
             _lib.check(L.vqw_pack_dgrad_weights(p(w), p(wt), co, cin, ks, st()))
             _lib.check(L.vqw_conv3x3_wino_prepare(p(wt), p(ud), ud.numel(), co, cin, st()))
 
+        # 3x3 over an up-sampled single source: the collapsed low-resolution forms, as hipops.ops takes them
+        up2 = bool(up) and not c1 and ks == 3 and dil == 1 and L.vqw_conv3x3_up2_supported(cin, co, N, h // 2, h // 2)
+        up2w = up2 and L.vqw_conv3x3_up2_wgrad_supported(cin, co, N, h // 2, h // 2)
+        if up2:
+            uws = torch.empty(L.vqw_conv3x3_up2_ws_bytes(cin, co), dtype=torch.uint8, device=dev)
+            _lib.check(L.vqw_conv3x3_up2_prepare(p(w), p(uws), uws.numel(), cin, co, st()))
+            glow = torch.empty(N, h // 2, h // 2, cin, device=dev)
+        if up2w:
+            wws = torch.empty(L.vqw_conv3x3_up2_wgrad_ws_bytes(cin, co, N, h // 2, h // 2), dtype=torch.uint8, device=dev)
+
         def fwd():
-            if wino_f:
+            if up2:
+                _lib.check(L.vqw_conv3x3_up2_fwd(p(x0), p(uws), p(b), p(y), N, h // 2, h // 2, cin, co, 0, st()))
+            elif wino_f:
                 _lib.check(L.vqw_conv3x3_wino_fwd(p(x0), p(uf), p(b), p(y), N, h, h, cin, co, 0, st()))
             else:
                 _lib.check(L.vqw_conv2d_fwd(p(x0), c0, int(up), p(x1), c1, p(w), p(b), p(y), N, h, h, co, ks, dil, 0, st()))
 
         def dgrad():
-            if wino_d:
+            if up2:
+                _lib.check(L.vqw_conv3x3_up2_dgrad(p(dy), p(uws), p(glow), N, h // 2, h // 2, cin, co, st()))
+            elif wino_d:
                 _lib.check(L.vqw_conv3x3_wino_fwd(p(dy), p(ud), None, p(gfull), N, h, h, co, cin, 0, st()))
             else:
                 _lib.check(L.vqw_conv2d_fwd(p(dy), co, 0, None, 0, p(wt), None, p(gfull), N, h, h, cin, ks, dil, 0, st()))
 
         def wgrad():
+            if up2w:
+                _lib.check(L.vqw_conv3x3_up2_wgrad(p(x0), p(dy), p(dw), p(db), p(wws), wws.numel(), N, h // 2, h // 2, cin, co, 0, st()))
+                return
             _lib.check(L.vqw_conv2d_wgrad(p(x0), c0, int(up), p(x1), c1, p(dy), p(dw), p(db), p(ws), ws.numel(), N, h, h, co, ks,
                                           dil, 0, st()))
         for name, fn, on in (("fwd", fwd, True), ("dgrad", dgrad, dg), ("wgrad", wgrad, True)):
