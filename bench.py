@@ -247,7 +247,8 @@ def main():
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
                 if tj.get("csrc_digest") == csrc_digest():
-                    traffic = tj["families"][dom]["hbm_bytes_per_launch"]
+                    # per API launch of the family (a call may be several kernel launches): bytes per step / calls per step
+                    traffic = tj["families"][dom]["hbm_bytes_per_step"] / primary[dom]["launches_per_step"]
                     traffic_source = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel sources %s)" % tj["csrc_digest"][:12]
                 else:
                     traffic_source = "none: profiles/r02_hbm_traffic.json was taken with other kernel sources"

@@ -27,6 +27,9 @@ def load(d, name):
     return agg
 
 
+STEPS = 3       # the PMC passes run `bench.py --steps 2 --warmup 1 --no-kernel-timing`: three training steps in all
+
+
 def main(fetch_dir, write_dir, out):
     F, Wr = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
     kernels = {}
@@ -40,13 +43,16 @@ def main(fetch_dir, write_dir, out):
         sel = [v for k, v in kernels.items() if any(k.startswith(p) for p in pats)]
         n = sum(v["launches"] for v in sel)
         if n:
-            fam[name] = dict(launches=n, hbm_bytes_per_launch=sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n)
+            tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel)
+            # per kernel launch, and per training step (an API call may be several kernel launches: the four parity
+            # launches of a collapsed up-sampled forward; bench.py divides the per-step figure by ITS launches per step)
+            fam[name] = dict(launches=n, hbm_bytes_per_launch=tot / n, hbm_bytes_per_step=tot / STEPS)
     import bench
     json.dump(dict(csrc_digest=bench.csrc_digest(), source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1`",
                    correction="reads = 2*FETCH_SIZE*1024 (gfx950 half-count), writes = WRITE_SIZE*1024",
                    families=fam, kernels=kernels), open(out, "w"), indent=1, sort_keys=True)
     for k, v in fam.items():
-        print("%-24s %6d launches  %8.1f MB / launch" % (k, v["launches"], v["hbm_bytes_per_launch"] / 1e6))
+        print("%-24s %6d kernel launches  %8.1f MB / launch  %9.1f MB / step" % (k, v["launches"], v["hbm_bytes_per_launch"] / 1e6, v["hbm_bytes_per_step"] / 1e6))
 
 
 if __name__ == "__main__":
