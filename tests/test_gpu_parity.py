@@ -1484,6 +1484,36 @@ def test_training_step_is_bit_deterministic():
     assert all(torch.equal(x, y) for x, y in zip(a[0], b[0]))
 
 
+@pytest.mark.parametrize("N,S,Cin,Cout,dil", [(32, 256, 32, 32, 1), (32, 128, 64, 64, 1), (32, 32, 256, 512, 1), (32, 16, 512, 512, 1),
+                                              (32, 256, 32, 32, 18), (32, 256, 32, 64, 1)])
+def test_conv_forms_agree_at_baseline_sizes(N, S, Cin, Cout, dil):
+    """BASELINE config 2's layer shapes at full size (batch 32): the forms the auto backend takes - Winograd-form input and
+    weight gradients, LDS-resident halo tiles / rows in the forward - against the implicit-GEMM kernels on the same tensors
+    (backend 2), both exact fp32: outputs and all gradients agree to rounding."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(N + S + Cin)
+    x = torch.randn(N, Cin, S, S, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (9 * Cin) ** 0.5).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(Cout, device=DEV, generator=g)
+    gy = torch.randn(N, Cout, S, S, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+
+    def run(backend):
+        old = ops.set_conv_backend(backend)
+        try:
+            xs, ws, bs = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+            y = ops.conv2d(xs, ws, bs, dilation=dil)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            return y.detach(), xs.grad, ws.grad, bs.grad
+        finally:
+            ops.set_conv_backend(old)
+    a, r = run(0), run(2)
+    for name, u, v, tol in zip(("y", "dx", "dw", "db"), a, r, (2e-6, 2e-6, 1e-5, 1e-5)):
+        assert_close(u, v, tol, "%s: auto backend vs implicit-GEMM kernels" % name)
+    with torch.no_grad():        # forward-only use: the Winograd forward (dilation 1) against the same reference
+        assert_close(ops.conv2d(x, w, b, dilation=dil), r[0], 2e-6, "forward-only form")
+
+
 def test_conv_tensors_beyond_4gib_run_as_image_groups():
     """A conv whose activation tensors exceed the 32-bit buffer-descriptor range (4 GiB) is run by the library as
     consecutive image groups: forward, input gradient and (accumulated) weight gradient equal the same work done in
