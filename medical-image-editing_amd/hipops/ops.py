@@ -355,12 +355,13 @@ def _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dil, relu=False):
 
 
 CONV_STATS = os.environ.get("VQW_CONV_STATS", "1") != "0"      # 0: InstanceNorm always reduces itself (A/B timing)
-# Winograd F(2x2, 3x3) form of plain 3x3 layers.  The INPUT GRADIENT takes it whenever the library serves the shape
-# (VQW_WINOGRAD=0 turns the kernels off altogether): that convolution is linear in dy, so its rounding difference (a few ulps
-# of the accumulated magnitude) reaches the parameter gradients unamplified.  The FORWARD does not by default: forward
-# activations decide discrete events (ReLU masks, pooling arg-max, code ids), and on the reference's step fixtures the
-# Winograd forward moved the parameter gradients 3-5x the reference's own fp32 spread away from its fp64 gradient
-# (direct form: within it) - DESIGN.md section 2.  VQW_WINOGRAD_FWD=1 opts in (forward-only uses, throughput runs).
+# Winograd F(2x2, 3x3) form of plain 3x3 layers.  The INPUT and WEIGHT GRADIENTS take it whenever the library serves the
+# shape (VQW_WINOGRAD=0 turns the kernels off altogether): they are linear in dy given the forward's masks, so the form's
+# rounding difference (a few ulps of the accumulated magnitude) reaches the parameter gradients unamplified.  The training
+# FORWARD does not by default: the Winograd form computes the four pixels of a tile by four different formulas, so equal
+# inputs no longer give bit-equal outputs, and behind the quantised (piecewise constant) map the reference's max-pools sit
+# on exact ties - on the config-4 step fixture the broken ties moved decoder gradients 3-5x the reference's own fp32 spread
+# away from its fp64 gradient.  VQW_WINOGRAD_FWD=1 opts in (throughput runs).
 WINOGRAD_FWD = os.environ.get("VQW_WINOGRAD_FWD", "0") == "1"
 # Forward-only uses (torch.no_grad(): validation forward, run_recon) have no gradient to disturb and take the Winograd
 # forward by themselves (VQW_WINOGRAD_EVAL=0: direct form there too).
@@ -369,9 +370,28 @@ _in_custom_op = False          # set by hipops.functional around its no_grad() c
 _wino_fwd_call = False         # decided per call by the conv2d / conv2d_cat wrappers, read inside the autograd Functions
 
 
+WINOGRAD_FWD_ENCODER = os.environ.get("VQW_WINOGRAD_FWD_ENCODER", "0") == "1"
+_wino_fwd_scope = 0            # > 0 inside `with winograd_forward():`
+
+
+class winograd_forward:
+    """Context: plain 3x3 layers called inside take the Winograd forward also in training.  For sub-networks whose
+    activations are not piecewise constant (the encoder: its input is an image).  The Winograd form computes the four pixels
+    of a 2x2 tile by four different formulas, so mathematically equal outputs are no longer bit-equal; behind the quantised
+    (piecewise constant) map the reference's max-pools sit on exact ties and a broken tie re-routes gradients."""
+
+    def __enter__(self):
+        global _wino_fwd_scope
+        _wino_fwd_scope += 1
+
+    def __exit__(self, *exc):
+        global _wino_fwd_scope
+        _wino_fwd_scope -= 1
+
+
 def _decide_wino_fwd():
     global _wino_fwd_call
-    _wino_fwd_call = WINOGRAD_FWD or (WINOGRAD_EVAL and not torch.is_grad_enabled() and not _in_custom_op)
+    _wino_fwd_call = WINOGRAD_FWD or _wino_fwd_scope > 0 or (WINOGRAD_EVAL and not torch.is_grad_enabled() and not _in_custom_op)
 
 
 class _Conv2d(torch.autograd.Function):

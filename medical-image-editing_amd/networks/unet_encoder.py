@@ -58,6 +58,9 @@ class UNetEncoder(nn.Module):
         self.init_embed = True
 
     def feature_extraction(self, x):
+        if ops.WINOGRAD_FWD_ENCODER:
+            with ops.winograd_forward():
+                return run_half(self, 1, self._levels, x)
         return run_half(self, 1, self._levels, x)
 
     def forward(self, x, skip_vq=False, rank=False):
