@@ -371,6 +371,7 @@ _wino_fwd_call = False         # decided per call by the conv2d / conv2d_cat wra
 
 
 WINOGRAD_FWD_ENCODER = os.environ.get("VQW_WINOGRAD_FWD_ENCODER", "0") == "1"
+WINOGRAD_FWD_POOLFREE = os.environ.get("VQW_WINOGRAD_FWD_POOLFREE", "1") != "0"      # decoder layers past its last max-pool
 _wino_fwd_scope = 0            # > 0 inside `with winograd_forward():`
 
 

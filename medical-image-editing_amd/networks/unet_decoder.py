@@ -1,4 +1,6 @@
 """SPADE-style U-Net decoder (reference: networks/unet_decoder.py:19-164) on the HIP kernels."""
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -54,10 +56,15 @@ class UNetDecoder(nn.Module):
                 d_skips[i] = self.dropblock(d_skips[i])
         # the SPADE modulation maps need only the skips: queue them on the branch stream, deepest level first, so
         # they run beside the bottleneck and the up-path trunk (same arithmetic as evaluating them inside each block)
-        maps = [u.style_maps(d_skip) for u, d_skip in zip(self.up_convs, d_skips)]
-        x = self.double_conv2(x)
-        for u, d_skip, m in zip(self.up_convs, d_skips, maps):
-            x = u(x, d_skip, maps=m)
-        out = ops.add(x, self.conv_last(x))
-        out = self.conv1x1(out)
-        return ops.tanh(out)
+        # Past the last max-pool nothing downstream decides anything by comparing activations of different pixels, so the
+        # layers from here on may take the Winograd forward in training too (ops.winograd_forward; the down path above
+        # keeps the direct form: its pools sit on exact ties of the piecewise constant input)
+        scope = ops.winograd_forward() if ops.WINOGRAD_FWD_POOLFREE else contextlib.nullcontext()
+        with scope:
+            maps = [u.style_maps(d_skip) for u, d_skip in zip(self.up_convs, d_skips)]
+            x = self.double_conv2(x)
+            for u, d_skip, m in zip(self.up_convs, d_skips, maps):
+                x = u(x, d_skip, maps=m)
+            out = ops.add(x, self.conv_last(x))
+            out = self.conv1x1(out)
+            return ops.tanh(out)
