@@ -43,13 +43,16 @@ def synthetic_batch(batch, size, seed, device):
 
 
 def csrc_digest():
-    """sha1 over the convolution kernel sources: ties a committed PMC traffic file to the kernels it was measured on."""
+    """sha1 over the convolution kernel sources and the host code that picks a kernel form per layer: ties a committed PMC
+    traffic file to the kernels and the dispatch it was measured on."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "medical-image-editing_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.startswith("conv") and f.endswith((".hip", ".h")) or f == "mfma_util.h":
             h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("hipops/ops.py", "networks/unet_decoder.py", "networks/unet_encoder.py", "networks/blocks.py"):
+        h.update(open(os.path.join(ROOT, "medical-image-editing_amd", f), "rb").read())
     return h.hexdigest()
 
 
@@ -263,6 +266,13 @@ def main():
                                       "VQW_CONCURRENT_VIEWS=0 equivalent): each kernel alone on the GPU"
                                       if kern_x else "HIP events over the timed region"),
                             kernels=primary)
+            if dom == "conv_winograd":
+                # this family's FLOPs are the 4/9 of the direct form's that its kernels execute: `achieved` / `frac` are
+                # hardware utilisation; priced at the direct form's (the operator's algorithmic) FLOPs the rate is 2.25x
+                roofline["achieved_in_direct_form_flops"] = ach * 2.25
+                roofline["frac_in_direct_form_flops"] = ach * 2.25 / (PEAK_FP32_MFMA / 1e12)
+                roofline["note"] = ("Winograd F(2x2,3x3) kernels: achieved/frac count the FLOPs executed (4/9 of the direct "
+                                    "form's); *_in_direct_form_flops price the same launches at the operator's FLOPs")
             if kern_x and dom in kern_c:
                 roofline["timed_region_concurrent"] = dict(
                     achieved=kern_c[dom]["tflops"], frac=kern_c[dom]["tflops"] / (PEAK_FP32_MFMA / 1e12),

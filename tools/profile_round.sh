@@ -5,6 +5,14 @@ set -e
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
+# HBM traffic first: the bench lines below read profiles/r02_hbm_traffic.json (tied to the sources by digest)
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+echo "fetch done"
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
+echo "write done"
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $R/profiles/r02_hbm_traffic.json > $O/hbm_traffic.txt
+cp $R/profiles/r02_hbm_traffic.json $O/hbm_traffic.json
+echo "traffic done"
 timeout -k 10 500 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench default done"
 timeout -k 10 500 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_steps20.json 2> $O/bench_steps20.err
@@ -15,10 +23,6 @@ export VQW_WGRAD_STREAM=0 VQW_CONCURRENT_VIEWS=0
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ser -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof_serialised.json 2> $O/ser.err
 unset VQW_WGRAD_STREAM VQW_CONCURRENT_VIEWS
 echo "ser done"
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
-echo "fetch done"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
-echo "write done"
 # config 4 and config 5
 timeout -k 10 300 python3 $R/tools/config4_bench.py > $O/config4_bench.json 2> $O/config4_bench.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg4 -o t -- python3 $R/tools/config4_bench.py --steps 3 --warmup 1 > /dev/null 2> $O/cfg4.err
