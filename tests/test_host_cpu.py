@@ -129,6 +129,42 @@ def test_dispatcher_registration_matches_header():
         assert torch.ops.vqw.add(a, a, torch.empty(8, device="cuda"), 8, 0) is None
 
 
+def test_winograd_forward_placement_rules():
+    """Where the Winograd FORWARD may be taken (hipops.ops._decide_wino_fwd): never in a plain training forward, always in
+    forward-only uses (no_grad) unless the call comes from a custom operator's implementation (those run a training forward
+    under no_grad), inside `ops.winograd_forward()` scopes (the decoder past its last max-pool), or when forced."""
+    from hipops import ops
+    saved = (ops.WINOGRAD_FWD, ops.WINOGRAD_EVAL, ops._in_custom_op)
+    try:
+        ops.WINOGRAD_FWD, ops.WINOGRAD_EVAL, ops._in_custom_op = False, True, False
+        ops._decide_wino_fwd()
+        assert ops._wino_fwd_call is False
+        with torch.no_grad():
+            ops._decide_wino_fwd()
+            assert ops._wino_fwd_call is True
+            ops._in_custom_op = True
+            ops._decide_wino_fwd()
+            assert ops._wino_fwd_call is False
+            ops._in_custom_op = False
+            ops.WINOGRAD_EVAL = False
+            ops._decide_wino_fwd()
+            assert ops._wino_fwd_call is False
+        with ops.winograd_forward():
+            with ops.winograd_forward():
+                ops._decide_wino_fwd()
+                assert ops._wino_fwd_call is True
+            ops._decide_wino_fwd()
+            assert ops._wino_fwd_call is True
+        ops._decide_wino_fwd()
+        assert ops._wino_fwd_call is False
+        ops.WINOGRAD_FWD = True
+        ops._decide_wino_fwd()
+        assert ops._wino_fwd_call is True
+    finally:
+        ops.WINOGRAD_FWD, ops.WINOGRAD_EVAL, ops._in_custom_op = saved
+        ops._decide_wino_fwd()
+
+
 def test_config_factory_mirrors_trainer_base(tmp_path):
     """trainers.config: the reference's config keys -> constructors exactly as trainers/base.py:164-237,261-278 wires them,
     incl. `init_embed = not use_init_embed`, None-for-false flags, per-network Adam settings; configs/ holds the five
