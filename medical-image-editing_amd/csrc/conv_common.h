@@ -60,7 +60,7 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
                   hipStream_t st, float* stats = nullptr);
 bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W);
 int conv_wino_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
-int conv_wino_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st);
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
 bool conv_up2_ok(int Cin, int Cout, long Plow);

@@ -1162,21 +1162,23 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
 // dbias != nullptr asks the kernel to produce the bias gradient too; returns 1 (not an error) in *bias_done when it did.
 // true when conv_mfma_wgrad takes the Winograd form for the layer (the profile scope prices it at the FLOPs it executes)
 bool conv_mfma_wgrad_is_wino(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil) {
-    return g_wgrad_variant != 1 && g_wino_wgrad && ks == 3 && dil == 1 && in.C1 == 0 && !in.up0 && (long)N * H * W >= 32 &&
-           fits_u32((long)N * H * W, in.C0, Cout) && conv_wino_wgrad_ok(in.C0, Cout, N, H, W);
+    if (in.C1 > 0 && (in.C0 % 16 != 0 || in.C1 % 16 != 0)) return false;      // a 16-channel ci block must not straddle the sources
+    if (in.up0 && ((H | W) & 1)) return false;
+    return g_wgrad_variant != 1 && g_wino_wgrad && ks == 3 && dil == 1 && (long)N * H * W >= 32 &&
+           fits_u32((long)N * H * W, in.C0 + in.C1, Cout) && conv_wino_wgrad_ok(in.C0 + in.C1, Cout, N, H, W);
 }
 int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, int* bias_done, float* ws, int N, int H, int W,
                     int Cout, int ks, int dil, hipStream_t st, int acc) {
     *bias_done = 0;
     if (!fits_u32((long)N * H * W, in.C0 + in.C1, Cout)) return conv_direct_wgrad(in, dy, dw, ws, N, H, W, Cout, ks, dil, st, acc);
     if (conv_mfma_wgrad_is_wino(in, N, H, W, Cout, ks, dil)) {     // Winograd form (conv_wino.hip): widths that are multiples of 16
-        const int Cin = in.C0;
+        const int Cin = in.C0 + in.C1;
         const long nout = (long)Cout * 9 * Cin;
         *bias_done = dbias != nullptr;
         int kt = 1;
         const int nsbw = conv_wino_wgrad_blocks(Cin, Cout, N, H, W, wg9_split_blocks(Cin, Cout, (long)N * H * W), &kt);
         float* bp = dbias ? ws + (size_t)nsbw * nout : nullptr;
-        int rc = conv_wino_wgrad(in.src0, dy, ws, bp, N, H, W, Cin, Cout, nsbw, kt, st);
+        int rc = conv_wino_wgrad(in, dy, ws, bp, N, H, W, Cout, nsbw, kt, st);
         if (rc) return rc;
         if (dbias) {
             rc = reduce_rows(bp, dbias, Cout, nsbw, st, acc);

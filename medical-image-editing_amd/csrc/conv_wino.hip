@@ -526,14 +526,16 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
 namespace {
 
 struct WinoWgArgs {
-    const float* x;
+    const float* x;            // source 0: C0 channels, at half resolution when up0 (nearest x2 up-sampled on the fly)
+    const float* x1;           // source 1: C1 channels at full resolution (channel concat [src0 | src1]), or null
+    int C0, C1, up0;
     const float* dy;
     float* part;
     float* bias_part;
     int N, H, W, Cin, Cout;
     int tilesY, tilesX, nsp;
     int n_ci_b, nblk, kt;
-    unsigned nbx, nbd;
+    unsigned nbx, nbx1, nbd;
 };
 
 constexpr int WW_DP = 40, WW_XP = 24;                 // floats per dY pixel (32 co + 8) / per X pixel (16 ci + 8) in LDS
@@ -563,13 +565,20 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
     const int sp0 = sblk * a.kt;
     const int my_tiles = min(a.kt, a.nsp - sp0);
     const int per_img = a.tilesY * a.tilesX;
-    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsd = make_rsrc(a.dy, a.nbd);
+    // the 16-channel ci block of the workgroup lies in one of the two sources (C0 % 16 == 0 whenever there are two)
+    const bool x_from0 = ci_base < a.C0;
+    const unsigned xC = x_from0 ? (unsigned)a.C0 : (unsigned)a.C1;
+    const unsigned nbx = x_from0 ? a.nbx : a.nbx1;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(x_from0 ? a.x : a.x1, nbx), rsd = make_rsrc(a.dy, a.nbd);
+    const int x_sh = (x_from0 && a.up0) ? 1 : 0;
+    const int x_Hs = H >> x_sh, x_Ws = W >> x_sh;
 
     // loader: dY float4 f -> pixel f / 8, cout quad f % 8; X float4 f -> halo pixel f / 4, ci quad f % 4
     const int d_c = co_base + (tid & 7) * 4;
     const bool d_ok = d_c < Cout;
     const int x_c = ci_base + (tid & 3) * 4;
     const bool x_cok = x_c < Cin;
+    const unsigned x_cb = (unsigned)(x_from0 ? x_c : x_c - a.C0) * 4u;
     const bool do_bias = a.bias_part != nullptr && ci_base == 0;
     float4 rd[LD], rx[LX];
     float4 bsum;
@@ -588,8 +597,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
         const int hy = hp / XW, hx = hp - hy * XW;
         const int yy = i_y0 - 1 + hy, xx = i_x0 - 1 + hx;
         const bool ok = (hp < XPIX) & x_cok & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
-        const unsigned pix = ((unsigned)i_n * H + (unsigned)yy) * W + (unsigned)xx;
-        rx[j] = buf_ld4(rsx, sel_u32(ok, (pix * (unsigned)Cin + x_c) * 4u, a.nbx));
+        const unsigned pix = ((unsigned)i_n * x_Hs + (unsigned)(yy >> x_sh)) * x_Ws + (unsigned)(xx >> x_sh);
+        rx[j] = buf_ld4(rsx, sel_u32(ok, pix * xC * 4u + x_cb, nbx));
     };
     // `once`: 1 when the committed tile is one of this workgroup's (the prefetch behind the last tile runs off its share)
     auto commit_d = [&](int j, int buf, float once) {
@@ -762,6 +771,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad(WinoWgArgs a) {
 
 }  // namespace
 
+// (two sources: both channel counts multiples of 16, so that a 16-channel ci block never straddles them)
 bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W) {
     if (g_wino_mode != 0 || !g_wino_env) return false;
     if (Cin % 16 != 0 || Cout % 32 != 0 || W % 16 != 0 || H < 2 || N < 1) return false;
@@ -780,8 +790,9 @@ int conv_wino_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs
     if (kt_out) *kt_out = kt;
     return ceil_div(nsp, kt);
 }
-int conv_wino_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st) {
+    const int Cin = in.C0 + in.C1;
     constexpr size_t lds = (size_t)(2 * (WW_D + WW_X) + 512 * 4) * sizeof(float);
     static_assert(lds <= 160 * 1024 && lds >= 8 * 512 * sizeof(float), "Winograd wgrad tiles do not fit the LDS");
     static bool attr_set = false;
@@ -795,12 +806,14 @@ int conv_wino_wgrad(const float* x, const float* dy, float* ws, float* bpart, in
     }
     const long P = (long)N * H * W;
     WinoWgArgs a;
-    a.x = x; a.dy = dy; a.part = ws; a.bias_part = bpart;
+    a.x = in.src0; a.x1 = in.src1; a.C0 = in.C0; a.C1 = in.C1; a.up0 = in.up0;
+    a.dy = dy; a.part = ws; a.bias_part = bpart;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     const int rw = W % 32 == 0 ? 32 : 16;
     a.tilesY = ceil_div(H, 256 / rw); a.tilesX = W / rw; a.nsp = N * a.tilesY * a.tilesX;
     a.n_ci_b = Cin / 16; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
-    a.nbx = (unsigned)(P * Cin * 4);
+    a.nbx = (unsigned)((in.up0 ? P / 4 : P) * in.C0 * 4);
+    a.nbx1 = (unsigned)(P * in.C1 * 4);
     a.nbd = (unsigned)(P * Cout * 4);
     if (rw == 32) k_conv_wino_wgrad<32><<<a.nblk * nsb, 512, lds, st>>>(a);
     else k_conv_wino_wgrad<16><<<a.nblk * nsb, 512, lds, st>>>(a);

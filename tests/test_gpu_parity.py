@@ -91,6 +91,11 @@ CONV_CASES = [
     (2, 16, 16, 64, 0, False, 64, 3, 1, True, True),
     (3, 16, 16, 256, 0, False, 256, 3, 1, False, False),
     (1, 40, 48, 32, 0, False, 64, 3, 1, True, False),
+    # Winograd-form weight gradient with two sources (up-sampled src0 | skip): UpBlock convs; ci blocks in either source
+    (2, 32, 32, 64, 32, True, 32, 3, 1, True, False),
+    (1, 16, 64, 32, 16, True, 64, 3, 1, False, True),
+    (2, 32, 16, 128, 64, True, 64, 3, 1, True, False),
+    (1, 24, 32, 16, 32, False, 32, 3, 1, True, False),
     # collapsed up-sampled forward on the halo kernel's 4-tap form (low-resolution width a multiple of 32): two cout tile
     # widths, ragged low-res height, ReLU epilogue
     (2, 32, 128, 64, 0, True, 32, 3, 1, True, False),
