@@ -69,6 +69,12 @@ int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H, int W, int
 int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const float* src1, int C1,
                          const float* w_ohwi, const float* bias, float* y, float* part,
                          int N, int H, int W, int Cout, int ksize, int dil, void* stream);
+/* y += conv(src0) ('same' conv, no bias): the input gradient of one of several convolutions of the same tensor summed in
+ * place (aspp.py:44-47: five branches of one input; autograd would add their gradients pairwise, three passes each).
+ * Served for the shapes of the row-chain kernel (dilated 3x3, 32 channels, rows <= 256 pixels): query ..._supported. */
+int vqw_conv2d_fwd_acc_supported(int C0, int N, int H, int W, int Cout, int ksize, int dil);
+int vqw_conv2d_fwd_acc(const float* src0, int C0, const float* w_ohwi, float* y, int N, int H, int W, int Cout, int ksize,
+                       int dil, void* stream);
 size_t vqw_conv2d_wgrad_ws_bytes(int C0, int C1, int N, int H, int W, int Cout, int ksize);
 /* dW[co][ky][kx][ci] (OHWI) and, if dbias != NULL, dbias[co] = sum_p dY.
  * accumulate=1 adds into dw / dbias (a layer used by both views of a step: one gradient buffer, no extra pass). */

@@ -142,6 +142,23 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
     return conv_direct_fwd(in, w_ohwi, bias, y, N, H, W, Cout, ksize, dil, relu, st);
 }
 
+// y += conv(src0): the input gradient of one of several convolutions of the same tensor, summed in place (autograd would
+// write each to a tensor of its own and add them pairwise: three more passes over the tensor per extra consumer).
+// Served by the row-chain kernel (dilated 3x3, 32 channels: the atrous pyramid's branches); query ..._supported first.
+extern "C" int vqw_conv2d_fwd_acc_supported(int C0, int N, int H, int W, int Cout, int ksize, int dil) {
+    ConvIn in{nullptr, nullptr, C0, 0, 0};
+    return g_conv_backend == 0 && N > 0 && conv_batch_group(N, H, W, C0, Cout) >= N && conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil) ? 1 : 0;
+}
+extern "C" int vqw_conv2d_fwd_acc(const float* src0, int C0, const float* w_ohwi, float* y, int N, int H, int W, int Cout,
+                                  int ksize, int dil, void* stream) {
+    VQW_CHECK(src0 && w_ohwi && y, "vqw_conv2d_fwd_acc: source, weights and output must be set");
+    VQW_CHECK(vqw_conv2d_fwd_acc_supported(C0, N, H, W, Cout, ksize, dil), "vqw_conv2d_fwd_acc: shape not served (query vqw_conv2d_fwd_acc_supported)");
+    ConvIn in{src0, nullptr, C0, 0, 0};
+    const double px = (double)N * H * W;
+    ProfScope ps(0, 2.0 * px * Cout * 9.0 * C0, (hipStream_t)stream, 4.0 * (px * C0 + 2.0 * px * Cout + 9.0 * Cout * C0));
+    return conv_dil_fwd(in, w_ohwi, nullptr, y, N, H, W, Cout, dil, 0, (hipStream_t)stream, nullptr, 1);
+}
+
 // Convolution that also leaves the InstanceNorm statistics of its output (per-tile partial sums from the epilogue of the
 // halo-tile kernel): the norm that follows (blocks.py:45-49: conv -> InstanceNorm -> ReLU) skips its own reduction pass.
 // ..._stats_parts() = partial (sum, M2 about the tile mean) pairs per (image, channel), 0 when the shape is not served.

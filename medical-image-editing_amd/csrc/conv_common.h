@@ -45,7 +45,7 @@ int conv_halo_up2_fwd(const float* x_low, const float* wc, const float* bias, fl
 extern int g_dil_mode;
 bool conv_dil_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
 int conv_dil_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int dil, int relu,
-                 hipStream_t st, float* stats = nullptr);
+                 hipStream_t st, float* stats = nullptr, int accumulate = 0);
 int conv_dil_stat_tiles(int H);
 bool conv_dil_wgrad_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil);
 int conv_dil_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int max_slabs, int N, int H, int W, int Cout, int dil,

@@ -49,7 +49,9 @@ struct DilArgs {
     float* stats;              // optional [N][H][Cout][2]: (sum, M2 about the row mean) of every output row
 };
 
-template <int NW>
+// ACC: the output is ADDED to what y holds (input gradients of several convolutions of one tensor summed in place: the
+// atrous pyramid's branches); the old values of a row's outputs are fetched behind the first MFMAs of its step.
+template <int NW, bool ACC>
 __global__ void __launch_bounds__(64 * NW, 1) k_conv_dilrow(DilArgs a) {
     constexpr int NT = 64 * NW, WMAX = 32 * NW, KP = 36;
     constexpr int SLOT = (WMAX + 1) * KP;             // floats per row slot (pixel WMAX = zero pixel)
@@ -158,6 +160,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_dilrow(DilArgs a) {
     const int col0 = 4 * (lane >> 5);
     const float lo = a.relu ? 0.f : -__builtin_inff();
     f32x16 acc, done;
+    float yold[ACC ? 16 : 1];
     bool pending = false;
     int dg = 0;                              // global row of the tile waiting in `done`
     // C/D layout (32x32): col = lane & 31 (cout), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel column)
@@ -188,9 +191,15 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_dilrow(DilArgs a) {
             auto slot = [&](int m) {         // m: MFMA position behind group 0 (compile-time after unrolling)
                 if (m < 2) flush_piece(m);
                 else if (m < 2 + LH) issue_h(m - 2, g2);
+                else if (ACC && m < 2 + LH + 16) {       // old value of output r of this step's row
+                    const int r = m - 2 - LH;
+                    const unsigned base = (((unsigned)g0 * W + (unsigned)(wv * 32 + col0)) * (unsigned)Cout + (unsigned)co) * 4u;
+                    yold[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsy, (int)sel_u32(st_ok, base, a.nby),
+                                                                                 ((r & 3) + 8 * (r >> 2)) * Cout * 4, 0));
+                }
                 else if (m >= 96 && m < 96 + LH) commit_h(m - 96, sA);
             };
-            auto slotted = [&](int m0) { return m0 >= 0 && (m0 < 2 + LH || (m0 + 4 > 96 && m0 < 96 + LH)); };
+            auto slotted = [&](int m0) { return m0 >= 0 && (m0 < 2 + LH + (ACC ? 16 : 0) || (m0 + 4 > 96 && m0 < 96 + LH)); };
             ldfrag(0, 0);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -214,7 +223,7 @@ __global__ void __launch_bounds__(64 * NW, 1) k_conv_dilrow(DilArgs a) {
             }
             pending = false;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) done[r] = fmaxf(acc[r] + bv0, lo);
+            for (int r = 0; r < 16; ++r) done[r] = fmaxf(acc[r] + bv0, lo) + (ACC ? yold[r] : 0.f);
             pending = true;
             dg = g0;
             if (a.stats) {       // uniform
@@ -451,13 +460,14 @@ bool conv_dil_fwd_ok(const ConvIn& in, int N, int H, int W, int Cout, int ks, in
 int conv_dil_stat_tiles(int H) { return H; }
 
 int conv_dil_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int dil, int relu,
-                 hipStream_t st, float* stats) {
+                 hipStream_t st, float* stats, int accumulate) {
     constexpr int NW = 8, KP = 36;
     constexpr size_t lds = (size_t)(3 * (32 * NW + 1) * KP + 9 * 32 * KP + NW * 32 * 2) * sizeof(float);
     static_assert(lds <= 160 * 1024, "row slots do not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_dilrow<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_dilrow<NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_dilrow<NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             vqw_set_error("conv_dil: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
@@ -475,7 +485,8 @@ int conv_dil_fwd(const ConvIn& in, const float* w, const float* bias, float* y, 
     a.nbx = (unsigned)(P * 32 * 4);
     a.nbw = (unsigned)((long)Cout * 9 * 32 * 4);
     a.nby = (unsigned)(P * Cout * 4);
-    k_conv_dilrow<NW><<<ceil_div(a.total, a.per), 64 * NW, lds, st>>>(a);
+    if (accumulate) k_conv_dilrow<NW, true><<<ceil_div(a.total, a.per), 64 * NW, lds, st>>>(a);
+    else k_conv_dilrow<NW, false><<<ceil_div(a.total, a.per), 64 * NW, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_dil");
     return VQW_OK;
 }

@@ -10,7 +10,7 @@ extern "C" void vqw_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vqw_last_error(void) { return g_err; }
-extern "C" int vqw_abi_version(void) { return 4; }
+extern "C" int vqw_abi_version(void) { return 5; }
 
 // ---------------------------------------------------------------------------------------------
 template <int RELU>

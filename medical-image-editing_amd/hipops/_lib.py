@@ -38,6 +38,8 @@ SIGNATURES = {
     "vqw_conv3x3_up2_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_up2_fwd_stats": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_conv2d_fwd_acc_supported": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
+    "vqw_conv2d_fwd_acc": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_wino_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_wino_ws_bytes": (c_sz, [c_i, c_i]),
     "vqw_conv3x3_wino_prepare": (c_i, [c_p, c_p, c_sz, c_i, c_i, c_p]),
@@ -125,7 +127,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def load():

@@ -462,6 +462,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
         ctx.up_ws = up_ws
+        ctx.group = _grad_group_call
         ctx.save_for_backward(x0, x1, w, y if relu else None)
         ctx.cfg = (dilation, up0, ks, N, H, W, Cout, bias is not None)
         # leaf parameters get their gradient written out-of-band on the side stream (see _deferred_wgrad)
@@ -483,7 +484,7 @@ class _Conv2d(torch.autograd.Function):
         need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         defer = ctx.defer and (needw or (needb and has_bias))
         g0, g1, gw, gb, gy = conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, ctx.up_ws, need0, need1,
-                                                  needw and not defer, needb and not defer)
+                                                  needw and not defer, needb and not defer, group=ctx.group)
         if defer:
             weight, bias = ctx.params
             _deferred_wgrad(weight, bias if (has_bias and bias.requires_grad) else None, x0, x1, gy, up0, ks, dilation,
@@ -491,7 +492,7 @@ class _Conv2d(torch.autograd.Function):
         return g0, g1, gw, gb, None, None, None, None
 
 
-def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb):
+def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb, group=None):
     """Input / weight / bias gradients of conv2d on the current stream -> (g0, g1, gw, gb, masked gy).  x0 / x1 / w are the
     NHWC tensors the forward saw, y_relu its output when the ReLU was fused (the incoming gradient is masked first),
     up_ws the collapsed-weight buffer when the forward took the low-resolution form."""
@@ -517,15 +518,35 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
             return buf
         wt = _cached(w, "dgrad", _pack)
-        g_full = empty_nhwc(N, Cin, H, W, gy)
-        if ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W):
+        if group is not None and need0 and group.buf is not None:
+            # a later member of a gradient group (single full-resolution source): add into the shared buffer
+            if L.vqw_conv2d_fwd_acc_supported(Cout, N, H, W, Cin, ks, dilation):
+                _lib.check(L.vqw_conv2d_fwd_acc(_p(gy), Cout, _p(wt), _p(group.buf), N, H, W, Cin, ks, dilation, _st()),
+                           "vqw_conv2d_fwd_acc")
+                g_full = None
+            else:
+                g_full = empty_nhwc(N, Cin, H, W, gy)
+        else:
+            g_full = empty_nhwc(N, Cin, H, W, gy)
+        if g_full is None:
+            pass
+        elif ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W):
             ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
             _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(g_full), N, H, W, Cout, Cin, 0, _st()),
                        "vqw_conv3x3_wino_fwd(dgrad)")
         else:
             _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
                        "vqw_conv2d_fwd(dgrad)")
-        if not up0 and x1 is None:
+        if group is not None and need0:
+            if group.buf is None:
+                group.buf = g_full                    # first member to run: its gradient is the buffer
+            elif g_full is not None:
+                group.buf.add_(g_full)                # no accumulating kernel for this member's shape
+            group.remaining -= 1
+            g0 = group.buf if group.remaining == 0 else None
+            if g0 is not None:
+                group.buf = None
+        elif not up0 and x1 is None:
             g0 = g_full
         else:
             if need0:
@@ -543,11 +564,31 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
     return g0, g1, gw, gb, gy
 
 
-def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, want_stats=False):
+class GradGroup:
+    """Several convolutions of ONE input tensor whose input gradients are summed in place instead of by autograd
+    (aspp.py:44-47: the pyramid's five branches).  Every member's backward adds its input gradient to one shared buffer
+    and returns None for the input, except the last one to run, which returns the buffer: autograd sees a single gradient
+    and launches no add kernels (three passes over the tensor each).  All members must take part in the backward pass
+    (their outputs are all used) and run on one stream."""
+
+    def __init__(self, members):
+        self.remaining = int(members)
+        self.buf = None
+
+
+GRAD_GROUPS = os.environ.get("VQW_GRAD_GROUPS", "1") != "0"      # 0: autograd sums the branch gradients (A/B timing)
+_grad_group_call = None        # set by conv2d() for the Function it is about to apply
+
+
+def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, want_stats=False, grad_group=None):
     """'same' conv (k in {1,3}, stride 1) of the virtual input [up2x(x) | skip] (channel concat);
     relu=True fuses nn.ReLU into the epilogue.  want_stats=True returns (y, part): `part` (or None when the shape is not
     served) holds the statistics of y for the InstanceNorm that follows: instance_norm(y, ..., part=part)."""
+    global _grad_group_call
     _decide_wino_fwd()
+    _grad_group_call = grad_group if (GRAD_GROUPS and skip is None and not up2x) else None
+    if grad_group is not None and _grad_group_call is None:
+        grad_group.remaining -= 1          # this member's gradient goes through autograd: the others must not wait for it
     if want_stats and CONV_STATS:
         return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), True)
     y = _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu))

@@ -1,4 +1,5 @@
 """Atrous spatial pyramid (reference: networks/aspp.py:10-47) on the HIP kernels."""
+import torch
 import torch.nn as nn
 
 from hipops import ops
@@ -28,5 +29,8 @@ class ASPP(nn.Module):
     def forward(self, x):
         # every branch normalises straight into its channel slice of the concatenated output
         # (each conv's epilogue leaves the statistics of its branch's norm)
-        raw, parts = zip(*[stage.conv(x, want_stats=True) for stage in self.stages.children()])
+        # the five branches read one tensor: their input gradients are summed in place (ops.GradGroup), not by autograd
+        stages = list(self.stages.children())
+        grp = ops.GradGroup(len(stages)) if (torch.is_grad_enabled() and x.requires_grad) else None
+        raw, parts = zip(*[stage.conv(x, want_stats=True, grad_group=grp) for stage in stages])
         return ops.instance_norm_cat(list(raw), relu=True, eps=1e-5, parts=parts)

@@ -28,8 +28,9 @@ class Conv2d(nn.Conv2d):
         # OHWI storage (channels_last); logical shape / state_dict unchanged
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x, up2x=False, skip=None, relu=False, want_stats=False):
-        return ops.conv2d(x, self.weight, self.bias, self.dilation[0], up2x=up2x, skip=skip, relu=relu, want_stats=want_stats)
+    def forward(self, x, up2x=False, skip=None, relu=False, want_stats=False, grad_group=None):
+        return ops.conv2d(x, self.weight, self.bias, self.dilation[0], up2x=up2x, skip=skip, relu=relu, want_stats=want_stats,
+                          grad_group=grad_group)
 
 
 def conv3x3(in_channels, out_channels, stride=1, padding=1, bias=True):

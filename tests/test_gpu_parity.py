@@ -1519,6 +1519,48 @@ def test_conv_forms_agree_at_baseline_sizes(N, S, Cin, Cout, dil):
         assert_close(ops.conv2d(x, w, b, dilation=dil), r[0], 2e-6, "forward-only form")
 
 
+def test_gradient_group_sums_branch_gradients_in_place():
+    """ASPP's five branches read one tensor: with ops.GradGroup their input gradients are summed in place (the row-chain
+    kernel's accumulating form for the dilated branches) and autograd sees one gradient; same values as autograd's sum."""
+    from networks.aspp import ASPP
+    ops = _ops()
+    torch.manual_seed(5)
+    m = ASPP(32, 32, [2, 6, 12, 18]).to(DEV)
+    x = torch.randn(2, 32, 40, 64, device=DEV)
+    r = torch.randn(2, 160, 40, 64, device=DEV)
+
+    def run(groups):
+        old, ops.GRAD_GROUPS = ops.GRAD_GROUPS, groups
+        try:
+            xs = x.clone().requires_grad_(True)
+            for p_ in m.parameters():
+                p_.grad = None
+            y = m(xs)
+            (y * r).sum().backward()
+            torch.cuda.synchronize()
+            return y.detach(), xs.grad, [p_.grad.clone() for p_ in m.parameters()]
+        finally:
+            ops.GRAD_GROUPS = old
+    ya, ga, wa = run(True)
+    yb, gb, wb = run(False)
+    assert torch.equal(ya, yb)
+    assert_close(ga, gb, 1e-6, "input gradient: in-place group sum vs autograd's sum")
+    for u, v in zip(wa, wb):
+        assert torch.equal(u, v)
+    # the accumulating kernel itself: y0 + conv(x) (dilated 3x3, 32 channels)
+    L = ops._L()
+    w = (torch.randn(32, 32, 3, 3, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last)
+    for d in (2, 18):
+        assert L.vqw_conv2d_fwd_acc_supported(32, 2, 40, 64, 32, 3, d)
+        y0 = torch.randn(2, 32, 40, 64, device=DEV).contiguous(memory_format=torch.channels_last)
+        want = y0 + ops.conv2d(x, w, dilation=d)
+        got = y0.clone(memory_format=torch.channels_last)
+        from hipops import _lib
+        _lib.check(L.vqw_conv2d_fwd_acc(ops._p(ops.nhwc(x)), 32, ops._p(w), ops._p(got), 2, 40, 64, 32, 3, d, ops._st()), "acc")
+        torch.cuda.synchronize()
+        assert_close(got, want, 1e-6, "y0 + conv, dilation %d" % d)
+
+
 def test_conv_tensors_beyond_4gib_run_as_image_groups():
     """A conv whose activation tensors exceed the 32-bit buffer-descriptor range (4 GiB) is run by the library as
     consecutive image groups: forward, input gradient and (accumulated) weight gradient equal the same work done in
