@@ -333,7 +333,7 @@ extern "C" int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float*
 }
 extern "C" int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W) {
     if (g_conv_backend != 0 || !conv_wino_ok(Cin, Cout, N, H, W)) return 0;
-    return conv_wino_stat_tiles(H, W);
+    return conv_wino_stat_tiles(Cin, Cout, H, W);
 }
 extern "C" int vqw_conv3x3_wino_fwd_stats(const float* x, const void* ws, const float* bias, float* y, float* part, int N, int H,
                                           int W, int Cin, int Cout, void* stream) {

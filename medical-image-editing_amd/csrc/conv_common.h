@@ -55,7 +55,12 @@ extern int g_wino_mode;
 bool conv_wino_ok(int Cin, int Cout, int N, int H, int W);
 size_t conv_wino_ws_floats(int Cin, int Cout);
 int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st);
-int conv_wino_stat_tiles(int H, int W);
+int conv_wino_stat_tiles(int Cin, int Cout, int H, int W);
+// ... with a 64-cout workgroup tile for Cout % 64 == 0, Cin % 16 == 0 (conv_wino64.hip; same weight layout)
+bool conv_wino64_ok(int Cin, int Cout);
+int conv_wino64_stat_tiles(int H, int W);
+int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
+                    hipStream_t st, float* stats = nullptr);
 int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
                   hipStream_t st, float* stats = nullptr);
 bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W);

@@ -43,7 +43,8 @@ static const int g_wino_env = env_int("VQW_WINOGRAD", 1);
 static const int g_max_blocks = []{ int v = env_int("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
 
 // U[xi = i*4 + j][co][ci] = sum_{ky,kx} G[i][ky] g[co][ky][kx][ci] G[j][kx],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-__global__ void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin) {
+// chunked = 1: [ci / 8][xi][co][ci % 8] - what the 64-cout kernel streams: the 64 couts of a (chunk, xi) are 2 KB in a row
+__global__ void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int chunked) {
     const long n = (long)Cout * Cin;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int co = (int)(e / Cin), ci = (int)(e % Cin);
@@ -58,10 +59,12 @@ __global__ void k_wino_weights(const float* __restrict__ w, float* __restrict__ 
         }
         for (int i = 0; i < 4; ++i) {
             const double r0 = t[i][0], r1 = 0.5 * (t[i][0] + t[i][1] + t[i][2]), r2 = 0.5 * (t[i][0] - t[i][1] + t[i][2]), r3 = t[i][2];
-            u[((long)(i * 4 + 0) * Cout + co) * Cin + ci] = (float)r0;
-            u[((long)(i * 4 + 1) * Cout + co) * Cin + ci] = (float)r1;
-            u[((long)(i * 4 + 2) * Cout + co) * Cin + ci] = (float)r2;
-            u[((long)(i * 4 + 3) * Cout + co) * Cin + ci] = (float)r3;
+            const double rr[4] = {r0, r1, r2, r3};
+            for (int j = 0; j < 4; ++j) {
+                const long xi = i * 4 + j;
+                const long at = chunked ? ((((long)(ci >> 3) * 16 + xi) * Cout + co) * 8 + (ci & 7)) : ((xi * Cout + co) * Cin + ci);
+                u[at] = (float)rr[j];
+            }
         }
     }
 }
@@ -331,12 +334,17 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
         };
         auto slot = [&](int p) {       // p = 0..63: MFMA position (compile-time after unrolling)
             // loads (address arithmetic included) behind the first MFMAs: halo of item i+2, U chunk of item i+1
+#ifndef WN_EXP_NO_LOADS
             if (p == 0) issue_setup(n2, tx2, ty2, ch2);
             if (p >= 1 && p < 1 + LH) issue_h(p - 1);
             if (p == 1 + LH) i_cc4 = (unsigned)(ch1 * WN_KC) * 4u;
             if (p >= 2 + LH && p < 2 + LH + LW) issue_u(p - 2 - LH);
             if (p >= WN_CP && p < WN_CP + LH) commit_h(p - WN_CP, hC);
             if (p >= WN_CP + 4 && p < WN_CP + 4 + LW) commit_u(p - WN_CP - 4, ucur ^ 1);
+#endif
+#ifdef WN_EXP_NO_XFORM
+            if (true) return;
+#endif
             if (p == 29) read_col(hB, 0);
             if (p >= 32 && p < 48) {   // column pass: column c = (p - 32) / 4, two operations per position
                 const int c = (p - 32) >> 2, k = ((p - 32) & 3) * 2;
@@ -356,7 +364,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             const int s = xi % 3;
+#ifndef WN_EXP_NO_BREAD
             if (xi + 2 < 16) ldb(xi + 2, (xi + 2) % 3);
+#else
+            if (xi == 0) ldb(2, 2);
+#endif
             acc[xi][0] = MFMA16(v[par][0][xi], bf[s][0].x, first ? zero4 : acc[xi][0]);
             slot(4 * xi); __builtin_amdgcn_sched_barrier(0);
             acc[xi][1] = MFMA16(v[par][0][xi], bf[s][1].x, first ? zero4 : acc[xi][1]);
@@ -367,7 +379,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
             slot(4 * xi + 3); __builtin_amdgcn_sched_barrier(0);
         }
 
+#ifdef WN_EXP_NO_EPI
+        if (ch == nch - 1 && acc[3][1][2] == 123.456f) {
+#else
         if (ch == nch - 1) {
+#endif
             // Y = A^T M A per (tile, cout) entry: lane-local over the 16 xi; then bias / ReLU, statistics, stores
             // C/D rows of a lane = tiles 4 q + r: RW = 32: tile row wv, columns 4 q + r; RW = 16: tile row 2 wv + (q >> 1),
             // columns 4 (q & 1) + r
@@ -425,7 +441,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
         cn = n1; ctx = tx1; cty = ty1; ch = ch1;
         n1 = n2; tx1 = tx2; ty1 = ty2; ch1 = ch2;
         advance(n2, tx2, ty2, ch2);
+#ifndef WN_EXP_NO_BARRIER
         __syncthreads();               // publishes the halo of item i+2 and the U chunk of item i+1
+#endif
         const int t = hA; hA = hB; hB = hC; hC = t;
         ucur ^= 1;
         fold_stats();
@@ -450,11 +468,12 @@ bool conv_wino_ok(int Cin, int Cout, int N, int H, int W) {
 size_t conv_wino_ws_floats(int Cin, int Cout) { return (size_t)16 * Cout * Cin; }
 int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st) {
     const long n = (long)Cout * Cin;
-    k_wino_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, u, Cout, Cin);
+    k_wino_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, u, Cout, Cin, conv_wino64_ok(Cin, Cout) ? 1 : 0);
     VQW_LAUNCH_CHECK("wino_weights");
     return VQW_OK;
 }
-int conv_wino_stat_tiles(int H, int W) {
+int conv_wino_stat_tiles(int Cin, int Cout, int H, int W) {
+    if (conv_wino64_ok(Cin, Cout)) return conv_wino64_stat_tiles(H, W);
     const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? 16 : 32;
     return H % tr == 0 ? (H / tr) * (W / rw) : 0;
 }
@@ -465,7 +484,7 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
         const long per_image = (long)H * W * (Cin > Cout ? Cin : Cout) * 4;
         const long g = 0xFFFFFFE0L / per_image;
         if (g < N) {
-            const int parts = stats ? conv_wino_stat_tiles(H, W) : 0;
+            const int parts = stats ? conv_wino_stat_tiles(Cin, Cout, H, W) : 0;
             for (int n0 = 0; n0 < N; n0 += (int)g) {
                 const int nn = N - n0 < g ? N - n0 : (int)g;
                 const size_t px = (size_t)n0 * H * W;
@@ -476,6 +495,7 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
             return VQW_OK;
         }
     }
+    if (conv_wino64_ok(Cin, Cout)) return conv_wino64_fwd(x, u, bias, y, N, H, W, Cin, Cout, relu, st, stats);
     const bool wide = W % 32 == 0;
     const size_t lds = (size_t)(3 * (wide ? WinoGeo<32>::HBUF : WinoGeo<16>::HBUF) + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
     static_assert((size_t)(3 * WinoGeo<16>::HBUF + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float) <= 160 * 1024, "Winograd buffers do not fit the 160 KB LDS");

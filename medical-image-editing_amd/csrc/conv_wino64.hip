@@ -1,0 +1,500 @@
+// Winograd F(2x2, 3x3) forward / dgrad for layers with Cout % 64 == 0, Cin % 16 == 0: the 64-cout workgroup tile.
+//
+// Why a second kernel.  Beside fp32 MFMAs every VALU instruction is ADDITIVE (profiles/r03_mfma_valu_microbench.txt:
+// v_mfma_f32_16x16x4_f32 runs on the SIMD's fp32 lanes; one v_add / v_mov / integer add costs 4.4-5 matrix-pipe cycles at
+// two waves per SIMD, 9-10 at one, a v_pk_* 10-15, VCC / SGPR-operand forms 6-7; LDS reads and writes, SALU and s_nop cost
+// nothing).  k_conv_wino (conv_wino.hip) issues ~115 VALU per 64 MFMAs (64 for the input transform, ~45 for the prefetch
+// addresses): 2048 / (2048 + 115 * 4.4 + barrier) = the 0.64 matrix-pipe occupancy its counters show.  This kernel is built
+// to issue as few VALU instructions as the algorithm allows:
+//
+//   * workgroup = 64 Winograd tiles (8 x 32 or 16 x 16 output pixels) x 64 couts; wave (mb, h) = tiles of M block mb (16
+//     tiles), HALF of the 16 transform positions (xi rows 2h, 2h+1) and all 64 couts: 8 xi x 4 N blocks x 4 = 128
+//     accumulator registers, 64 MFMAs per 8-channel chunk like before - but the input transform of a wave is 32 add / sub
+//     (two of the four rows of B^T d B) instead of 64, and it is shared by 64 couts instead of 32: a quarter of the
+//     transform VALU per MFMA of the 32-cout kernel.
+//   * no address arithmetic in the loop: a halo slot's byte offset is computed once per REGION (with the padding / edge
+//     select folded in: an invalid lane holds an out-of-range offset, the buffer load returns 0), the channel chunk is
+//     the load's scalar offset (soffset: not part of the range check), the U slots differ by scalar offsets only; LDS
+//     addresses are per-lane bases plus immediates because everything that alternates (halo buffer, U buffer, operand
+//     set) follows the item's parity, which is a template parameter of the item body.
+//   * the accumulators of a region's first chunk start from the MFMA's inline 0 (a body variant), not from 128 v_mov.
+//   * region epilogue: each wave applies A^T . A to its half of the xi (linear: y = y_h0 + y_h1), the halves meet through
+//     LDS (a wave finalises two of the four N blocks and sends the other two to its partner), then bias / ReLU /
+//     statistics partials / stores as in the 32-cout kernel.
+//
+// Halo ring: two buffers suffice - the patch of item i+1 is read (and transformed) during item i, so the buffer of
+// item i is dead from the barrier that ends item i-1 and receives the halo of item i+2 during item i.
+#include "common.h"
+#include "conv_common.h"
+#include "mfma_util.h"
+#include <cstdlib>
+#include <type_traits>
+
+extern int g_wino_mode;
+
+namespace {
+
+static int env_int64(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static const int g_w64_env = env_int64("VQW_WINOGRAD64", 1);
+static const int g_w64_max_blocks = []{ int v = env_int64("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct W64Args {
+    const float* x;
+    const float* u;            // [Cin / 8][16 xi][Cout][8] (k_wino_weights, chunked)
+    const float* bias;
+    float* y;
+    int N, H, W, Cin, Cout;
+    int tilesY, tilesX, nsp;   // regions per image column / row, total
+    int ntn, nch;              // 64-cout tiles, 8-channel chunks (even)
+    int kt;                    // consecutive regions per workgroup
+    int relu;
+    unsigned nbx, nbu, nby;
+    float* stats;              // optional [N][tilesY*tilesX][Cout][2]: per-region (sum, M2 about the region mean)
+};
+
+constexpr int W6_KPH = 10;                 // floats per halo pixel in LDS (8 channels + 2: conflict-free ds_read_b64 patches)
+constexpr int W6_UBUF = 16 * 64 * 8;       // floats per U chunk: [xi][64 couts][8 channels], float4 halves swizzled by cout bit 3
+// Region geometry, RW = region width: 8 rows x 32 columns (halo 10 x 34), or - for maps whose width is a multiple of 16 only
+// (the 16 x 16 level) - 16 x 16 (halo 18 x 18, LDS row stride 24 pixels: the two tile rows of an M block then land on
+// complementary banks).  64 tiles per region either way.
+template <int RW> struct W64Geo {
+    static constexpr int TR = RW == 32 ? 8 : 16;
+    static constexpr int HR = TR + 2, HWV = RW + 2;
+    static constexpr int HWS = RW == 32 ? 34 : 24;
+    static constexpr int HBUF = HR * HWS * W6_KPH;
+};
+#ifdef W6_EXP_NO_BARRIER
+#define W6_ITEM_BARRIER() do {} while (0)
+#else
+#define W6_ITEM_BARRIER() __syncthreads()
+#endif
+#ifndef W6_LS
+#define W6_LS 2                            // MFMA positions between two prefetch loads (a burst of 48 wave-loads stalls their issue)
+#endif
+#ifndef W6_BD
+#define W6_BD 1                            // how many xi ahead of their MFMAs the B fragments are read
+#endif
+constexpr int W6_CP = 26;                  // MFMA position of the first LDS commit of the prefetched data
+
+template <int RW>
+__global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
+    using G = W64Geo<RW>;
+    constexpr int NT = 512;
+    constexpr int HWS = G::HWS, HWV = G::HWV, HBUF = G::HBUF, UBUF = W6_UBUF;
+    constexpr int HPIX = G::HR * HWV;          // 340 / 324 halo pixels
+    constexpr int HF = HPIX * 2;               // float4 per halo chunk: 680 / 648
+    static_assert(HF > NT && HF <= 2 * NT, "two halo slots per thread");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                      // [2][HBUF]
+    float* Us = smem + 2 * HBUF;           // [2][UBUF]
+    float* Ex = Us + UBUF;                 // exchange area of the region epilogue: U buffer 1 (dead by then) + 32 KB
+    float* Rs = Us + 3 * UBUF;             // [2][4 M blocks][64 couts][2] statistics of the waves' 64 pixels
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: scalar branches on h
+    const int mb = wv & 3, h = wv >> 2;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
+
+    const int ntn = a.ntn, nch = a.nch;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % ntn;
+    const int sp0 = (lb / ntn) * a.kt;
+    const int co_base = tile_n * 64;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int nitems = my_tiles * nch;
+    const int per_img = a.tilesY * a.tilesX;
+    if (nitems <= 0) return;               // uniform per workgroup
+
+    // ---- loader slots (fixed per thread) ----
+    // halo float4 f -> halo pixel f / 2, channel quad f % 2; slot 1 of the threads past the end repeats another thread's
+    // slot 0 (same address, same data: a benign duplicate instead of a masked store)
+    int h_lds[2];
+    int h_yx;                              // (hy0, hx0, hy1, hx1) packed in bytes
+    const int c4 = tid & 1;
+    {
+        int pk = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int f = tid + j * NT;
+            if (f >= HF) f -= HF;
+            const int hp = f >> 1, hy = hp / HWV, hx = hp - hy * HWV;
+            h_lds[j] = (hy * HWS + hx) * W6_KPH + c4 * 4;
+            pk |= (hy | (hx << 8)) << (16 * j);
+        }
+        h_yx = pk;
+    }
+    unsigned h_voff[2];                    // byte offsets of the two slots in the region whose halo is fetched next
+    auto region_offsets = [&](int n, int tx, int ty) {
+        const int y0 = ty * G::TR - 1, x0 = tx * RW - 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int hy = (h_yx >> (16 * j)) & 0xff, hx = (h_yx >> (16 * j + 8)) & 0xff;
+            const int yy = y0 + hy, xx = x0 + hx;
+            const bool ok = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+            const unsigned pix = ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
+            h_voff[j] = sel_u32(ok, pix * (unsigned)Cin * 4u + (unsigned)c4 * 16u, 0xFFFFFFFFu);
+        }
+    };
+    // U float4 f = tid + 512 j -> row = xi * 64 + n = (tid >> 1) + 256 j, channel quad tid & 1
+    const int u_n = (tid >> 1) & 63;
+    // (a wave's slot = 32 couts x 32 bytes = 1 KB in a row of the chunked layout)
+    const unsigned u_voff = (((unsigned)(tid >> 7) * Cout + co_base + u_n) * 8u + c4 * 4) * 4u;
+    const unsigned u_jstride = 4u * Cout * 32u;                            // 4 xi further per slot
+    const unsigned u_cstride = 16u * Cout * 32u;                           // per 8-channel chunk
+    const int u_lds = (tid >> 1) * 8 + ((c4 ^ ((u_n >> 3) & 1)) * 4);      // + j * 2048 floats
+
+    float4 rh[2], ru[4];
+    auto issue_h = [&](int j, int chunk) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)h_voff[j], chunk * 32, 0);
+        unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        rh[j].x = __uint_as_float(a0); rh[j].y = __uint_as_float(a1); rh[j].z = __uint_as_float(a2); rh[j].w = __uint_as_float(a3);
+    };
+    auto issue_u = [&](int j, int chunk) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsu, (int)u_voff, (int)(chunk * u_cstride + j * u_jstride), 0);
+        unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        ru[j].x = __uint_as_float(a0); ru[j].y = __uint_as_float(a1); ru[j].z = __uint_as_float(a2); ru[j].w = __uint_as_float(a3);
+    };
+    auto commit_h = [&](int j, float* Hb) {    // a halo pixel is 40 bytes: two 8-byte-aligned halves
+        float* p = Hb + h_lds[j];
+        f32x2 lo, hi;
+        lo.x = rh[j].x; lo.y = rh[j].y; hi.x = rh[j].z; hi.y = rh[j].w;
+        *(f32x2*)p = lo;
+        *(f32x2*)(p + 2) = hi;
+    };
+    auto commit_u = [&](int j, float* Ub) { *(float4*)&Ub[u_lds + j * 2048] = ru[j]; };
+
+    // ---- item cursors: (image, strip, region row, chunk) of items i, i+1, i+2 ----
+    int cn, ctx, cty, ch = 0;
+    {
+        cn = sp0 / per_img;
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    auto advance = [&](int& n, int& tx, int& ty, int& c) {     // the item after (n, tx, ty, c)
+        const int adv = c + 1 == nch ? 1 : 0;
+        c = adv ? 0 : c + 1;
+        const int ty1 = ty + adv, wy = ty1 == a.tilesY ? 1 : 0;
+        ty = wy ? 0 : ty1;
+        const int tx1 = tx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        tx = wx ? 0 : tx1;
+        n += wx;
+    };
+    int n1 = cn, tx1 = ctx, ty1 = cty, ch1 = 0;
+    advance(n1, tx1, ty1, ch1);
+    int n2 = n1, tx2 = tx1, ty2 = ty1, ch2 = ch1;
+    advance(n2, tx2, ty2, ch2);
+
+    // ---- fragment bases: lane (tile m = lane & 15, channel pair q = lane >> 4) ----
+    const int m = lane & 15, q = lane >> 4;
+    // rows of the 4 x 4 patch this wave needs, as (A, B, C): h = 0: (0, 1, 2) -> e0 = A - C, e1 = B + C;
+    // h = 1: (3, 2, 1) -> A - C = -(e3), B - C = e2.  One formula pair with sg = +1 / -1: eP = A - C, eQ = B + sg * C
+    // (sg * C is exact, so the fma rounds once like the add / sub it stands for); xi row 3 arrives negated, which the
+    // epilogue's h = 1 branch folds into its signs.
+    const int rA = h ? 3 : 0, rB = h ? 2 : 1, rC = h ? 1 : 2;
+    const int prow = RW == 32 ? 2 * mb : 2 * (2 * mb + (m >> 3)), pcol = RW == 32 ? 2 * m : 2 * (m & 7);
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };     // distinct base registers: no ds_read2 merging
+    const int a_A = opaque(((prow + rA) * HWS + pcol) * W6_KPH + 2 * q);
+    const int a_B = opaque(((prow + rB) * HWS + pcol) * W6_KPH + 2 * q);
+    const int a_C = opaque(((prow + rC) * HWS + pcol) * W6_KPH + 2 * q);
+    // local xi row 0 = eP: xi row (h ? 3 : 0); local row 1 = eQ: xi row (h ? 2 : 1)
+    const int b_swz = ((q >> 1) ^ (m >> 3)) * 4 + (q & 1) * 2;
+    const int b_0 = opaque(((h ? 3 : 0) * 4 * 64 + m) * 8 + b_swz);        // + (cc * 64 + nb * 16) * 8
+    const int b_1 = opaque(((h ? 2 : 1) * 4 * 64 + m) * 8 + b_swz);
+    // sg, mone live in VGPRs the compiler cannot see through: an SGPR operand costs 1.5 x, and a literal -1 would turn the
+    // fma back into a subtraction that the vector combiner pairs into v_pk_add_f32 over the two channels of a ds_read_b64
+    // (10-15 pipe cycles instead of 2 x 4.4)
+    float sg, mone;
+    { float s = h ? -1.f : 1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(sg) : "v"(s)); }
+    { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
+
+    f32x4 acc[8][4];
+    f32x2 dcol[2][3];                  // two patch columns in flight: rows A, B, C
+    float e[2][2][4];                  // [channel of the pair][local row][column] after the column pass
+    float v[2][2][8];                  // [parity of the item][channel of the pair][local xi = local row * 4 + column]
+
+    auto read_col = [&](const float* Hb, int c) {
+        const float* Hc = Hb + c * W6_KPH;
+        dcol[c & 1][0] = *(const f32x2*)&Hc[a_A];
+        dcol[c & 1][1] = *(const f32x2*)&Hc[a_B];
+        dcol[c & 1][2] = *(const f32x2*)&Hc[a_C];
+    };
+    auto col_op = [&](int c, int k) {          // k = 0..3: channel k >> 1, local row k & 1
+        const int t = k >> 1;
+        const float dA = dcol[c & 1][0][t], dB = dcol[c & 1][1][t], dC = dcol[c & 1][2][t];
+        if ((k & 1) == 0) e[t][0][c] = __builtin_fmaf(mone, dC, dA);
+        else e[t][1][c] = __builtin_fmaf(sg, dC, dB);
+    };
+    auto row_op = [&](int par, int k) {        // k = 0..15: local row k >> 3, channel (k >> 2) & 1, column k & 3
+        const int lr = k >> 3, t = (k >> 2) & 1, cc = k & 3;
+        const float e0 = e[t][lr][0], e1 = e[t][lr][1], e2 = e[t][lr][2], e3 = e[t][lr][3];
+        v[par][t][lr * 4 + cc] = cc == 0 ? e0 - e2 : cc == 1 ? e1 + e2 : cc == 2 ? e2 - e1 : e1 - e3;
+    };
+
+    // ---- prologue: halo of items 0 and 1, U chunk of item 0, operands of item 0 ----
+    region_offsets(cn, ctx, cty);
+    issue_h(0, 0); issue_h(1, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_u(j, 0);
+    commit_h(0, Hs); commit_h(1, Hs);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) commit_u(j, Us);
+    region_offsets(n1, tx1, ty1);
+    issue_h(0, ch1); issue_h(1, ch1);
+    commit_h(0, Hs + HBUF); commit_h(1, Hs + HBUF);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        read_col(Hs, c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) col_op(c, k);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) row_op(0, k);
+    __syncthreads();                   // halo buffer 0 is overwritten during item 0
+    region_offsets(n2, tx2, ty2);
+
+    float bvv[2];                      // bias of the two N blocks this wave finalises: nb = 2 h, 2 h + 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bvv[i] = a.bias ? a.bias[co_base + (2 * h + i) * 16 + m] : 0.f;
+    const float lo = a.relu ? 0.f : -__builtin_inff();
+    int spar = 0;
+
+    // One item; PAR = its parity: operands v[PAR], halo of the NEXT item in buffer PAR ^ 1, U chunk in buffer PAR; the halo of
+    // item i+2 goes to halo buffer PAR, the U chunk of item i+1 to U buffer PAR ^ 1.  FIRST: first chunk of a region.
+    auto body = [&](auto PAR, auto FIRST) {
+        constexpr int par = decltype(PAR)::value;
+        constexpr bool first = decltype(FIRST)::value;
+        const float* Uc = Us + par * UBUF;
+        const float* Hn = Hs + (par ^ 1) * HBUF;
+        float* Hw = Hs + par * HBUF;
+        float* Uw = Us + (par ^ 1) * UBUF;
+        f32x2 bf[W6_BD + 1][4];        // B fragments run W6_BD xi ahead of the MFMAs that consume them
+        auto ldb = [&](int l, int nb) {
+            bf[l % (W6_BD + 1)][nb] = *(const f32x2*)&Uc[(l < 4 ? b_0 : b_1) + ((l & 3) * 64 + nb * 16) * 8];
+        };
+        auto slot = [&](int p) {       // p = 0..63: MFMA position (compile-time after unrolling)
+#if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_HLOADS)      // timing-only A/B builds (tools/wino_ab.sh): wrong results
+            if (p >= 1 && p < 1 + 2 * W6_LS && (p - 1) % W6_LS == 0) issue_h((p - 1) / W6_LS, ch2);
+            if (p >= W6_CP && p < W6_CP + 2) commit_h(p - W6_CP, Hw);
+#endif
+#if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_ULOADS)
+            if (p >= 1 + 2 * W6_LS && p < 1 + 6 * W6_LS && (p - 1) % W6_LS == 0) issue_u((p - 1) / W6_LS - 2, ch1);
+            if (p >= W6_CP + 2 && p < W6_CP + 6) commit_u(p - W6_CP - 2, Uw);
+#endif
+#ifdef W6_EXP_NO_XFORM
+            if (true) return;
+#endif
+            if (p == 29) read_col(Hn, 0);
+            if (p >= 32 && p < 48) {   // column pass: column (p - 32) / 4, one operation per position
+                const int c = (p - 32) >> 2, k = (p - 32) & 3;
+                if (k == 0 && c < 3) read_col(Hn, c + 1);
+                col_op(c, k);
+            }
+            if (p >= 48) row_op(par ^ 1, p - 48);
+        };
+#pragma unroll
+        for (int l = 0; l < W6_BD; ++l)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) { ldb(l, nb); __builtin_amdgcn_sched_barrier(0); }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const int s = l % (W6_BD + 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+#ifndef W6_EXP_NO_BREAD
+                    if (k == 0 && l + W6_BD < 8) ldb(l + W6_BD, nb);
+#endif
+                    acc[l][nb] = MFMA16(v[par][k][l], k == 0 ? bf[s][nb].x : bf[s][nb].y, (first && k == 0) ? zero4 : acc[l][nb]);
+                    slot(l * 8 + k * 4 + nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+    };
+
+    // Region epilogue of a wave (HH = its xi half): partial y = A^T M_h A over the wave's two xi rows for every (tile, cout)
+    // entry it holds; N blocks 2 HH, 2 HH + 1 are finalised here, the other two go to the partner wave (same mb, other h).
+    // C/D layout (16x16): col = lane & 15 (cout), row = 4 (lane >> 4) + r (tile of the M block).
+    auto partial = [&](auto HH, int nb, int r, float* yv) {       // yv[a * 2 + b]
+        constexpr int hh = decltype(HH)::value;
+        float p0[4], p1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float l0 = acc[j][nb][r], l1 = acc[4 + j][nb][r];
+            if (hh == 0) { p0[j] = l0 + l1; p1[j] = l1; }          // local rows = m0, m1:   m0 + m1 | m1
+            else { p0[j] = l1; p1[j] = l0 - l1; }                  // local rows = -m3, m2:  m2 | -m2 - m3
+        }
+        yv[0] = (p0[0] + p0[1]) + p0[2];
+        yv[1] = (p0[1] - p0[2]) - p0[3];
+        yv[2] = (p1[0] + p1[1]) + p1[2];
+        yv[3] = (p1[1] - p1[2]) - p1[3];
+    };
+    // 1. the partner's two N blocks -> exchange area [(mb, destination h)][k = 0..7][lane] float4
+    auto epi_send = [&](auto HH) {
+        constexpr int hh = decltype(HH)::value;
+        float* Xo = Ex + (((mb * 2 + (hh ^ 1)) * 8) * 64 + lane) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float yv[4];
+                partial(HH, hh == 0 ? 2 + i : i, r, yv);
+                float4 o;
+                o.x = yv[0]; o.y = yv[1]; o.z = yv[2]; o.w = yv[3];
+                *(float4*)&Xo[(i * 4 + r) * 256] = o;
+            }
+    };
+    // 2. own two N blocks: own partial + the partner's, bias / ReLU, statistics, stores
+    auto epi_finish = [&](auto HH) {
+        constexpr int hh = decltype(HH)::value;
+        const float* Xi = Ex + (((mb * 2 + hh) * 8) * 64 + lane) * 4;
+        // tiles 4 q + r of M block mb: RW = 32: tile row mb, columns 4 q + r; RW = 16: tile row 2 mb + (q >> 1), columns 4 (q & 1) + r
+        const int yrow0 = cty * G::TR + (RW == 32 ? 2 * mb : 2 * (2 * mb + (q >> 1)));
+        const int xcol0 = ctx * RW + (RW == 32 ? 8 * q : 8 * (q & 1));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float yv[16];      // [r][a][b]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float own[4];
+                partial(HH, 2 * hh + i, r, own);
+                const float4 o = *(const float4*)&Xi[(i * 4 + r) * 256];
+                yv[r * 4 + 0] = fmaxf((own[0] + o.x) + bvv[i], lo);
+                yv[r * 4 + 1] = fmaxf((own[1] + o.y) + bvv[i], lo);
+                yv[r * 4 + 2] = fmaxf((own[2] + o.z) + bvv[i], lo);
+                yv[r * 4 + 3] = fmaxf((own[3] + o.w) + bvv[i], lo);
+            }
+            const unsigned co = (unsigned)(co_base + (2 * hh + i) * 16 + m);
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const int yy = yrow0 + aa;
+                const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cout + co;
+                const int voff = (int)sel_u32(yy < H, base * 4u, 0xFFFFFFFFu);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+            }
+            if (a.stats) {     // uniform: H % TR == 0 whenever statistics are requested
+                float t1, t2;
+                lane_stats<16>(yv, t1, t2);
+                stat_merge_eq(t1, t2, __shfl_xor(t1, 16, 64), __shfl_xor(t2, 16, 64), 1.f / 32.f);
+                stat_merge_eq(t1, t2, __shfl_xor(t1, 32, 64), __shfl_xor(t2, 32, 64), 1.f / 64.f);
+                if (lane < 16) {
+                    float* R = Rs + spar * (4 * 64 * 2) + (mb * 64 + (2 * hh + i) * 16 + lane) * 2;
+                    R[0] = t1;
+                    R[1] = t2;
+                }
+            }
+        }
+    };
+    auto fold_stats = [&]() {          // after the barrier that follows epi_finish
+        if (!a.stats) return;          // uniform
+        if (tid < 64) {
+            const float* R = Rs + spar * (4 * 64 * 2) + tid * 2;
+            float s1 = R[0], s2 = R[1];              // M blocks of 64 pixels, merged in order
+#pragma unroll
+            for (int r = 1; r < 4; ++r) stat_merge(s1, s2, (float)(64 * r), R[r * 128], R[r * 128 + 1], 64.f);
+            const int t = (cn * a.tilesX + ctx) * a.tilesY + cty;
+            float* o = a.stats + ((size_t)t * Cout + co_base + tid) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+        spar ^= 1;
+    };
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto shift = [&]() {               // item i+1 becomes the current item
+        cn = n1; ctx = tx1; cty = ty1; ch = ch1;
+        n1 = n2; tx1 = tx2; ty1 = ty2; ch1 = ch2;
+        advance(n2, tx2, ty2, ch2);
+    };
+    // nch is even: a region is nch / 2 (even, odd) item pairs; the first pair starts the accumulators from the MFMA's inline 0.
+    // (Explicit region / pair loops rather than one item loop with an `if (first)` diamond: with 128 accumulators live the
+    // diamond's PHIs cost register copies and spills.)  Every branch is uniform per workgroup.
+    for (int reg = 0; reg < my_tiles; ++reg) {
+        body(P0{}, std::true_type{});
+        W6_ITEM_BARRIER();             // publishes the halo of item i+2 and the U chunk of item i+1
+        shift();
+        body(P1{}, std::false_type{});
+        W6_ITEM_BARRIER();
+        for (int c = 2; c < nch; c += 2) {
+            shift();
+            if (ch2 == 0) region_offsets(n2, tx2, ty2);   // item i+2 opens a region: its halo offsets
+            body(P0{}, std::false_type{});
+            W6_ITEM_BARRIER();
+            shift();
+            body(P1{}, std::false_type{});
+            W6_ITEM_BARRIER();
+        }
+        // region (cn, ctx, cty) is complete
+#ifdef W6_EXP_NO_EPI
+        if (acc[3][1][2] == 123.456f)
+#endif
+        {
+        if (h == 0) epi_send(P0{}); else epi_send(P1{});
+        __syncthreads();
+        if (h == 0) epi_finish(P0{}); else epi_finish(P1{});
+        __syncthreads();               // the exchange area is U buffer 1 again from the next item on
+        fold_stats();
+        }
+        shift();
+        if (ch2 == 0) region_offsets(n2, tx2, ty2);       // item i+2 opens a region: its halo offsets
+    }
+}
+
+}  // namespace
+
+// the 64-cout kernel serves a layer whenever its channel counts allow (k_wino_weights then writes the chunked layout)
+bool conv_wino64_ok(int Cin, int Cout) { return g_w64_env != 0 && Cin % 16 == 0 && Cout % 64 == 0; }
+int conv_wino64_stat_tiles(int H, int W) {
+    const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? 8 : 16;
+    return H % tr == 0 ? (H / tr) * (W / rw) : 0;
+}
+
+int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
+                    hipStream_t st, float* stats) {
+    const bool wide = W % 32 == 0;
+    const size_t lds = (size_t)(2 * (wide ? W64Geo<32>::HBUF : W64Geo<16>::HBUF) + 3 * W6_UBUF + 2 * 4 * 64 * 2) * sizeof(float);
+    static_assert((size_t)(2 * W64Geo<16>::HBUF + 3 * W6_UBUF + 2 * 4 * 64 * 2) * sizeof(float) <= 160 * 1024, "buffers do not fit the 160 KB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino64<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_wino64<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            vqw_set_error("conv_wino64: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    W64Args a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = ceil_div(H, wide ? 8 : 16); a.tilesX = W / (wide ? 32 : 16); a.nsp = N * a.tilesY * a.tilesX;
+    a.ntn = Cout / 64; a.nch = Cin / 8;
+    a.relu = relu;
+    a.stats = stats;
+    const long P = (long)N * H * W;
+    a.nbx = (unsigned)(P * Cin * 4);
+    a.nbu = (unsigned)(16L * Cout * Cin * 4);
+    a.nby = (unsigned)(P * Cout * 4);
+    int groups = g_w64_max_blocks / a.ntn;
+    if (groups < 1) groups = 1;
+    const int even = ceil_div(a.nsp, groups);
+    a.kt = even < 1 ? 1 : even;
+    if (wide) k_conv_wino64<32><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    else k_conv_wino64<16><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino64");
+    return VQW_OK;
+}

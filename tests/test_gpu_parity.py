@@ -62,6 +62,14 @@ CONV_CASES = [
     (2, 16, 32, 16, 0, False, 32, 3, 1, False, False),
     (3, 12, 32, 48, 0, False, 80, 3, 1, True, False),
     (1, 16, 64, 16, 0, False, 48, 3, 1, True, True),
+    # 64-cout Winograd kernel (conv_wino64.hip: Cout % 64 == 0, Cin % 16 == 0; forward under the winograd_forward fixture,
+    # input gradient of the mirrored channel counts always): both region shapes, ragged H, several regions per workgroup,
+    # two cout tiles, the shortest legal channel walk (two chunks)
+    (2, 48, 64, 64, 0, False, 128, 3, 1, True, True),
+    (3, 16, 16, 64, 0, False, 64, 3, 1, True, False),
+    (1, 20, 16, 128, 0, False, 64, 3, 1, True, False),
+    (1, 256, 320, 16, 0, False, 64, 3, 1, True, False),
+    (2, 22, 32, 64, 0, False, 16, 3, 1, False, False),     # its input gradient: 16 -> 64
     # 16-cout layers on the 16x16x4 MFMA path of the halo kernel (16 x 32 pixel tiles, ragged H, two sources)
     (2, 32, 32, 16, 0, False, 16, 3, 1, True, True),
     (1, 40, 64, 48, 0, False, 16, 3, 1, True, False),
@@ -295,6 +303,9 @@ STATS_CASES = [
     (2, 48, 64, 24, 0, False, 96),     # Winograd form: three regions per strip, three cout tiles
     (1, 16, 32, 128, 0, False, 48),    # Winograd form: 16 chunks, partial cout tile
     (2, 32, 16, 64, 0, False, 64),     # Winograd form on a 16-wide map (32 x 16 regions); direct form: no statistics
+    (2, 24, 64, 32, 0, False, 128),    # 64-cout Winograd kernel: 8 x 32 regions, two cout tiles
+    (3, 16, 16, 64, 0, False, 64),     # ... 16 x 16 regions (one per image)
+    (1, 64, 96, 16, 0, False, 64),     # ... two chunks, 24 regions
     (2, 32, 32, 32, 16, True, 16),     # up-sampled + concat source, 16 couts
     (1, 32, 64, 64, 32, True, 32),     # two sources, 32 couts
 ]
