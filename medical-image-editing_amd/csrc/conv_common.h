@@ -64,7 +64,11 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
 int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
                   hipStream_t st, float* stats = nullptr);
 bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W);
-int conv_wino_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
+int conv_wino_wgrad_blocks(const ConvIn& in, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
+bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);
+int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
+int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+                      hipStream_t st);
 int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st);
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)

@@ -1176,7 +1176,7 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
         const long nout = (long)Cout * 9 * Cin;
         *bias_done = dbias != nullptr;
         int kt = 1;
-        const int nsbw = conv_wino_wgrad_blocks(Cin, Cout, N, H, W, wg9_split_blocks(Cin, Cout, (long)N * H * W), &kt);
+        const int nsbw = conv_wino_wgrad_blocks(in, Cout, N, H, W, wg9_split_blocks(Cin, Cout, (long)N * H * W), &kt);
         float* bp = dbias ? ws + (size_t)nsbw * nout : nullptr;
         int rc = conv_wino_wgrad(in, dy, ws, bp, N, H, W, Cout, nsbw, kt, st);
         if (rc) return rc;

@@ -798,7 +798,9 @@ bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W) {
     return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
 }
 // slabs for a given upper bound
-int conv_wino_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
+int conv_wino_wgrad_blocks(const ConvIn& in, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
+    const int Cin = in.C0 + in.C1;
+    if (conv_wino64_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino64_wgrad_blocks(Cin, Cout, N, H, W, max_slabs, kt_out);
     const int nblk = (Cout / 32) * (Cin / 16);
     const int rw = W % 32 == 0 ? 32 : 16;
     const int nsp = N * ceil_div(H, 256 / rw) * (W / rw);
@@ -813,6 +815,7 @@ int conv_wino_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs
 int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st) {
     const int Cin = in.C0 + in.C1;
+    if (conv_wino64_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino64_wgrad(in.src0, dy, ws, bpart, N, H, W, Cin, Cout, nsb, kt, st);
     constexpr size_t lds = (size_t)(2 * (WW_D + WW_X) + 512 * 4) * sizeof(float);
     static_assert(lds <= 160 * 1024 && lds >= 8 * 512 * sizeof(float), "Winograd wgrad tiles do not fit the LDS");
     static bool attr_set = false;

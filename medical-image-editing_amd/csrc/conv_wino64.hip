@@ -76,9 +76,6 @@ template <int RW> struct W64Geo {
 #ifndef W6_LS
 #define W6_LS 2                            // MFMA positions between two prefetch loads (a burst of 48 wave-loads stalls their issue)
 #endif
-#ifndef W6_BD
-#define W6_BD 1                            // how many xi ahead of their MFMAs the B fragments are read
-#endif
 constexpr int W6_CP = 26;                  // MFMA position of the first LDS commit of the prefetched data
 
 template <int RW>
@@ -99,6 +96,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: scalar branches on h
     const int mb = wv & 3, h = wv >> 2;
+#if defined(W6_PRIO) && W6_PRIO == 1
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(W6_PRIO) && W6_PRIO == 2
+    if (wv < 4) __builtin_amdgcn_s_setprio(1);
+#endif
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
 
@@ -216,6 +218,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
 
     f32x4 acc[8][4];
+    f32x2 bf[2][4];                    // B fragments: xi l in bf[l & 1]; those of an item's last xi cross the barrier
     f32x2 dcol[2][3];                  // two patch columns in flight: rows A, B, C
     float e[2][2][4];                  // [channel of the pair][local row][column] after the column pass
     float v[2][2][8];                  // [parity of the item][channel of the pair][local xi = local row * 4 + column]
@@ -276,9 +279,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
         const float* Hn = Hs + (par ^ 1) * HBUF;
         float* Hw = Hs + par * HBUF;
         float* Uw = Us + (par ^ 1) * UBUF;
-        f32x2 bf[W6_BD + 1][4];        // B fragments run W6_BD xi ahead of the MFMAs that consume them
         auto ldb = [&](int l, int nb) {
-            bf[l % (W6_BD + 1)][nb] = *(const f32x2*)&Uc[(l < 4 ? b_0 : b_1) + ((l & 3) * 64 + nb * 16) * 8];
+            bf[l & 1][nb] = *(const f32x2*)&Uc[(l < 4 ? b_0 : b_1) + ((l & 3) * 64 + nb * 16) * 8];
         };
         auto slot = [&](int p) {       // p = 0..63: MFMA position (compile-time after unrolling)
 #if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_HLOADS)      // timing-only A/B builds (tools/wino_ab.sh): wrong results
@@ -300,26 +302,50 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
             }
             if (p >= 48) row_op(par ^ 1, p - 48);
         };
+        // The item's first B fragments are requested right behind the barrier; the eight MFMAs of the PREVIOUS item's last xi
+        // (operands and fragments already in registers) run while they arrive - without them every wave of the workgroup
+        // would sit through the LDS latency with an idle matrix pipe once per item.
 #pragma unroll
-        for (int l = 0; l < W6_BD; ++l)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) { ldb(l, nb); __builtin_amdgcn_sched_barrier(0); }
+        for (int nb = 0; nb < 4; ++nb) { ldb(0, nb); __builtin_amdgcn_sched_barrier(0); }
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        if (first) {
 #pragma unroll
-        for (int l = 0; l < 8; ++l) {
-            const int s = l % (W6_BD + 1);
+            for (int p = 0; p < 8; ++p) slot(p);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[7][nb] = zero4;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    acc[7][nb] = MFMA16(v[par ^ 1][k][7], k == 0 ? bf[1][nb].x : bf[1][nb].y, acc[7][nb]);
+                    slot(k * 4 + nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+#pragma unroll
+        for (int l = 0; l < 7; ++l) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb) {
 #ifndef W6_EXP_NO_BREAD
-                    if (k == 0 && l + W6_BD < 8) ldb(l + W6_BD, nb);
+                    if (k == 0) ldb(l + 1, nb);          // (l = 6: the fragments of xi 7 stay in bf[1] for the next body)
 #endif
-                    acc[l][nb] = MFMA16(v[par][k][l], k == 0 ? bf[s][nb].x : bf[s][nb].y, (first && k == 0) ? zero4 : acc[l][nb]);
-                    slot(l * 8 + k * 4 + nb);
+                    acc[l][nb] = MFMA16(v[par][k][l], k == 0 ? bf[l & 1][nb].x : bf[l & 1][nb].y, (first && k == 0) ? zero4 : acc[l][nb]);
+                    slot(8 + l * 8 + k * 4 + nb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
         }
+    };
+    auto flush = [&]() {               // the last xi of a region's last item (odd parity)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                acc[7][nb] = MFMA16(v[1][k][7], k == 0 ? bf[1][nb].x : bf[1][nb].y, acc[7][nb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
     };
 
     // Region epilogue of a wave (HH = its xi half): partial y = A^T M_h A over the wave's two xi rows for every (tile, cout)
@@ -440,6 +466,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
             W6_ITEM_BARRIER();
         }
         // region (cn, ctx, cty) is complete
+        flush();
 #ifdef W6_EXP_NO_EPI
         if (acc[3][1][2] == 123.456f)
 #endif
@@ -496,5 +523,400 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
     if (wide) k_conv_wino64<32><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
     else k_conv_wino64<16><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino64");
+    return VQW_OK;
+}
+
+// =====================================================================================================================
+// Weight gradient in Winograd form for Cout % 64 == 0, Cin % 32 == 0 (one full-resolution source)
+// =====================================================================================================================
+//   dU[xi][co][ci] = sum over tiles of dM[xi][tile][co] V[xi][tile][ci],   dM = A dY A^T,  V = B^T d B,   dW = G^T dU G
+// Same accounting as above: k_conv_wino_wgrad (conv_wino.hip) spends ~3 VALU instructions per MFMA (both operands are
+// transformed by the wave that multiplies them, every prefetch address is computed in the loop).  Here a workgroup owns a
+// (64 co x 32 ci) block of dU; wave (r, kh) = xi ROW r (4 of the 16 xi) x all 64 x 32 entries (4 x 4 x 2 x 4 = 128
+// accumulators) x half of the region's tiles as its K slice.  Per k-step of 4 tiles a lane builds row r of dM for its co in
+// 4 instructions per co block (the row of A dY is one fma, the columns p0, p0 + p1, p0 - p1, p1 two more; signs of row 3 /
+// column 3 are folded into the final transform) and row r of V for its ci in 8 per ci block: 32 VALU for 32 MFMAs.
+// Operands are built one k-step ahead of the MFMAs that consume them, across the region barrier too (one barrier per
+// 128 MFMAs); prefetch addresses are per-thread constants against a buffer descriptor whose base moves with the region
+// (SALU), image-edge padding costs three VALU instructions per slot and region (edge bits of the slot & the region's flags).
+namespace {
+
+struct W64WgArgs {
+    const float* x;
+    const float* dy;
+    float* part;               // [nsb][Cout][9][Cin]
+    float* bias_part;          // [nsb][Cout] or null
+    int N, H, W, Cin, Cout;
+    int tilesY, tilesX, nsp;
+    int n_ci_b, nblk, kt;
+    unsigned nbx, nbd;         // bytes of x / dy
+};
+
+constexpr int WG_DP = 72, WG_XP = 40;     // floats per dY pixel (64 co + 8) / X pixel (32 ci + 8): adjacent tiles 16 banks apart
+template <int RW> struct WgGeo {
+    static constexpr int TRP = RW == 32 ? 4 : 8;           // pixel rows per region: 32 tiles
+    static constexpr int XW = RW + 2, XR = TRP + 2, XPIX = XR * XW;
+    static constexpr int DBUF = 128 * WG_DP, XBUF = XPIX * WG_XP;
+};
+
+template <int RW>
+__global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad64(W64WgArgs a) {
+    using G = WgGeo<RW>;
+    constexpr int NT = 512, DBUF = G::DBUF, XBUF = G::XBUF, XW = G::XW;
+    constexpr int XF = G::XPIX * 8;                        // float4 per X halo: 1632 / 1440
+    constexpr int LX = (XF + NT - 1) / NT;                 // 4 / 3 slots
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: dY tiles [2][DBUF], then X halos [2][XBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = wv & 3, kh = wv >> 2;
+#if defined(W6_PRIO) && W6_PRIO == 1
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#elif defined(W6_PRIO) && W6_PRIO == 2
+    if (wv < 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    // the (co, ci) blocks of one spatial split read the same dY / X regions: keep them on one XCD's L2
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = lb % a.nblk, sblk = lb / a.nblk;
+    const int co_base = (blk / a.n_ci_b) * 64, ci_base = (blk % a.n_ci_b) * 32;
+    const int sp0 = sblk * a.kt;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int per_img = a.tilesY * a.tilesX;
+    const bool do_bias = a.bias_part != nullptr && ci_base == 0;
+
+    // ---- loader slots ----
+    // dY float4 f = tid + 512 j -> pixel f / 16, co quad f % 16 = tid & 15
+    const int d_px = tid >> 4;                                            // + 32 j
+    const unsigned d_fix = ((unsigned)((RW == 32 ? 0 : (d_px >> 4)) * W + (RW == 32 ? d_px : (d_px & 15))) * Cout + co_base + (tid & 15) * 4) * 4u;
+    const unsigned d_jstride = (unsigned)((RW == 32 ? 1 : 2) * W) * Cout * 4u;      // 32 pixels further: one / two rows
+    const int d_lds = d_px * WG_DP + (tid & 15) * 4;                      // + j * 32 * WG_DP
+    // X float4 f = tid + 512 j -> halo pixel f / 8, ci quad f % 8 = tid & 7; slots past the end repeat another thread's
+    unsigned x_fix[LX];
+    int x_lds[LX];
+    unsigned x_bits = 0;                   // 4 bits per slot: the pixel lies on the halo's top / bottom row, left / right column
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+        int f = tid + j * NT;
+        if (f >= XF) f -= XF;
+        const int hp = f >> 3, hy = hp / XW, hx = hp - hy * XW;
+        x_fix[j] = ((unsigned)(hy * W + hx) * Cin + ci_base + (tid & 7) * 4) * 4u;     // against the pixel (y0 - 1, x0 - 1)
+        x_lds[j] = 2 * DBUF + hp * WG_XP + (tid & 7) * 4;
+        x_bits |= (unsigned)((hy == 0 ? 1 : 0) | (hy == G::XR - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == XW - 1 ? 8 : 0)) << (4 * j);
+    }
+    float4 rd[4], rx[LX];
+    float4 bsum;
+    bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+        float4 f;
+        unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        f.x = __uint_as_float(a0); f.y = __uint_as_float(a1); f.z = __uint_as_float(a2); f.w = __uint_as_float(a3);
+        return f;
+    };
+    // region (n, tx, ty): descriptors whose base is the region's first dY pixel / the pixel (y0 - 1, x0 - 1) of X.  Offsets
+    // are range-checked against the rest of the tensor; what lies before its start is masked by the lane masks.
+    __amdgpu_buffer_rsrc_t rsd, rsx;
+    unsigned x_edges = 0;               // the region's edge flags (top, bottom, left, right), once per slot nibble
+    auto region_setup = [&](int n, int tx, int ty) {
+        const int y0 = ty * G::TRP, x0 = tx * RW;
+        const long dpix = ((long)n * H + y0) * W + x0;
+        const long doff = dpix * Cout * 4;
+        rsd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + doff), 0, (int)(unsigned)((long)a.nbd - doff), 0x00020000);
+        const long xoff = (dpix - W - 1) * Cin * 4;                       // may lie before the tensor (first region): masked
+        const long xleft = (long)a.nbx - xoff;
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
+        x_edges = ((y0 == 0 ? 1u : 0u) | (y0 + G::TRP == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + RW == W ? 8u : 0u)) * 0x1111u;
+    };
+    auto issue_d = [&](int j) { rd[j] = ld4(rsd, d_fix, j * d_jstride); };
+    auto issue_x = [&](int j) {
+        const unsigned vo = (x_bits & x_edges & (0xFu << (4 * j))) ? 0xFFFFFFFFu : x_fix[j];      // padding: out of range -> 0
+        rx[j] = ld4(rsx, vo, 0);
+    };
+    float once_v = 1.f;                 // 0 for the prefetch past the workgroup's share (a repeat of its last region)
+    auto commit_d = [&](int j, int buf) {
+        *(float4*)&smem[d_lds + buf * DBUF + j * 32 * WG_DP] = rd[j];
+        if (do_bias) {                  // uniform; fused bias gradient
+            bsum.x = __builtin_fmaf(once_v, rd[j].x, bsum.x); bsum.y = __builtin_fmaf(once_v, rd[j].y, bsum.y);
+            bsum.z = __builtin_fmaf(once_v, rd[j].z, bsum.z); bsum.w = __builtin_fmaf(once_v, rd[j].w, bsum.w);
+        }
+    };
+    auto commit_x = [&](int j, int buf) { *(float4*)&smem[x_lds[j] + buf * XBUF] = rx[j]; };
+
+    // ---- fragment addressing: lane (channel idx = lane & 15, tile k = lane >> 4 of the k-step) ----
+    const int idx = lane & 15, k = lane >> 4;
+    // k-step s of K half kh: RW = 32: tile row kh, tile columns 4 s + k;  RW = 16: tile row 2 kh + (s >> 1), columns 4 (s & 1) + k
+    // rows of A dY: r = 0: y0.; 1: y0. + y1.; 2: y0. - y1.; 3: y1. (negated: folded)  ->  p = yF + sA * yS
+    const int aF = r == 3 ? 1 : 0, aS = r == 0 ? 0 : 1;
+    const int trow0 = RW == 32 ? kh : 2 * kh;
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    const int a_F = opaque(((2 * trow0 + aF) * RW + 2 * k) * WG_DP + idx);       // + s-part, + b * WG_DP, + mbk * 16
+    const int a_S = opaque(((2 * trow0 + aS) * RW + 2 * k) * WG_DP + idx);
+    // rows of B^T d: r = 0: d0 - d2; 1: d1 + d2; 2: d2 - d1; 3: d1 - d3  ->  e = dA + sB * dB
+    const int iA = r == 0 ? 0 : r == 2 ? 2 : 1, iB = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3;
+    // (the X buffers start 72 KB into the LDS, beyond the 64 KB immediate of a ds_read: their offset lives in the base register)
+    const int x_A = opaque(2 * DBUF + ((2 * trow0 + iA) * XW + 2 * k) * WG_XP + idx);       // + s-part, + column * WG_XP, + nbk * 16
+    const int x_B = opaque(2 * DBUF + ((2 * trow0 + iB) * XW + 2 * k) * WG_XP + idx);
+    float sA, sB;
+    { float s = (r == 1) ? 1.f : (r == 2) ? -1.f : 0.f; asm volatile("v_mov_b32 %0, %1" : "=v"(sA) : "v"(s)); }
+    { float s = (r == 1) ? 1.f : -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(sB) : "v"(s)); }
+    // pixel offset of k-step s inside the region's dY tile / X halo
+    auto s_px_d = [](int s) { return RW == 32 ? 8 * s : 2 * (s >> 1) * 16 + 8 * (s & 1); };
+    auto s_px_x = [](int s) { return RW == 32 ? 8 * s : 2 * (s >> 1) * XW + 8 * (s & 1); };
+
+    f32x4 acc[4][4][2];                // [xi column][co block][ci block]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[c][mb][nb][q] = 0.f;
+    float dm[2][4][4];                 // [operand set][co block][xi column]
+    float vv[2][2][4];                 // [operand set][ci block][xi column]
+    float ra[2][4], rb[2][8];          // raw LDS values of two groups in flight
+
+    // Operand build for k-step s from the buffers (Db, Xb), as six groups: g = 0..3 co block g (4 reads, 4 VALU),
+    // g = 4, 5 ci block g - 4 (8 reads, 8 VALU)
+    auto rd_grp = [&](int nbuf, int s, int g, int i) {       // read i of group g from buffer nbuf
+        if (g < 4) {
+            const int o = nbuf * DBUF + s_px_d(s) * WG_DP + g * 16 + (i & 1) * WG_DP;
+            ra[g & 1][i] = i < 2 ? smem[a_F + o] : smem[a_S + o];
+        } else {
+            const int o = nbuf * XBUF + s_px_x(s) * WG_XP + (g - 4) * 16 + (i & 3) * WG_XP;
+            rb[g & 1][i] = i < 4 ? smem[x_A + o] : smem[x_B + o];
+        }
+    };
+    auto op_grp = [&](int set, int g, int i) {          // VALU operation i of group g
+        if (g < 4) {
+            float* d = dm[set][g];
+            const float* q = ra[g & 1];
+            if (i == 0) d[0] = __builtin_fmaf(sA, q[2], q[0]);          // p0
+            if (i == 1) d[3] = __builtin_fmaf(sA, q[3], q[1]);          // p1 (column 3 = -p1: folded)
+            if (i == 2) d[1] = d[0] + d[3];
+            if (i == 3) d[2] = d[0] - d[3];
+        } else {
+            float* o = vv[set][g - 4];
+            float* q = rb[g & 1];
+            if (i < 4) q[i] = __builtin_fmaf(sB, q[4 + i], q[i]);       // e[i] in place
+            if (i == 4) o[0] = q[0] - q[2];
+            if (i == 5) o[1] = q[1] + q[2];
+            if (i == 6) o[2] = q[2] - q[1];
+            if (i == 7) o[3] = q[1] - q[3];
+        }
+    };
+    // position p = 0..31 of a phase -> what is built beside MFMA p:
+    //   p 0-3 reads A0 | 4-7 ops A0, reads A1 | 8-11 ops A1, reads A2 | 12-15 ops A2, reads A3 | 16-19 ops A3, reads B0 (2 each)
+    //   | 20-27 ops B0, reads B1 | 28-31 ops B1 (2 each)
+    auto build_slot = [&](int nbuf, int s, int set, int p) {
+        if (p < 4) rd_grp(nbuf, s, 0, p);
+        else if (p < 16) { op_grp(set, (p - 4) >> 2, (p - 4) & 3); rd_grp(nbuf, s, ((p - 4) >> 2) + 1, (p - 4) & 3); }
+        else if (p < 20) { op_grp(set, 3, p - 16); rd_grp(nbuf, s, 4, 2 * (p - 16)); rd_grp(nbuf, s, 4, 2 * (p - 16) + 1); }
+        else if (p < 28) { op_grp(set, 4, p - 20); rd_grp(nbuf, s, 5, p - 20); }
+        else { op_grp(set, 5, 2 * (p - 28)); op_grp(set, 5, 2 * (p - 28) + 1); }
+    };
+
+    // ---- region cursors ----
+    int cn = sp0 / per_img, ctx, cty;
+    {
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    auto next_region = [&](int& n, int& tx, int& ty) {
+        const int ty1 = ty + 1, wy = ty1 == a.tilesY ? 1 : 0;
+        ty = wy ? 0 : ty1;
+        const int tx1 = tx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        tx = wx ? 0 : tx1;
+        n += wx;
+    };
+    if (my_tiles > 0) {
+        // prologue: region 0 into buffer 0, operands of its first k-step; the dY loads of region 1 in flight
+        region_setup(cn, ctx, cty);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_d(j);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) issue_x(j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) commit_d(j, 0);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) commit_x(j, 0);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 32; ++p) build_slot(0, 0, 0, p);
+    }
+    // the region whose data is fetched next (clamped to the workgroup's share: past it the last region is fetched again)
+    int ln = cn, ltx = ctx, lty = cty, lcount = 0;
+    auto load_advance = [&]() {
+        if (lcount + 1 < my_tiles) { next_region(ln, ltx, lty); ++lcount; once_v = 1.f; } else once_v = 0.f;
+        region_setup(ln, ltx, lty);
+    };
+    if (my_tiles > 0) {
+        load_advance();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_d(j);
+    }
+
+    // One phase = the 32 MFMAs of k-step s (operand set SET) + the build of the next k-step's operands (set SET ^ 1) from
+    // buffer NB + what LOADS says: 0 commit dY of the next region and issue its X loads, 2 commit that X and issue the dY
+    // loads of the region after it
+    auto phase = [&](auto SET, auto SNEXT, auto NBUF, auto DBUFW, auto LOADS) {
+        constexpr int set = decltype(SET)::value, sn = decltype(SNEXT)::value, nbuf = decltype(NBUF)::value;
+        constexpr int wbuf = decltype(DBUFW)::value, loads = decltype(LOADS)::value;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int p = c * 8 + mb * 2 + nb;
+                    acc[c][mb][nb] = MFMA16(dm[set][mb][c], vv[set][nb][c], acc[c][mb][nb]);
+#ifndef W6_EXP_NO_BUILD               // timing-only A/B builds (tools/wino_ab.sh): wrong results
+                    build_slot(nbuf, sn, set ^ 1, p);
+#endif
+#ifndef W6_EXP_NO_WLOADS
+                    // prefetch: ~1.75 phases (2 us) between a load and its LDS commit; the two batches never hold registers together
+#ifndef W6_EXP_NO_WCOMMIT
+                    if (loads == 0 && p >= 2 && p < 6) commit_d(p - 2, wbuf);
+                    if (loads == 2 && p >= 2 && p < 2 + LX) commit_x(p - 2, wbuf);
+#endif
+#ifndef W6_EXP_NO_WISSUE
+                    if (loads == 0 && p >= 10 && p < 10 + 2 * LX && (p & 1) == 0) issue_x((p - 10) >> 1);
+                    if (loads == 2 && p >= 10 && p < 18 && (p & 1) == 0) issue_d((p - 10) >> 1);
+#endif
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto region = [&](auto BUF) {      // the four k-steps of a region that sits in buffer BUF
+        constexpr int b = decltype(BUF)::value;
+        using B = std::integral_constant<int, b>;
+        using NB = std::integral_constant<int, b ^ 1>;
+        phase(I0{}, I1{}, B{}, NB{}, I0{});        // k-step 0 (set 0), builds k-step 1; commits dY of the next region, issues its X
+        phase(I1{}, I2{}, B{}, NB{}, I1{});        // k-step 1, builds 2
+        load_advance();
+        phase(I0{}, I3{}, B{}, NB{}, I2{});        // k-step 2, builds 3; commits X; issues dY of the region after the next
+#ifndef W6_EXP_NO_WBARRIER
+        __syncthreads();                           // the next region's buffers are complete; this region's are read once more
+#endif
+        phase(I1{}, I0{}, NB{}, B{}, I3{});        // k-step 3, builds k-step 0 of the next region
+    };
+    for (int g = 0; g < my_tiles; g += 2) {        // uniform per workgroup
+        region(I0{});
+        if (g + 1 < my_tiles) region(I1{});
+    }
+
+    // ---- fold: the two K halves and the four xi rows meet in LDS, one co block (16 couts) per round ----
+    __syncthreads();
+    float* red = smem;                     // [kh][r][c][16 co][32 ci] = 64 KB
+    if (do_bias) {                         // threads with equal (tid & 15) hold the same 4 couts
+        *(float4*)&red[tid * 4] = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            const int cq = tid >> 2, comp = tid & 3;
+            float sum = 0.f;
+            for (int i = 0; i < 32; ++i) sum += red[(i * 16 + cq) * 4 + comp];
+            a.bias_part[(size_t)sblk * Cout + co_base + tid] = sum;
+        }
+        __syncthreads();
+    }
+    // (one base register made opaque HERE: left to itself the compiler computes the 128 store addresses at kernel entry and
+    // carries them, spilled, through the main loop)
+    int fold_w = ((kh * 4 + r) * 4 * 16 + 4 * (lane >> 4)) * 32 + idx, fold_r = tid;
+    asm volatile("" : "+v"(fold_w), "+v"(fold_r));
+#ifdef W6_EXP_NO_FOLD
+    if (acc[1][2][1][3] == 123.456f)
+#endif
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        // C/D layout (16x16): col = lane & 15 (ci), row = 4 (lane >> 4) + q (co within the block)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    red[fold_w + c * 512 + q * 32 + nb * 16] = acc[c][mb][nb][q];
+        __syncthreads();
+        {
+            const int e = fold_r;          // (co16, ci32) = (tid >> 5, tid & 31)
+            float tcol[3][4];              // G^T applied down the rows: [ky][column]
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float u[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float t = red[((0 * 4 + rr) * 4 + c) * 512 + e] + red[((1 * 4 + rr) * 4 + c) * 512 + e];
+                    u[rr] = ((rr == 3) != (c == 3)) ? -t : t;           // row 3 / column 3 of dM were built without their sign
+                }
+                tcol[0][c] = u[0] + 0.5f * (u[1] + u[2]);
+                tcol[1][c] = 0.5f * (u[1] - u[2]);
+                tcol[2][c] = u[3] + 0.5f * (u[1] + u[2]);
+            }
+            const int co = co_base + mb * 16 + (tid >> 5), ci = ci_base + (tid & 31);
+            float* o = a.part + (size_t)sblk * Cout * 9 * Cin + ((size_t)co * 9) * Cin + ci;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float t0 = tcol[ky][0], t1 = tcol[ky][1], t2 = tcol[ky][2], t3 = tcol[ky][3];
+                o[(ky * 3 + 0) * Cin] = t0 + 0.5f * (t1 + t2);
+                o[(ky * 3 + 1) * Cin] = 0.5f * (t1 - t2);
+                o[(ky * 3 + 2) * Cin] = t3 + 0.5f * (t1 + t2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// one full-resolution source, whole regions (4 x 32 or 8 x 16 pixels)
+bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W) {
+    if (!g_w64_env || C1 != 0 || up0 || C0 % 32 != 0 || Cout % 64 != 0 || W % 16 != 0) return false;
+    return H % (W % 32 == 0 ? 4 : 8) == 0;
+}
+int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
+    const int nblk = (Cout / 64) * (Cin / 32);
+    const int rw = W % 32 == 0 ? 32 : 16;
+    const int nsp = N * (H / (128 / rw)) * (W / rw);
+    int nsb = g_w64_max_blocks / nblk;
+    if (nsb > max_slabs) nsb = max_slabs;
+    if (nsb > nsp) nsb = nsp;
+    if (nsb < 1) nsb = 1;
+    const int kt = ceil_div(nsp, nsb);
+    if (kt_out) *kt_out = kt;
+    return ceil_div(nsp, kt);
+}
+int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+                      hipStream_t st) {
+    const int rw = W % 32 == 0 ? 32 : 16;
+    const size_t lds = (size_t)2 * (rw == 32 ? WgGeo<32>::DBUF + WgGeo<32>::XBUF : WgGeo<16>::DBUF + WgGeo<16>::XBUF) * sizeof(float);
+    static_assert((size_t)2 * (WgGeo<32>::DBUF + WgGeo<32>::XBUF) * sizeof(float) <= 160 * 1024, "wgrad tiles do not fit the LDS");
+    static_assert((size_t)2 * (WgGeo<16>::DBUF + WgGeo<16>::XBUF) * sizeof(float) >= 64 * 1024, "the fold needs 64 KB");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino_wgrad64<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_conv_wino_wgrad64<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            vqw_set_error("conv_wino64_wgrad: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const long P = (long)N * H * W;
+    W64WgArgs a;
+    a.x = x; a.dy = dy; a.part = ws; a.bias_part = bpart;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = H / (128 / rw); a.tilesX = W / rw; a.nsp = N * a.tilesY * a.tilesX;
+    a.n_ci_b = Cin / 32; a.nblk = (Cout / 64) * a.n_ci_b; a.kt = kt;
+    a.nbx = (unsigned)(P * Cin * 4);
+    a.nbd = (unsigned)(P * Cout * 4);
+    if (rw == 32) k_conv_wino_wgrad64<32><<<a.nblk * nsb, 512, lds, st>>>(a);
+    else k_conv_wino_wgrad64<16><<<a.nblk * nsb, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino64_wgrad");
     return VQW_OK;
 }
