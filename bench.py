@@ -136,7 +136,12 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # VQW_DP_FORCE=1 on one GPU: a process group of one rank over RCCL with every data-parallel collective issued (they are
+    # identities): what the RCCL code path costs next to the kernels, measurable without a second GPU
+    forced = world == 1 and os.environ.get("VQW_DP_FORCE", "0") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_PORT", "29655")
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -155,7 +160,7 @@ def main():
         args.size = int(cfg.dataset.image_size)
     g = cfg.model.vqmodel
     torch.manual_seed(0)                                   # identical replicas on every rank
-    tr = build_first_step_trainer(cfg, device=dev, data_parallel=world > 1)
+    tr = build_first_step_trainer(cfg, device=dev, data_parallel=world > 1 or forced)
     pool = [synthetic_batch(args.batch, args.size, 1234 + 1000 * rank + s, dev) for s in range(4)]
 
     # the dependency chain of the step runs on a high-priority stream, the off-chain weight gradients on the (normal
@@ -179,6 +184,8 @@ def main():
     timing = not args.no_kernel_timing
     if timing:
         _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
+    from hipops import ops as _ops
+    coll0 = (_ops.collective_calls, tr.reducer.launches if tr.reducer is not None else 0)
     ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -188,6 +195,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    coll1 = (_ops.collective_calls, tr.reducer.launches if tr.reducer is not None else 0)
     if rank == 0:
         ms1 = torch.cuda.memory_stats(dev)
         print("[bench] %d timed steps: %.1f ms/step; device segments allocated inside the timed region: %d (+%.2f GB reserved)"
@@ -200,7 +208,6 @@ def main():
     # on a side stream next to the chain kernels, which stretches every kernel's own duration.  Two extra steps with
     # the side stream off give the kernels' exclusive durations (reported as roofline.exclusive).
     prof_x = (ctypes.c_double * 20)()
-    from hipops import ops as _ops
     if timing and _ops.WGRAD_ASYNC:
         _ops.WGRAD_ASYNC = False
         cv, tr.concurrent_views = tr.concurrent_views, False
@@ -302,12 +309,16 @@ def main():
             "step_fraction_of_fp32_mfma_roofline_executed": executed / (ms_per_step * 1e-3) / PEAK_FP32_MFMA if executed else None,
             "step_fraction_of_hbm_roofline": per_gpu * BYTES_PER_IMAGE * scale / PEAK_HBM if rcfg else None,
             "loss_total": total,
+            # ranks of the RCCL process group the timed steps ran in (0: no process group - a plain single-GPU run), and the
+            # collectives one rank issued per step: SyncBN / VQ statistics all-reduces, gradient-bucket all-reduces
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
+            "collectives_per_step": {"statistics": (coll1[0] - coll0[0]) / args.steps, "gradient_buckets": (coll1[1] - coll0[1]) / args.steps},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

@@ -34,7 +34,9 @@ extern "C" {
 const char* vqw_last_error(void);
 int vqw_abi_version(void);
 /* 0 = auto (MFMA kernels when shapes allow), 1 = force the generic VALU kernels, 2 = MFMA kernels but
- * never the LDS-resident halo-tile forward (A/B timing, tests).  Returns the previous mode. */
+ * never the LDS-resident halo-tile forward (A/B timing, tests), 3 = auto but never a Winograd-form kernel (every plain
+ * 3x3 layer in direct form: the reference for "the training forward's codebook indices do not depend on the Winograd
+ * kernels").  Returns the previous mode. */
 int vqw_set_conv_backend(int mode);
 /* Measurement aid (bench.py roofline): HIP events recorded on the launch stream around every convolution kernel
  * family between begin and end.  end() synchronises on those events and fills out[5][4] =

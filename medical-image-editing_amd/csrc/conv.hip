@@ -69,12 +69,12 @@ struct ProfScope {
     }
 };
 extern "C" int vqw_set_conv_backend(int mode) {
-    int old = g_conv_backend == 1 ? 1 : (g_halo_mode ? 2 : 0);
+    int old = g_conv_backend == 1 ? 1 : (g_halo_mode ? 2 : (g_wino_mode ? 3 : 0));
     g_conv_backend = mode == 1 ? 1 : 0;
     g_halo_mode = mode == 2 ? 1 : 0;
     g_wgrad_tile_mode = mode == 2 ? 1 : 0;
     g_dil_mode = mode == 2 ? 1 : 0;
-    g_wino_mode = mode == 2 ? 1 : 0;
+    g_wino_mode = (mode == 2 || mode == 3) ? 1 : 0;
     return old;
 }
 

@@ -827,8 +827,29 @@ def instance_norm_cat(xs, relu=True, eps=1e-5, parts=None):
 # ----------------------------------------------------------------------------------------------
 # StyledDenorm core: BatchNorm2d(affine=False)(x) * (1 + gamma) + beta (+ReLU)
 # ----------------------------------------------------------------------------------------------
+# VQW_DP_FORCE=1 (or force_collectives(True)): issue every data-parallel collective - SyncBN statistics, VQ statistics, the
+# gradient buckets of trainers.GradientAllReducer - also in a process group of ONE rank.  A one-GPU box can then run the
+# real RCCL code path (ProcessGroupNCCL's stream / event ordering against the two view streams and the weight-gradient
+# lanes); with one rank every all-reduce is the identity, so the step must equal the non-distributed step bit for bit
+# (tests/test_gpu_dp.py::test_rccl_world_size_one_equals_plain_step).
+FORCE_COLLECTIVES = os.environ.get("VQW_DP_FORCE", "0") == "1"
+collective_calls = 0           # small collectives issued from this module since import (tools/dp_probe prints it per step)
+
+
+def force_collectives(on=True):
+    global FORCE_COLLECTIVES
+    old, FORCE_COLLECTIVES = FORCE_COLLECTIVES, bool(on)
+    return old
+
+
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
+def _all_reduce(t):
+    global collective_calls
+    collective_calls += 1
+    dist.all_reduce(t)
 
 
 class _Spade(torch.autograd.Function):
@@ -861,7 +882,7 @@ class _Spade(torch.autograd.Function):
             if sync and _dist_on():
                 # SyncBatchNorm semantics (run_vqwnet.py:121): global-batch statistics, one small all-reduce.
                 # Every rank holds the same per-rank batch (weak scaling), so the count needs no exchange.
-                dist.all_reduce(sums)
+                _all_reduce(sums)
                 count *= dist.get_world_size()
             cur = _order_begin(running_mean)
             _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
@@ -906,7 +927,7 @@ class _Spade(torch.autograd.Function):
         _lib.check(L.vqw_spade_bwd_reduce(_p(x), _p(mr), gptr, bptr, _p(gy), dgptr, dbptr, gbs, _p(sums), _p(ws),
                                           ws.numel(), N, H * W, C, int(relu), _st()), "vqw_spade_bwd_reduce")
         if training and sync and _dist_on():
-            dist.all_reduce(sums)
+            _all_reduce(sums)
         _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), gptr, bptr, gbs, _p(gy), _p(sums), count, _p(gx), N * H * W, C,
                                          int(relu), int(training), _st()), "vqw_spade_bwd_apply")
         return gx, dgamma, dbeta, None, None, None, None, None, None, None, None, (gy if ctx.has_res else None), None
@@ -1266,11 +1287,11 @@ class _VQ(torch.autograd.Function):
             scale = 1.0
             if _dist_on() and dist_mode != "local":
                 if dist_mode == "global":
-                    dist.all_reduce(stats)              # counts and sums over the global batch
+                    _all_reduce(stats)                  # counts and sums over the global batch
                 elif dist_mode == "reference":
                     # vq_module.py:187-193: embed_sum rank-averaged, counts local (C3 quirk; C2's dead
                     # N x K all-reduce is never reproduced)
-                    dist.all_reduce(stats[K:])
+                    _all_reduce(stats[K:])
                     scale = 1.0 / dist.get_world_size()
                 else:
                     raise RuntimeError("unknown VQ dist_mode %r" % dist_mode)
@@ -1296,12 +1317,13 @@ def vq_quantize(x, embed, cluster_size, embed_avg, training, momentum, eps, dist
     return _VQ.apply(x, embed, cluster_size, embed_avg, bool(training), float(momentum), float(eps), dist_mode, int(id_base))
 
 
-def kmeans_codebook(features, dict_size, seed=0, tol=1e-4, max_iter=100):
+def kmeans_codebook(features, dict_size, seed=0, tol=1e-4, max_iter=100, return_ids=False):
     """Lloyd's k-means over pixel features (P, D) -> centres (K, D): what kmeans_pytorch.kmeans (the reference's codebook
     initialisation, unet_encoder.py:77-82) computes.  Own semantics (the dependency is absent, parity unpinned): centres
     start from K distinct random rows (seeded), an iteration = nearest-centre assignment + per-centre mean (the VQ search /
     statistics kernels and vqw_kmeans_update), empty clusters keep their centre, stop when (sum_k |delta_k|)^2 < tol as
-    kmeans_pytorch does, or after max_iter.  Returns (centres, list of (inertia, shift, empty codes) per iteration)."""
+    kmeans_pytorch does, or after max_iter.  Returns (centres, list of (mean squared distance per row, shift, empty codes)
+    per iteration) and, with return_ids, the assignment of the last search (oracle/kmeans_ref.py restates this on the CPU)."""
     _dev(features)
     P, D = features.shape
     if P < dict_size:
@@ -1326,7 +1348,7 @@ def kmeans_codebook(features, dict_size, seed=0, tol=1e-4, max_iter=100):
         history.append((float(commit) * D, sh[0], int(sh[1])))       # commit = mean squared distance per element -> per row
         if sh[0] ** 2 < tol:
             break
-    return centres, history
+    return (centres, history, ids) if return_ids else (centres, history)
 
 
 def vq_lookup(ids, embed, mask=None, scale=None):
@@ -1568,7 +1590,7 @@ class _BnLrelu(torch.autograd.Function):
             ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
             _lib.check(L.vqw_bn_partial_stats(_p(x), _p(sums), _p(ws), ws.numel(), N, H * W, C, _st()), "vqw_bn_partial_stats")
             if sync and _dist_on():
-                dist.all_reduce(sums)
+                _all_reduce(sums)
                 count *= dist.get_world_size()
             cur = _order_begin(running_mean)
             _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
@@ -1601,7 +1623,7 @@ class _BnLrelu(torch.autograd.Function):
         gx = torch.empty_like(x, memory_format=CL)
         if training and sync and _dist_on():
             local = sums.clone()
-            dist.all_reduce(sums)
+            _all_reduce(sums)
             _lib.check(L.vqw_bn_affine_bwd_apply(_p(x), _p(mr), _p(gamma), _p(beta), _p(gy), _p(sums), count, _p(gx), None, None,
                                                  N * H * W, C, slope, 1, 0, _st()), "vqw_bn_affine_bwd_apply")
             dbeta.copy_(local[0::2])
@@ -1655,7 +1677,8 @@ def neg_mean(logits):
 
 
 def set_conv_backend(mode):
-    """0 = auto (MFMA kernels where shapes allow), 1 = generic VALU kernels only (testing)."""
+    """0 = auto (MFMA kernels where shapes allow), 1 = generic VALU kernels only (testing), 2 = no LDS-resident tile kernels,
+    3 = auto without any Winograd-form kernel.  Returns the previous mode."""
     return _L().vqw_set_conv_backend(int(mode))
 
 

@@ -43,6 +43,7 @@ class GradientAllReducer:
             p.__dict__["_vqw_own_hooks"] = p.__dict__.get("_vqw_own_hooks", 0) + 1
         self._events = {}
         self._armed = False
+        self.launches = 0          # gradient-bucket collectives issued (tools/dp_probe)
         self._sync_lanes = None
         try:
             from hipops import ops as _ops
@@ -56,7 +57,16 @@ class GradientAllReducer:
         self._pending = [len(b) for b in self.buckets]
         self._seen = set()
         self._work = []
-        self._armed = self.world > 1
+        self._armed = self.world > 1 or self._forced()
+
+    @staticmethod
+    def _forced():
+        """hipops.ops.FORCE_COLLECTIVES: run the bucketed all-reduce in a one-rank group too (the RCCL path on one GPU)."""
+        try:
+            from hipops import ops as _ops
+            return bool(_ops.FORCE_COLLECTIVES) and dist.is_initialized()
+        except Exception:
+            return False
 
     def _on_grad_listener(self, p):
         if p in self._bucket_of:
@@ -91,6 +101,7 @@ class GradientAllReducer:
         self._flat[bi] = (flat, views)
         # async: on RCCL the collective runs on the process group's own stream, ordered after the producing
         # kernels by the event torch.distributed records, so it overlaps with the rest of backward
+        self.launches += 1
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._work.append((bi, work))
 

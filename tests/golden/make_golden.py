@@ -40,7 +40,7 @@ def checksum(t):
 
 
 def save(name, d):
-    path = os.path.join(HERE, name)
+    path = os.path.join(os.environ.get("GOLDEN_OUT", HERE), name)
     np.savez_compressed(path, **d)
     print("wrote %-28s %8.1f KB  (%d arrays)" % (name, os.path.getsize(path) / 1024, len(d)))
 
@@ -215,6 +215,19 @@ def ref_first_step(enc, dec, eopt, dopt, image, noise, cfg):
                 ids_1=ids1, ids_2=ids2, recon_1=rec1, recon_2=rec2, embed_1=e1, embed_2=e2), grads
 
 
+def ref_vq_gaps(enc, x):
+    """Top-1 / top-2 score gap of every pixel of `x` under the encoder's CURRENT codebook (vq_module.py:45-62), per
+    pixel in (B, H, W) order: an implementation's ids must be bit-equal wherever this gap is clear of fp32 rounding.
+    The extra feature pass changes nothing (no random numbers, no running statistics in the encoder)."""
+    with torch.no_grad():
+        f = enc(x, skip_vq=True)
+        f = f[0] if isinstance(f, (tuple, list)) else f
+        Bn, D, Hh, Ww = f.shape
+        flat = f.permute(0, 2, 3, 1).reshape(-1, D)
+        sc, _ = R.vq_module._torch_knn(enc.vq.embed, flat, 2, "l2")
+        return (sc[:, 0] - sc[:, 1]).reshape(Bn, Hh, Ww)
+
+
 def sample_idx(numel, n=64, seed=0):
     g = torch.Generator().manual_seed(seed)
     return torch.randint(0, numel, (min(n, numel),), generator=g)
@@ -266,6 +279,7 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
         image, _ = O.synthetic_slices(batch, size, 999)
         e, _, ids = enc(image)
         d["eval/image"], d["eval/ids"], d["eval/recon"] = npy(image), npy(ids), npy(dec(e))
+        d["eval/gap"] = npy(ref_vq_gaps(enc, image))
         g = torch.Generator().manual_seed(3)
         lab = torch.randint(0, K + 1, (batch, size, size), generator=g)
         lab[:, : size // 4, :] = lab[:, :1, :1]   # a constant region, like an edited label map
@@ -290,6 +304,9 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
                 img_v, noi_v = (image.flip(0), noise.flip(0)) if flip else (image, noise)
                 variants.append(ref_first_step(copy.deepcopy(enc), copy.deepcopy(dec), None, None, img_v, noi_v, cfg)[1])
             torch.set_num_threads(8)
+        if s == 0:      # the views of ref_first_step, before the step moves the codebook
+            d["step0/gap_1"] = npy(ref_vq_gaps(enc, image))
+            d["step0/gap_2"] = npy(ref_vq_gaps(enc, torch.flip(image, dims=[3]) + noise))
         out, grads = ref_first_step(enc, dec, eopt, dopt, image, noise, cfg)
         if s == 0:
             # principled gradient gate (tests/helpers.py::check_grads_vs_fp64): 256 sampled entries of the fp64 gradient and

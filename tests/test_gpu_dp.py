@@ -16,8 +16,9 @@ import os, sys, torch, torch.distributed as dist
 root = sys.argv[1]; out = sys.argv[2]
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "medical-image-editing_amd"))
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-if world > 1:
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+forced = os.environ.get("VQW_DP_FORCE", "0") == "1"      # one rank, every collective issued all the same (hipops.ops)
+if world > 1 or forced:
+    dist.init_process_group(os.environ.get("VQW_TEST_BACKEND", "gloo"), rank=rank, world_size=world)
 from trainers import FirstStepTrainer, FlipViews, LossWeights
 from networks import UNetEncoder, UNetDecoder
 from oracle.vqwnet_ref import synthetic_slices
@@ -30,23 +31,26 @@ with torch.no_grad():
     enc.vq.embed.mul_(0.7); enc.vq.cluster_size.fill_(B * S * S / K)
     enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
 tr = FirstStepTrainer(dict_size=K, momentum=0.99, views=FlipViews(border=2), encoder=enc, decoder=dec, device="cuda:0",
-                      data_parallel=world > 1, loss_weight=LossWeights(cross=float(os.environ.get("VQW_TEST_CROSS_W", "1"))))
+                      data_parallel=world > 1 or forced, loss_weight=LossWeights(cross=float(os.environ.get("VQW_TEST_CROSS_W", "1"))))
 img, noise = synthetic_slices(B, S, 11)
 lo, hi = (rank * B // world, (rank + 1) * B // world)
 o = tr.training_step({"image": img[lo:hi].cuda()}, noise=noise[lo:hi].cuda())
 torch.cuda.synchronize()
+from hipops import ops as _ops
 res = {"total": float(o["total"].detach()), "ids_1": o["ids_1"].cpu(),
+       "collectives": (_ops.collective_calls, tr.reducer.launches if tr.reducer is not None else 0),
+       "backend": dist.get_backend() if dist.is_initialized() else "",
        "vq": {k: v.cpu() for k, v in enc.vq.state_dict().items()},
        "bn": {k: v.cpu() for k, v in dec.state_dict().items() if "running_" in k},
        "g": {k: p.grad.cpu() for k, p in list(enc.named_parameters())[:8] + list(dec.named_parameters())[:40:4]},
        "p": {k: p.detach().cpu() for k, p in list(dec.named_parameters())[:6]}}
 torch.save(res, out + ".%d" % rank)
-if world > 1:
+if world > 1 or forced:
     dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def _run(world, tmp_path, tag, port, cross_w=1.0):
+def _run(world, tmp_path, tag, port, cross_w=1.0, extra_env=None):
     script = tmp_path / "dpw.py"
     script.write_text(WORKER)
     out = str(tmp_path / tag)
@@ -54,12 +58,33 @@ def _run(world, tmp_path, tag, port, cross_w=1.0):
     for r in range(world):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r),
                    VQW_TEST_CROSS_W=str(cross_w))
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, out], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:
         o = p.communicate(timeout=500)[0].decode()
         assert p.returncode == 0, o[-3000:]
     return [torch.load(out + ".%d" % r) for r in range(world)]
+
+
+def test_rccl_world_size_one_equals_plain_step(tmp_path):
+    """The data-parallel step over RCCL itself (backend "nccl"), as far as one GPU allows: a process group of ONE rank with
+    every collective forced on (VQW_DP_FORCE=1) - the SyncBN statistics of both views on their two streams, the VQ EMA
+    statistics, the gradient buckets flattened behind the weight-gradient lanes and all-reduced asynchronously on
+    ProcessGroupNCCL's stream, finish() and the optimiser step.  With one rank every all-reduce is the identity and the mean
+    divides by 1, so losses, ids, VQ buffers, BN running statistics, averaged gradients and updated parameters must equal the
+    non-distributed step BIT FOR BIT; a missing stream dependency shows up as a difference."""
+    plain = _run(1, tmp_path, "plain1", 29631)[0]
+    rccl = _run(1, tmp_path, "rccl1", 29632, extra_env={"VQW_DP_FORCE": "1", "VQW_TEST_BACKEND": "nccl"})[0]
+    assert rccl["backend"] == "nccl" and plain["backend"] == ""
+    assert plain["collectives"] == (0, 0)
+    n_small, n_buckets = rccl["collectives"]
+    assert n_small >= 2 + 16 and n_buckets >= 1, rccl["collectives"]      # 2 VQ + SyncBN forward / backward of both views
+    assert rccl["total"] == plain["total"]
+    assert torch.equal(rccl["ids_1"], plain["ids_1"])
+    for grp in ("vq", "bn", "g", "p"):
+        for k in plain[grp]:
+            assert torch.equal(rccl[grp][k], plain[grp][k]), "%s %s differs between the RCCL step and the plain step" % (grp, k)
 
 
 def test_two_rank_dp_matches_single_process(tmp_path):
