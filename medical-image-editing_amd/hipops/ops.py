@@ -112,12 +112,30 @@ _join_queued = False
 grad_ready_listeners = []      # callables(param): the param's gradient is final and enqueued on the side stream
 
 
+# The DDP detection below reads a private class attribute of torch.  On a torch build without it the check would silently
+# say "no DDP" and the reducer would never see the conv weight gradients (hang or unsynchronised training), so its absence
+# switches the out-of-band route off for good instead: every weight gradient then flows through autograd, which is always
+# correct.  set_wgrad_route("autograd") is the explicit form a wrapper can call.
+_DDP = torch.nn.parallel.DistributedDataParallel
+_WGRAD_ROUTE = "auto" if hasattr(_DDP, "_active_ddp_module") else "autograd"
+
+
+def set_wgrad_route(route):
+    """"auto": conv weight gradients of leaf parameters are written out-of-band on the side stream unless a DDP forward is
+    active or the parameter carries foreign hooks; "autograd": always through autograd.  Returns the previous route."""
+    global _WGRAD_ROUTE
+    if route not in ("auto", "autograd"):
+        raise ValueError("wgrad route must be 'auto' or 'autograd'")
+    old, _WGRAD_ROUTE = _WGRAD_ROUTE, route
+    return old
+
+
 def wgrad_through_autograd(*params):
     """True when weight gradients must flow through autograd instead of being written out-of-band on a side stream:
     inside a torch DistributedDataParallel forward (its reducer learns about a gradient from the AccumulateGrad hook of
     the parameter; the reference launches under Lightning's DDPPlugin, run_vqwnet.py:112-121) or when somebody
     registered a hook on the parameter."""
-    if getattr(torch.nn.parallel.DistributedDataParallel, "_active_ddp_module", None) is not None:
+    if _WGRAD_ROUTE == "autograd" or getattr(_DDP, "_active_ddp_module", None) is not None:
         return True
     for p in params:
         if p is None:
@@ -367,7 +385,6 @@ WINOGRAD_FWD = os.environ.get("VQW_WINOGRAD_FWD", "0") == "1"
 # forward by themselves (VQW_WINOGRAD_EVAL=0: direct form there too).
 WINOGRAD_EVAL = os.environ.get("VQW_WINOGRAD_EVAL", "1") != "0"
 _in_custom_op = False          # set by hipops.functional around its no_grad() calls: those are training forwards
-_wino_fwd_call = False         # decided per call by the conv2d / conv2d_cat wrappers, read inside the autograd Functions
 
 
 WINOGRAD_FWD_ENCODER = os.environ.get("VQW_WINOGRAD_FWD_ENCODER", "0") == "1"
@@ -391,13 +408,14 @@ class winograd_forward:
 
 
 def _decide_wino_fwd():
-    global _wino_fwd_call
-    _wino_fwd_call = WINOGRAD_FWD or _wino_fwd_scope > 0 or (WINOGRAD_EVAL and not torch.is_grad_enabled() and not _in_custom_op)
+    """The per-call decision, handed to the autograd Functions as an explicit (non-differentiable) argument: a caller that
+    reaches them without the wrapper, or a second host thread, cannot inherit another call's decision."""
+    return bool(WINOGRAD_FWD or _wino_fwd_scope > 0 or (WINOGRAD_EVAL and not torch.is_grad_enabled() and not _in_custom_op))
 
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, dilation, up0, relu, want_stats=False):
+    def forward(ctx, x0, x1, weight, bias, dilation, up0, relu, want_stats=False, wino_fwd=False, grad_group=None):
         _dev(x0, x1, weight, bias)
         x0 = nhwc(x0)
         x1 = nhwc(x1) if x1 is not None else None
@@ -433,7 +451,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _lib.check(L.vqw_conv3x3_up2_fwd(_p(x0), _p(up_ws), _p(bias), _p(y), N, H // 2, W // 2, Cin, Cout, int(relu), _st()),
                            "vqw_conv3x3_up2_fwd")
-        elif _wino_fwd_call and not up0 and x1 is None and ks == 3 and dilation == 1 and \
+        elif wino_fwd and not up0 and x1 is None and ks == 3 and dilation == 1 and \
                 _L().vqw_conv3x3_wino_supported(Cin, Cout, N, H, W) and \
                 (not (want_stats and not relu) or _L().vqw_conv3x3_wino_fwd_stats_parts(Cin, Cout, N, H, W) > 0
                  or _L().vqw_conv2d_fwd_stats_parts(Cin, 0, 0, N, H, W, Cout, ks, dilation) == 0):
@@ -462,7 +480,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 y = _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dilation, relu)
         ctx.up_ws = up_ws
-        ctx.group = _grad_group_call
+        ctx.group = grad_group
         ctx.save_for_backward(x0, x1, w, y if relu else None)
         ctx.cfg = (dilation, up0, ks, N, H, W, Cout, bias is not None)
         # leaf parameters get their gradient written out-of-band on the side stream (see _deferred_wgrad)
@@ -489,7 +507,7 @@ class _Conv2d(torch.autograd.Function):
             weight, bias = ctx.params
             _deferred_wgrad(weight, bias if (has_bias and bias.requires_grad) else None, x0, x1, gy, up0, ks, dilation,
                             N, H, W, Cout, collapsed=ctx.up_ws is not None)
-        return g0, g1, gw, gb, None, None, None, None
+        return g0, g1, gw, gb, None, None, None, None, None, None
 
 
 def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb, group=None):
@@ -538,14 +556,7 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
                        "vqw_conv2d_fwd(dgrad)")
         if group is not None and need0:
-            if group.buf is None:
-                group.buf = g_full                    # first member to run: its gradient is the buffer
-            elif g_full is not None:
-                group.buf.add_(g_full)                # no accumulating kernel for this member's shape
-            group.remaining -= 1
-            g0 = group.buf if group.remaining == 0 else None
-            if g0 is not None:
-                group.buf = None
+            g0 = group.member_done(g_full)
         elif not up0 and x1 is None:
             g0 = g_full
         else:
@@ -568,30 +579,63 @@ class GradGroup:
     """Several convolutions of ONE input tensor whose input gradients are summed in place instead of by autograd
     (aspp.py:44-47: the pyramid's five branches).  Every member's backward adds its input gradient to one shared buffer
     and returns None for the input, except the last one to run, which returns the buffer: autograd sees a single gradient
-    and launches no add kernels (three passes over the tensor each).  All members must take part in the backward pass
-    (their outputs are all used) and run on one stream."""
+    and launches no add kernels (three passes over the tensor each).  All members must take part in every backward pass
+    over the graph (their outputs are all used) and run on one stream.  The group re-arms itself when its last member has
+    run, so a second pass over a retained graph works; a pass in which only SOME members ran (torch.autograd.grad over part
+    of the branch outputs) cannot hand the input its gradient and raises at the end of that pass instead of dropping it."""
 
     def __init__(self, members):
-        self.remaining = int(members)
+        self.members = self.remaining = int(members)
         self.buf = None
+        self._watching = False
+
+    def opt_out(self):
+        """A member whose input gradient goes through autograd after all (no accumulating route for its form)."""
+        self.members -= 1
+        self.remaining -= 1
+
+    def member_done(self, g_full):
+        """Called by a member's backward with its input gradient (None: already added to the buffer by the kernel).
+        Returns what the member hands to autograd: the summed buffer from the last member to run, None from the others."""
+        if not self._watching:             # first member of this pass: check completeness when the pass ends
+            self._watching = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
+        if self.buf is None:
+            self.buf = g_full                     # first member to run: its gradient is the buffer
+        elif g_full is not None:
+            self.buf.add_(g_full)                 # no accumulating kernel for this member's shape
+        self.remaining -= 1
+        if self.remaining < 0:
+            raise RuntimeError("GradGroup: more backward calls than members")
+        if self.remaining > 0:
+            return None
+        out, self.buf, self.remaining = self.buf, None, self.members          # complete: re-armed for another pass
+        return out
+
+    def _end_of_pass(self):
+        self._watching = False
+        if self.buf is not None or self.remaining != self.members:
+            ran = self.members - self.remaining
+            self.buf, self.remaining = None, self.members
+            raise RuntimeError("GradGroup: only %d of %d members took part in this backward pass - their shared input "
+                               "gradient was not delivered (partial backward over grouped branches: set VQW_GRAD_GROUPS=0)"
+                               % (ran, self.members))
 
 
 GRAD_GROUPS = os.environ.get("VQW_GRAD_GROUPS", "1") != "0"      # 0: autograd sums the branch gradients (A/B timing)
-_grad_group_call = None        # set by conv2d() for the Function it is about to apply
 
 
 def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, want_stats=False, grad_group=None):
     """'same' conv (k in {1,3}, stride 1) of the virtual input [up2x(x) | skip] (channel concat);
     relu=True fuses nn.ReLU into the epilogue.  want_stats=True returns (y, part): `part` (or None when the shape is not
     served) holds the statistics of y for the InstanceNorm that follows: instance_norm(y, ..., part=part)."""
-    global _grad_group_call
-    _decide_wino_fwd()
-    _grad_group_call = grad_group if (GRAD_GROUPS and skip is None and not up2x) else None
-    if grad_group is not None and _grad_group_call is None:
-        grad_group.remaining -= 1          # this member's gradient goes through autograd: the others must not wait for it
+    wino = _decide_wino_fwd()
+    group = grad_group if (GRAD_GROUPS and skip is None and not up2x) else None
+    if grad_group is not None and group is None:
+        grad_group.opt_out()               # this member's gradient goes through autograd: the others must not wait for it
     if want_stats and CONV_STATS:
-        return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), True)
-    y = _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu))
+        return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), True, wino, group)
+    y = _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), False, wino, group)
     return (y, None) if want_stats else y
 
 
@@ -663,7 +707,7 @@ def _deferred_wgrad_cat(wa, ba, wb, bb, x0, gy, ks, N, H, W):
 
 class _ConvCat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wa, ba, wb, bb):
+    def forward(ctx, x, wa, ba, wb, bb, wino_fwd=False):
         _dev(x, wa, ba, wb, bb)
         x = nhwc(x)
         Ca, Cin, ks, _ = wa.shape
@@ -672,7 +716,7 @@ class _ConvCat(torch.autograd.Function):
         if x.shape[1] != Cin or tuple(wb.shape[1:]) != (Cin, ks, ks):
             raise RuntimeError("conv2d_cat: shapes %s / %s / %s do not match" % (tuple(x.shape), tuple(wa.shape), tuple(wb.shape)))
         w, b = _cat_weights(wa, ba, wb, bb)
-        if _wino_fwd_call and ks == 3 and _L().vqw_conv3x3_wino_supported(Cin, Ca + Cb, N, H, W):
+        if wino_fwd and ks == 3 and _L().vqw_conv3x3_wino_supported(Cin, Ca + Cb, N, H, W):
             L = _L()
             u = _cached(wa, "cat_wino", lambda: _wino_weights(L, w, Cin, Ca + Cb), deps=(wb,))
             y = empty_nhwc(N, Ca + Cb, H, W, x)
@@ -718,13 +762,12 @@ class _ConvCat(torch.autograd.Function):
             gb_ = torch.empty(Ct, dtype=torch.float32, device=gy.device)
             _run_wgrad(L, x, None, gy, gw, gb_, False, ks, 1, N, H, W, Ct, False, False)
             gwa, gwb, gba, gbb = gw[:Ca], gw[Ca:], gb_[:Ca], gb_[Ca:]
-        return gx, gwa, gba, gwb, gbb
+        return gx, gwa, gba, gwb, gbb, None
 
 
 def conv2d_cat(x, weight_a, bias_a, weight_b, bias_b):
     """[conv(x, weight_a, bias_a) | conv(x, weight_b, bias_b)] along channels (3x3 / 1x1, stride 1, 'same')."""
-    _decide_wino_fwd()
-    return _ConvCat.apply(x, weight_a, bias_a, weight_b, bias_b)
+    return _ConvCat.apply(x, weight_a, bias_a, weight_b, bias_b, _decide_wino_fwd())
 
 
 # ----------------------------------------------------------------------------------------------

@@ -40,21 +40,36 @@ class UNetEncoder(nn.Module):
         offline: hipops.ops.kmeans_codebook restates Lloyd's iteration on the VQ kernels (own semantics, documented
         there); `kmeans_seed` / `kmeans_max_iter` are attributes of this module."""
         import torch.distributed as dist
-        feats = embed.detach()
+        feats = embed.detach().contiguous()          # NCHW rows for the collective (the gather outputs match it)
         on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        world = dist.get_world_size() if on else 1
+        # every rank knows the global row count: refuse BEFORE any collective, or the others would wait in it for ever
+        rows_total = world * feats.shape[0] * feats.shape[2] * feats.shape[3]
+        if rows_total < self.dict_size:
+            raise RuntimeError("k-means needs at least dict_size = %d feature rows, got %d" % (self.dict_size, rows_total))
         if on:
-            parts = [torch.zeros_like(feats) for _ in range(dist.get_world_size())]
-            dist.all_gather(parts, feats.contiguous())
+            parts = [torch.empty_like(feats) for _ in range(world)]
+            dist.all_gather(parts, feats)
             feats = torch.cat(parts, dim=0)
         is_root = (not on) or dist.get_rank() == 0
+        failure = None
         if is_root:
-            rows = feats.permute(0, 2, 3, 1).reshape(-1, self.dims)
-            centres, self.kmeans_history = ops.kmeans_codebook(rows, self.dict_size, seed=getattr(self, "kmeans_seed", 0),
-                                                               max_iter=getattr(self, "kmeans_max_iter", 100))
-            with torch.no_grad():
-                self.vq.embed.copy_(centres)
+            try:
+                rows = feats.permute(0, 2, 3, 1).reshape(-1, self.dims)
+                centres, self.kmeans_history = ops.kmeans_codebook(rows, self.dict_size, seed=getattr(self, "kmeans_seed", 0),
+                                                                   max_iter=getattr(self, "kmeans_max_iter", 100))
+                with torch.no_grad():
+                    self.vq.embed.copy_(centres)
+            except Exception as e:       # tell the other ranks before re-raising: they are about to wait for the codebook
+                failure = e
         if on:
+            status = torch.tensor([0 if failure is None else 1], dtype=torch.int32, device=self.vq.embed.device)
+            dist.broadcast(status, 0)
+            if int(status.item()):
+                raise failure if failure is not None else RuntimeError("k-means codebook initialisation failed on rank 0")
             dist.broadcast(self.vq.embed, 0)
+        elif failure is not None:
+            raise failure
         self.init_embed = True
 
     def feature_extraction(self, x):

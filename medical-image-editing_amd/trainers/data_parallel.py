@@ -52,6 +52,24 @@ class GradientAllReducer:
         except Exception:       # plain torch modules (CPU tests)
             pass
 
+    def close(self):
+        """Detach from the parameters: remove the hooks, give back the hook allowance, stop listening to the side stream."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for b in self.buckets:
+            for p in b:
+                n = p.__dict__.get("_vqw_own_hooks", 0)
+                if n > 0:
+                    p.__dict__["_vqw_own_hooks"] = n - 1
+        try:
+            from hipops import ops as _ops
+            if self._on_grad_listener in _ops.grad_ready_listeners:
+                _ops.grad_ready_listeners.remove(self._on_grad_listener)
+        except Exception:
+            pass
+        self.buckets, self._bucket_of = [], {}
+
     def prepare(self):
         """Arm the hooks for one backward pass."""
         self._pending = [len(b) for b in self.buckets]

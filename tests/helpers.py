@@ -75,6 +75,9 @@ def step_cfg(g):
                 optim=dict(lr=float(g["cfg/lr"]), betas=tuple(float(b) for b in g["cfg/betas"]), weight_decay=0.0))
 
 
+SPREAD_STAT = "median"
+
+
 def check_grads_vs_fp64(g, grads, factor=2.0, what=""):
     """Principled end-to-end gradient gate.  The step fixtures hold, per parameter, 256 sampled entries of the gradient the
     REFERENCE modules produce in fp64 (`step0/g64.*`) and of four fp32 evaluations of the same reference step that are
@@ -98,8 +101,16 @@ def check_grads_vs_fp64(g, grads, factor=2.0, what=""):
         numel = int(np.prod(grads[k].shape)) if grads.get(k) is not None else 1
         return float((sample.double() - ref).norm()) / (float(ref.norm()) + n64[k] / numel ** 0.5)
 
-    spread = {k: max(max(err(torch.from_numpy(np.asarray(g["step0/g32v%d.%s" % (i, k)])), k) for i in range(nvar)),
-                     float(np.max(g["step0/gerr32." + k]))) for k in live}
+    # per variant: the larger of its sampled and its whole-tensor error; the parameter's spread is the MEDIAN over the
+    # variants, not their maximum: the one-thread evaluations sit 20-400x further from fp64 than the run as launched (ATen's
+    # single-thread normalisation path, not the mathematics), and a gate scaled by the worst of them would let a 1 % indexing
+    # error of a kernel through.  SPREAD_STAT = "max" restores the old, looser gate for comparison.
+    def variant_errs(k):
+        whole = np.asarray(g["step0/gerr32." + k], dtype=np.float64).reshape(-1)
+        return [max(err(torch.from_numpy(np.asarray(g["step0/g32v%d.%s" % (i, k)])), k), float(whole[i]) if i < whole.size else 0.0)
+                for i in range(nvar)]
+    stat = np.max if SPREAD_STAT == "max" else np.median
+    spread = {k: float(stat(variant_errs(k))) for k in live}
     floor = float(np.median(list(spread.values())))
     ratios, over = [], []
     for k in names:

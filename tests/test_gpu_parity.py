@@ -1556,6 +1556,27 @@ def test_gradient_group_sums_branch_gradients_in_place():
     assert_close(ga, gb, 1e-6, "input gradient: in-place group sum vs autograd's sum")
     for u, v in zip(wa, wb):
         assert torch.equal(u, v)
+    # a second pass over the retained graph delivers the same gradient again (the group re-arms itself) ...
+    xs = x.clone().requires_grad_(True)
+    y = m(xs)
+    loss = (y * r).sum()
+    loss.backward(retain_graph=True)
+    g1 = xs.grad.clone()
+    xs.grad = None
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(xs.grad, g1) and torch.equal(g1, ga)
+    # ... and a pass over only some of the branch outputs raises instead of silently dropping the shared input gradient
+    xs = x.clone().requires_grad_(True)
+    wts = [(torch.randn(32, 32, 3, 3, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(2)]
+    grp = ops.GradGroup(2)
+    y1, y2 = ops.conv2d(xs, wts[0], dilation=2, grad_group=grp), ops.conv2d(xs, wts[1], dilation=6, grad_group=grp)
+    with pytest.raises(RuntimeError, match="GradGroup"):
+        torch.autograd.grad(y1.sum(), xs, retain_graph=True)
+    both = torch.autograd.grad((y1 + y2).sum(), xs)[0]          # the group was re-armed: a complete pass still works
+    want = torch.autograd.grad((ops.conv2d(xs, wts[0], dilation=2) + ops.conv2d(xs, wts[1], dilation=6)).sum(), xs)[0]
+    torch.cuda.synchronize()
+    assert_close(both, want, 1e-6, "grouped input gradient after a rejected partial pass")
     # the accumulating kernel itself: y0 + conv(x) (dilated 3x3, 32 channels)
     L = ops._L()
     w = (torch.randn(32, 32, 3, 3, device=DEV) * 0.1).contiguous(memory_format=torch.channels_last)

@@ -137,32 +137,23 @@ def test_winograd_forward_placement_rules():
     saved = (ops.WINOGRAD_FWD, ops.WINOGRAD_EVAL, ops._in_custom_op)
     try:
         ops.WINOGRAD_FWD, ops.WINOGRAD_EVAL, ops._in_custom_op = False, True, False
-        ops._decide_wino_fwd()
-        assert ops._wino_fwd_call is False
+        assert ops._decide_wino_fwd() is False
         with torch.no_grad():
-            ops._decide_wino_fwd()
-            assert ops._wino_fwd_call is True
+            assert ops._decide_wino_fwd() is True
             ops._in_custom_op = True
-            ops._decide_wino_fwd()
-            assert ops._wino_fwd_call is False
+            assert ops._decide_wino_fwd() is False
             ops._in_custom_op = False
             ops.WINOGRAD_EVAL = False
-            ops._decide_wino_fwd()
-            assert ops._wino_fwd_call is False
+            assert ops._decide_wino_fwd() is False
         with ops.winograd_forward():
             with ops.winograd_forward():
-                ops._decide_wino_fwd()
-                assert ops._wino_fwd_call is True
-            ops._decide_wino_fwd()
-            assert ops._wino_fwd_call is True
-        ops._decide_wino_fwd()
-        assert ops._wino_fwd_call is False
+                assert ops._decide_wino_fwd() is True
+            assert ops._decide_wino_fwd() is True
+        assert ops._decide_wino_fwd() is False
         ops.WINOGRAD_FWD = True
-        ops._decide_wino_fwd()
-        assert ops._wino_fwd_call is True
+        assert ops._decide_wino_fwd() is True
     finally:
         ops.WINOGRAD_FWD, ops.WINOGRAD_EVAL, ops._in_custom_op = saved
-        ops._decide_wino_fwd()
 
 
 def test_config_factory_mirrors_trainer_base(tmp_path):
