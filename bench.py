@@ -183,6 +183,7 @@ def main():
     torch.cuda.synchronize()
     timing = not args.no_kernel_timing
     if timing:
+        L.vqw_profile_families(0x1F)         # timed region: the five conv families only (see include/vqwnet_hip.h)
         _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
     from hipops import ops as _ops
     coll0 = (_ops.collective_calls, tr.reducer.launches if tr.reducer is not None else 0)
@@ -201,18 +202,19 @@ def main():
         print("[bench] %d timed steps: %.1f ms/step; device segments allocated inside the timed region: %d (+%.2f GB reserved)"
               % (args.steps, dt / args.steps * 1e3, ms1["segment.all.allocated"] - ms0["segment.all.allocated"],
                  (ms1["reserved_bytes.all.current"] - ms0["reserved_bytes.all.current"]) / 2**30), file=sys.stderr, flush=True)
-    prof = (ctypes.c_double * 20)()
+    prof = (ctypes.c_double * 24)()
     if timing:
         _lib.check(L.vqw_profile_end(prof), "vqw_profile_end")
     # Second, untimed look at the same kernels WITHOUT concurrency: in the timed region the weight-gradient kernels run
     # on a side stream next to the chain kernels, which stretches every kernel's own duration.  Two extra steps with
     # the side stream off give the kernels' exclusive durations (reported as roofline.exclusive).
-    prof_x = (ctypes.c_double * 20)()
+    prof_x = (ctypes.c_double * 24)()
     if timing and _ops.WGRAD_ASYNC:
         _ops.WGRAD_ASYNC = False
         cv, tr.concurrent_views = tr.concurrent_views, False
         step(0)
         torch.cuda.synchronize()
+        L.vqw_profile_families(0x3F)         # serialised pass: the HBM-bound norm / element-wise family as well
         _lib.check(L.vqw_profile_begin(), "vqw_profile_begin")
         for i in range(args.serial_steps):
             step(1 + i)
@@ -233,6 +235,7 @@ def main():
         # (the Winograd family's FLOPs are the 4/9 of the direct form's that the matrix cores execute: its TFLOP/s is
         # hardware utilisation like the others'; x 2.25 = the rate in direct-form FLOPs)
         fam = ["conv_mfma_fwd_dgrad", "conv_mfma_wgrad", "conv_generic_fwd", "conv_generic_wgrad", "conv_winograd"]
+        HBM_FAMILY = 5      # normalisation / element-wise entry points: bytes as launched, no FLOPs
 
         def families(pr, nsteps):
             out = {}
@@ -288,6 +291,19 @@ def main():
                          "stream run concurrently: a kernel's own duration then includes time its waves spend "
                          "sharing CUs with other kernels, so it under-states kernel quality; throughput (`value`) "
                          "is what the concurrency buys")
+        # the HBM-bound block of the step (InstanceNorm / SPADE forward and backward, ResBlock tails, ReLU backward, adds,
+        # pooling, Adam): the same HIP events, serialised pass; achieved = tensor passes as launched x 4 B / time
+        roofline_hbm = None
+        pr = prof_x if any(prof_x) else prof
+        nst = args.serial_steps if any(prof_x) else args.steps
+        if pr[4 * HBM_FAMILY] > 0:
+            n, ms, by = pr[4 * HBM_FAMILY], pr[4 * HBM_FAMILY + 1], pr[4 * HBM_FAMILY + 3]
+            roofline_hbm = dict(bound="hbm", family="norm_elementwise", launches_per_step=n / nst, ms_per_step=ms / nst,
+                                achieved=by / (ms * 1e-3) / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=by / (ms * 1e-3) / PEAK_HBM,
+                                bytes_per_step=by / nst,
+                                note="HIP events around the normalisation / element-wise entry points (vqw_inorm_*, vqw_spade_*, "
+                                     "vqw_res_tail_*, vqw_relu_bwd, vqw_add, vqw_maxpool2_*, vqw_adam_step); bytes = tensor passes "
+                                     "as launched; autograd's own at::add / fill kernels are outside these events")
         per_gpu = imgs / world
         scale = (args.size / 256.0) ** 2
         # FLOPs the kernels actually executed per step (collapsed up-sampled and Winograd-form convs at 4/9 of the reference's count), from the
@@ -314,6 +330,7 @@ def main():
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "collectives_per_step": {"statistics": (coll1[0] - coll0[0]) / args.steps, "gradient_buckets": (coll1[1] - coll0[1]) / args.steps},
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size)

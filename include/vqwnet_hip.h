@@ -39,13 +39,18 @@ int vqw_abi_version(void);
  * kernels").  Returns the previous mode. */
 int vqw_set_conv_backend(int mode);
 /* Measurement aid (bench.py roofline): HIP events recorded on the launch stream around every convolution kernel
- * family between begin and end.  end() synchronises on those events and fills out[5][4] =
- * {launches, total ms, total FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA wgrad, generic fwd, generic wgrad,
- * Winograd-form fwd/dgrad/wgrad}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of
- * the direct form's).
+ * family - and around the HBM-bound normalisation / element-wise entry points - between begin and end.  end() synchronises
+ * on those events and fills out[6][4] = {launches, total ms, total FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA
+ * wgrad, generic fwd, generic wgrad, Winograd-form fwd/dgrad/wgrad, HBM-bound norm / element-wise (bytes = tensor passes as
+ * launched)}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of the direct
+ * form's).  (ABI 6: the sixth family.)
  * Not meant for graph capture; off by default.                                                              */
 int vqw_profile_begin(void);
 int vqw_profile_end(double* out);
+/* Which families record events (bit f = family f; default all).  bench.py keeps the ~390 norm / element-wise launches of a
+ * step out of its TIMED region (two event records each would cost the step 2 %) and times them in the serialised pass.
+ * Returns the previous mask. */
+int vqw_profile_families(unsigned mask);
 
 /* ---- convolution: replaces F.conv2d fwd/bwd behind nn.Conv2d in
  *      networks/blocks.py:5-6,25,45,48,75,79,80,102,108,112,117; networks/aspp.py:19-24;

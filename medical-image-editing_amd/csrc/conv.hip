@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "conv_common.h"
+#include "prof.h"
 #include "../../include/vqwnet_hip.h"
 
 static int g_conv_backend = 0;  // 0 auto, 1 generic only
@@ -10,9 +11,9 @@ static int g_conv_backend = 0;  // 0 auto, 1 generic only
 // Optional per-launch timing of the convolution kernels (bench.py roofline): HIP events recorded on the SAME
 // stream right around each conv kernel family.  Off by default; nothing is recorded, allocated or synchronised
 // unless vqw_profile_begin() was called.  Families: 0 = MFMA fwd/dgrad, 1 = MFMA wgrad (incl. slab reduce),
-// 2 = generic fwd, 3 = generic wgrad, 4 = Winograd-form fwd/dgrad/wgrad (FLOPs = the 4/9 the matrix cores execute).
-#define PROF_MAX 16384
-#define PROF_FAMILIES 5
+// 2 = generic fwd, 3 = generic wgrad, 4 = Winograd-form fwd/dgrad/wgrad (FLOPs = the 4/9 the matrix cores execute),
+// 5 = HBM-bound normalisation / element-wise kernels (prof.h).
+#define PROF_MAX 32768
 static bool g_prof_on = false;
 static int g_prof_n = 0;
 static hipEvent_t* g_prof_ev = nullptr;   // 2 * PROF_MAX events
@@ -52,22 +53,22 @@ extern "C" int vqw_profile_end(double* out /*[PROF_FAMILIES][4]*/) {
     }
     return VQW_OK;
 }
-struct ProfScope {
-    int idx;
-    hipStream_t st;
-    ProfScope(int family, double flops, hipStream_t s, double bytes = 0.0) : idx(-1), st(s) {
-        if (g_prof_on && g_prof_n < PROF_MAX) {
-            idx = g_prof_n++;
-            g_prof_family[idx] = family;
-            g_prof_flops[idx] = flops;
-            g_prof_bytes[idx] = bytes;
-            (void)hipEventRecord(g_prof_ev[2 * idx], st);
-        }
-    }
-    ~ProfScope() {
-        if (idx >= 0) (void)hipEventRecord(g_prof_ev[2 * idx + 1], st);
-    }
-};
+static unsigned g_prof_mask = 0xFFFFFFFFu;
+extern "C" int vqw_profile_families(unsigned mask) {
+    const unsigned old = g_prof_mask;
+    g_prof_mask = mask;
+    return (int)old;
+}
+int vqw_prof_open(int family, double flops, double bytes, hipStream_t st) {
+    if (!g_prof_on || g_prof_n >= PROF_MAX || !((g_prof_mask >> family) & 1u)) return -1;
+    const int idx = g_prof_n++;
+    g_prof_family[idx] = family;
+    g_prof_flops[idx] = flops;
+    g_prof_bytes[idx] = bytes;
+    (void)hipEventRecord(g_prof_ev[2 * idx], st);
+    return idx;
+}
+void vqw_prof_close(int idx, hipStream_t st) { (void)hipEventRecord(g_prof_ev[2 * idx + 1], st); }
 extern "C" int vqw_set_conv_backend(int mode) {
     int old = g_conv_backend == 1 ? 1 : (g_halo_mode ? 2 : (g_wino_mode ? 3 : 0));
     g_conv_backend = mode == 1 ? 1 : 0;

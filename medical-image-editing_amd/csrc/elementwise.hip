@@ -1,5 +1,6 @@
 // Element-wise, pooling, scalar-loss and optimiser kernels (HBM-bound; float4 streams).
 #include "common.h"
+#include "prof.h"
 #include "../../include/vqwnet_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -10,7 +11,7 @@ extern "C" void vqw_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vqw_last_error(void) { return g_err; }
-extern "C" int vqw_abi_version(void) { return 5; }
+extern "C" int vqw_abi_version(void) { return 6; }
 
 // ---------------------------------------------------------------------------------------------
 template <int RELU>
@@ -30,6 +31,7 @@ __global__ void k_add(const float* __restrict__ a, const float* __restrict__ b, 
 }
 
 extern "C" int vqw_add(const float* a, const float* b, float* y, long n, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 3, n);
     VQW_CHECK(a && b && y && n > 0, "vqw_add: bad arguments");
     VQW_CHECK((((uintptr_t)a | (uintptr_t)b | (uintptr_t)y) & 15) == 0, "vqw_add: pointers must be 16-byte aligned");
     int g = stream_grid((n + 3) / 4, 256);
@@ -45,6 +47,7 @@ __global__ void k_relu_bwd(const float* __restrict__ y, const float* __restrict_
         gx[i] = y[i] > 0.f ? gy[i] : 0.f;
 }
 extern "C" int vqw_relu_bwd(const float* y, const float* gy, float* gx, long n, void* stream) {
+    VQW_PROF_HBM(stream, 3, n);
     VQW_CHECK(y && gy && gx && n > 0, "vqw_relu_bwd: bad arguments");
     k_relu_bwd<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(y, gy, gx, n);
     VQW_LAUNCH_CHECK("vqw_relu_bwd");
@@ -76,6 +79,7 @@ __global__ void k_maxpool2_fwd(const float* __restrict__ x, float* __restrict__ 
     }
 }
 extern "C" int vqw_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    VQW_PROF_HBM(stream, 1.25, (double)N * H * W * C);
     VQW_CHECK(x && y && N > 0 && C > 0 && H >= 2 && W >= 2, "vqw_maxpool2_fwd: bad arguments (N=%d H=%d W=%d C=%d)", N, H, W, C);
     long total = (long)N * (H / 2) * (W / 2) * C;
     k_maxpool2_fwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, y, N, H, W, C);
@@ -117,6 +121,7 @@ __global__ void k_maxpool2_bwd(const float* __restrict__ x, const float* __restr
 }
 extern "C" int vqw_maxpool2_bwd(const float* x, const float* gy, const float* g_skip, float* gx,
                                 int N, int H, int W, int C, void* stream) {
+    VQW_PROF_HBM(stream, 2.25, (double)N * H * W * C);
     VQW_CHECK(x && gy && gx && N > 0 && C > 0 && H >= 2 && W >= 2, "vqw_maxpool2_bwd: bad arguments");
     long total = (long)N * H * W * C;
     k_maxpool2_bwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(x, gy, g_skip, gx, N, H, W, C);
@@ -202,6 +207,7 @@ __global__ void __launch_bounds__(256) k_res_tail_fwd4(const float4* __restrict_
 }
 extern "C" int vqw_res_tail_fwd(const float* a, const float* b, float* out, float* pooled, int N, int H, int W, int C,
                                 void* stream) {
+    VQW_PROF_HBM(stream, 3.25, (double)N * H * W * C);
     VQW_CHECK(a && b && out && pooled && N > 0 && C > 0, "vqw_res_tail_fwd: bad arguments");
     VQW_CHECK((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0 && H >= 2 && W >= 2, "vqw_res_tail_fwd: needs even H, W and C %% 4 == 0");
     VQW_CHECK(((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)pooled) & 15) == 0), "vqw_res_tail_fwd: 16-byte alignment");
@@ -251,6 +257,7 @@ __global__ void __launch_bounds__(256) k_res_tail_norm_fwd4(const float4* __rest
 }
 extern "C" int vqw_res_tail_norm_fwd(const float* x2, const float* mr2, const float* xid, const float* mrid, float* out,
                                      float* pooled, int N, int H, int W, int C, void* stream) {
+    VQW_PROF_HBM(stream, 3.25, (double)N * H * W * C);
     VQW_CHECK(x2 && mr2 && xid && mrid && out && pooled && N > 0 && C > 0, "vqw_res_tail_norm_fwd: bad arguments");
     VQW_CHECK((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0 && H >= 2 && W >= 2, "vqw_res_tail_norm_fwd: needs even H, W and C %% 4 == 0");
     VQW_CHECK(((((uintptr_t)x2 | (uintptr_t)xid | (uintptr_t)out | (uintptr_t)pooled | (uintptr_t)mr2 | (uintptr_t)mrid) & 15) == 0),
@@ -263,6 +270,7 @@ extern "C" int vqw_res_tail_norm_fwd(const float* x2, const float* mr2, const fl
 }
 extern "C" int vqw_res_tail_bwd(const float* out, const float* g_pooled, const float* g_out, float* gx, int N, int H, int W,
                                 int C, void* stream) {
+    VQW_PROF_HBM(stream, 3.25, (double)N * H * W * C);
     VQW_CHECK(out && gx && (g_pooled || g_out) && N > 0 && C > 0, "vqw_res_tail_bwd: bad arguments");
     VQW_CHECK((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0 && H >= 2 && W >= 2, "vqw_res_tail_bwd: needs even H, W and C %% 4 == 0");
     VQW_CHECK(((((uintptr_t)out | (uintptr_t)g_pooled | (uintptr_t)g_out | (uintptr_t)gx) & 15) == 0), "vqw_res_tail_bwd: 16-byte alignment");
@@ -504,6 +512,7 @@ extern "C" int vqw_adam_multi(const void* chunks_dev, int n_chunks, float lr, fl
 
 extern "C" int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, float bias_corr1, float bias_corr2, void* stream) {
+    VQW_PROF_HBM(stream, 7, n);
     VQW_CHECK(p && g && m && v && n > 0, "vqw_adam_step: bad arguments");
     VQW_CHECK(bias_corr1 > 0.f && bias_corr2 > 0.f, "vqw_adam_step: bias corrections must be positive");
     k_adam<<<stream_grid(n, 256), 256, 0, (hipStream_t)stream>>>(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,

@@ -4,6 +4,7 @@
 // part[n][split][c][2] (fixed pixel ranges per block, fixed tree inside the block), stage 2 sums the
 // partials in index order.  No float atomics -> bitwise reproducible run to run.
 #include "common.h"
+#include "prof.h"
 #include "../../include/vqwnet_hip.h"
 
 #define PLANE_MAX_SPLITS 64
@@ -301,6 +302,7 @@ __global__ void __launch_bounds__(256) k_inorm_finalize_parts(const float* __res
 }
 extern "C" int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, const float* part,
                                    int nparts, int N, int HW, int C, float eps, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 2, (double)N * HW * C);
     VQW_CHECK(x && y && mean_rstd && part && nparts > 0 && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd_parts: bad arguments");
     VQW_CHECK(y_coff >= 0 && y_coff + C <= y_cstride, "vqw_inorm_fwd_parts: output channel slice [%d,%d) outside stride %d", y_coff, y_coff + C, y_cstride);
     hipStream_t st = (hipStream_t)stream;
@@ -343,6 +345,7 @@ extern "C" int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_
 
 extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, void* ws,
                              size_t ws_bytes, int N, int HW, int C, float eps, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 3, (double)N * HW * C);
     VQW_CHECK(x && y && mean_rstd && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_fwd: bad arguments");
     VQW_CHECK(y_coff >= 0 && y_coff + C <= y_cstride, "vqw_inorm_fwd: output channel slice [%d,%d) outside stride %d", y_coff, y_coff + C, y_cstride);
     VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_inorm_fwd: workspace too small");
@@ -423,6 +426,7 @@ __global__ void k_inorm_bwd_apply(const float* __restrict__ x, const float* __re
 
 extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
                              float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 5, (double)N * HW * C);
     VQW_CHECK(x && mean_rstd && gy && gx && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_bwd: bad arguments");
     VQW_CHECK(gy_coff >= 0 && gy_coff + C <= gy_cstride, "vqw_inorm_bwd: gradient channel slice outside stride");
     size_t need = vqw_plane_ws_bytes(N, C, HW);
@@ -560,6 +564,7 @@ __global__ void k_inorm_bwd_pair_apply4(const float4* __restrict__ xa, const flo
 // a: InstanceNorm + ReLU, b: InstanceNorm; both get gy.  ws: 2 x vqw_plane_ws_bytes(N, C, HW).
 extern "C" int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float* xb, const float* mrb, const float* gy, float* gxa,
                                   float* gxb, void* ws, size_t ws_bytes, int N, int HW, int C, void* stream) {
+    VQW_PROF_HBM(stream, 8, (double)N * HW * C);
     VQW_CHECK(xa && mra && xb && mrb && gy && gxa && gxb && ws && N > 0 && HW > 0 && C > 0, "vqw_inorm_bwd_pair: bad arguments");
     VQW_CHECK((C & 3) == 0, "vqw_inorm_bwd_pair: C %% 4 == 0");
     VQW_CHECK(((((uintptr_t)xa | (uintptr_t)xb | (uintptr_t)gy | (uintptr_t)gxa | (uintptr_t)gxb | (uintptr_t)mra | (uintptr_t)mrb) & 15) == 0),
@@ -642,6 +647,7 @@ extern "C" int vqw_bn_stats_from_parts(const float* part, double* sums, int rows
 
 extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size_t ws_bytes, int N, int HW, int C,
                                     void* stream) {
+    VQW_PROF_HBM(stream, 1, (double)N * HW * C);
     VQW_CHECK(x && sums && ws && N > 0 && HW > 0 && C > 0, "vqw_bn_partial_stats: bad arguments");
     VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_bn_partial_stats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -734,6 +740,7 @@ __global__ void __launch_bounds__(256) k_spade_fwd4(const float4* __restrict__ x
 // y = act(spade(x)) + res: the block's final `shortcut + main` (blocks.py:134) inside the last modulation kernel
 extern "C" int vqw_spade_fwd_res(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
                                  const float* res, float* y, long P, int C, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 5, (double)P * C);
     VQW_CHECK(x && mean_rstd && gamma && beta && res && y && P > 0 && C > 0 && gb_stride >= C, "vqw_spade_fwd_res: bad arguments");
     VQW_CHECK((C & 3) == 0 && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(y) && al16(mean_rstd) && al16(res),
               "vqw_spade_fwd_res: needs C %% 4 == 0 and 16-byte aligned tensors");
@@ -746,6 +753,7 @@ extern "C" int vqw_spade_fwd_res(const float* x, const float* mean_rstd, const f
 }
 extern "C" int vqw_spade_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
                              float* y, long P, int C, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 4, (double)P * C);
     VQW_CHECK(x && mean_rstd && gamma && beta && y && P > 0 && C > 0 && gb_stride >= C, "vqw_spade_fwd: bad arguments");
     long total = P * C;
     hipStream_t st = (hipStream_t)stream;
@@ -790,6 +798,7 @@ struct FSpadeBwd {
 extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                                     const float* gy, float* dgamma, float* dbeta, int gb_stride, double* sums, void* ws,
                                     size_t ws_bytes, int N, int HW, int C, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 6, (double)N * HW * C);
     VQW_CHECK(x && mean_rstd && gamma && beta && gy && dgamma && dbeta && sums && ws && N > 0 && HW > 0 && C > 0 &&
                   gb_stride >= C, "vqw_spade_bwd_reduce: bad arguments");
     VQW_CHECK(ws_bytes >= vqw_plane_ws_bytes(N, C, HW), "vqw_spade_bwd_reduce: workspace too small");
@@ -881,6 +890,7 @@ __global__ void __launch_bounds__(256) k_spade_bwd_apply4(const float4* __restri
 extern "C" int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
                                    const float* gy, const double* sums, double count, float* gx, long P, int C,
                                    int relu, int training, void* stream) {
+    VQW_PROF_HBM(stream, 4, (double)P * C);
     VQW_CHECK(x && mean_rstd && gamma && beta && gy && gx && P > 0 && C > 0 && gb_stride >= C, "vqw_spade_bwd_apply: bad arguments");
     VQW_CHECK(!training || (sums && count > 0), "vqw_spade_bwd_apply: training needs sums and count");
     long total = P * C;

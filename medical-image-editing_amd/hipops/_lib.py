@@ -25,6 +25,7 @@ SIGNATURES = {
     "vqw_set_conv_backend": (c_i, [c_i]),
     "vqw_profile_begin": (c_i, []),
     "vqw_profile_end": (c_i, [c_p]),
+    "vqw_profile_families": (c_i, [ctypes.c_uint]),
     "vqw_conv2d_fwd": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_pack_dgrad_weights": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "vqw_conv2d_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i]),
@@ -127,7 +128,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def load():
