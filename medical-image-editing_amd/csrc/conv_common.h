@@ -56,9 +56,9 @@ bool conv_wino_ok(int Cin, int Cout, int N, int H, int W);
 size_t conv_wino_ws_floats(int Cin, int Cout);
 int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st);
 int conv_wino_stat_tiles(int Cin, int Cout, int H, int W);
-// ... with a 64-cout workgroup tile for Cout % 64 == 0, Cin % 16 == 0 (conv_wino64.hip; same weight layout)
-bool conv_wino64_ok(int Cin, int Cout);
-int conv_wino64_stat_tiles(int H, int W);
+// ... on the low-VALU kernel of conv_wino64.hip: 64-cout tile (Cout % 64 == 0) or two M blocks x 32 couts (Cout % 32 == 0, W % 32 == 0)
+bool conv_wino64_ok(int Cin, int Cout, int W);
+int conv_wino64_stat_tiles(int Cin, int Cout, int H, int W);
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
                     hipStream_t st, float* stats = nullptr);
 int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,

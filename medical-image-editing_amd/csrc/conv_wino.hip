@@ -43,7 +43,7 @@ static const int g_wino_env = env_int("VQW_WINOGRAD", 1);
 static const int g_max_blocks = []{ int v = env_int("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
 
 // U[xi = i*4 + j][co][ci] = sum_{ky,kx} G[i][ky] g[co][ky][kx][ci] G[j][kx],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
-// chunked = 1: [ci / 8][xi][co][ci % 8] - what the 64-cout kernel streams: the 64 couts of a (chunk, xi) are 2 KB in a row
+// chunked = 1: [ci / 8][xi][co][ci % 8] - what the kernels stream: the couts of a (chunk, xi) lie in a row, 32 bytes each
 __global__ void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int chunked) {
     const long n = (long)Cout * Cin;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
         const int xi = row >> 5, n = row & 31;
         const int co = co_base + n;
         u_lds[j] = row * WN_KPU + c4 * 4;
-        u_off[j] = co < Cout ? (((unsigned)xi * Cout + co) * (unsigned)Cin + c4 * 4) * 4u : 0xFFFFFFFFu;
+        u_off[j] = co < Cout ? (((unsigned)xi * Cout + co) * 8u + c4 * 4) * 4u : 0xFFFFFFFFu;       // chunked layout [Cin / 8][xi][Cout][8]
     }
 
     float4 rh[LH], ru[LW];
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
         const unsigned pix = i_img + (unsigned)(yy * W + xx);
         rh[j] = buf_ld4(rsx, sel_u32(ok, pix * (unsigned)Cin * 4u + i_cc4 + h_c * 4u, a.nbx));
     };
-    auto issue_u = [&](int j) { ru[j] = buf_ld4(rsu, sel_u32(u_off[j] == 0xFFFFFFFFu, a.nbu, u_off[j] + i_cc4)); };
+    auto issue_u = [&](int j) { ru[j] = buf_ld4(rsu, sel_u32(u_off[j] == 0xFFFFFFFFu, a.nbu, u_off[j] + (i_cc4 >> 5) * (16u * (unsigned)Cout * 32u))); };
     auto commit_h = [&](int j, int buf) {       // a halo pixel is 40 bytes: two 8-byte-aligned halves
         float* p = &Hs[(h_st[j] ? buf : 0) + h_lds[j]];
         f32x2 lo, hi;
@@ -468,12 +468,12 @@ bool conv_wino_ok(int Cin, int Cout, int N, int H, int W) {
 size_t conv_wino_ws_floats(int Cin, int Cout) { return (size_t)16 * Cout * Cin; }
 int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st) {
     const long n = (long)Cout * Cin;
-    k_wino_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, u, Cout, Cin, conv_wino64_ok(Cin, Cout) ? 1 : 0);
+    k_wino_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, u, Cout, Cin, 1);      // every kernel streams the chunked layout
     VQW_LAUNCH_CHECK("wino_weights");
     return VQW_OK;
 }
 int conv_wino_stat_tiles(int Cin, int Cout, int H, int W) {
-    if (conv_wino64_ok(Cin, Cout)) return conv_wino64_stat_tiles(H, W);
+    if (conv_wino64_ok(Cin, Cout, W)) return conv_wino64_stat_tiles(Cin, Cout, H, W);
     const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? 16 : 32;
     return H % tr == 0 ? (H / tr) * (W / rw) : 0;
 }
@@ -495,7 +495,7 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
             return VQW_OK;
         }
     }
-    if (conv_wino64_ok(Cin, Cout)) return conv_wino64_fwd(x, u, bias, y, N, H, W, Cin, Cout, relu, st, stats);
+    if (conv_wino64_ok(Cin, Cout, W)) return conv_wino64_fwd(x, u, bias, y, N, H, W, Cin, Cout, relu, st, stats);
     const bool wide = W % 32 == 0;
     const size_t lds = (size_t)(3 * (wide ? WinoGeo<32>::HBUF : WinoGeo<16>::HBUF) + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
     static_assert((size_t)(3 * WinoGeo<16>::HBUF + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float) <= 160 * 1024, "Winograd buffers do not fit the 160 KB LDS");

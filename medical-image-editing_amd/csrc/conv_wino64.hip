@@ -58,15 +58,25 @@ struct W64Args {
 };
 
 constexpr int W6_KPH = 10;                 // floats per halo pixel in LDS (8 channels + 2: conflict-free ds_read_b64 patches)
-constexpr int W6_UBUF = 16 * 64 * 8;       // floats per U chunk: [xi][64 couts][8 channels], float4 halves swizzled by cout bit 3
-// Region geometry, RW = region width: 8 rows x 32 columns (halo 10 x 34), or - for maps whose width is a multiple of 16 only
-// (the 16 x 16 level) - 16 x 16 (halo 18 x 18, LDS row stride 24 pixels: the two tile rows of an M block then land on
-// complementary banks).  64 tiles per region either way.
-template <int RW> struct W64Geo {
-    static constexpr int TR = RW == 32 ? 8 : 16;
+// Workgroup shapes.  MBW = M blocks (of 16 tiles) per wave, NBW = 4 / MBW N blocks (of 16 couts) per wave:
+//   MBW = 1: 64 tiles x 64 couts (Cout % 64 == 0): 32 transform VALU per 64 MFMAs;
+//   MBW = 2: 128 tiles x 32 couts (Cout % 32 == 0, widths that are multiples of 32): 64 per 64 MFMAs - what a 32-cout
+//            tile costs in any layout - but none of the 32-cout kernel's address arithmetic, accumulator zeroing and
+//            post-barrier bubbles.
+// Region geometry, RW = region width: 8 MBW rows x 32 columns (halo rows x 34), or - for maps whose width is a multiple of
+// 16 only (the 16 x 16 level, MBW = 1) - 16 x 16 (halo 18 x 18, LDS row stride 24 pixels: the two tile rows of an M block
+// then land on complementary banks).
+template <int RW, int MBW> struct W64Geo {
+    static_assert(MBW == 1 || (MBW == 2 && RW == 32), "two M blocks per wave: 32-wide regions only");
+    static constexpr int NBW = 4 / MBW;
+    static constexpr int NCO = 16 * NBW;                   // couts per workgroup
+    static constexpr int TR = RW == 32 ? 8 * MBW : 16;
     static constexpr int HR = TR + 2, HWV = RW + 2;
     static constexpr int HWS = RW == 32 ? 34 : 24;
     static constexpr int HBUF = HR * HWS * W6_KPH;
+    static constexpr int UBUF = 16 * NCO * 8;              // floats per U chunk: [xi][couts][8 channels], float4 halves swizzled by cout bit 3
+    static constexpr int EXF = 16384;                      // exchange area of the region epilogue: 64 KB
+    static constexpr size_t LDS_FLOATS = 2 * HBUF + UBUF + EXF + 2 * 4 * NCO * 2;
 };
 #ifdef W6_EXP_NO_BARRIER
 #define W6_ITEM_BARRIER() do {} while (0)
@@ -78,29 +88,27 @@ template <int RW> struct W64Geo {
 #endif
 constexpr int W6_CP = 26;                  // MFMA position of the first LDS commit of the prefetched data
 
-template <int RW>
+template <int RW, int MBW>
 __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
-    using G = W64Geo<RW>;
-    constexpr int NT = 512;
-    constexpr int HWS = G::HWS, HWV = G::HWV, HBUF = G::HBUF, UBUF = W6_UBUF;
-    constexpr int HPIX = G::HR * HWV;          // 340 / 324 halo pixels
-    constexpr int HF = HPIX * 2;               // float4 per halo chunk: 680 / 648
-    static_assert(HF > NT && HF <= 2 * NT, "two halo slots per thread");
+    using G = W64Geo<RW, MBW>;
+    constexpr int NT = 512, NBW = G::NBW, NCO = G::NCO;
+    constexpr int HWS = G::HWS, HWV = G::HWV, HBUF = G::HBUF, UBUF = G::UBUF;
+    constexpr int HPIX = G::HR * HWV;          // 340 / 324 / 612 halo pixels
+    constexpr int HF = HPIX * 2;               // float4 per halo chunk: 680 / 648 / 1224
+    constexpr int LH = (HF + NT - 1) / NT;     // 2 / 2 / 3 halo slots per thread
+    constexpr int LU = NBW;                    // U slots per thread: 512 NBW float4 per chunk
+    static_assert(HF > (LH - 1) * NT && HF >= NT, "every halo slot but the last is full");
+    static_assert(1 + (LH + LU) * W6_LS <= W6_CP && W6_CP + LH + LU <= 32, "prefetch slots fit the first half of an item");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                      // [2][HBUF]
     float* Us = smem + 2 * HBUF;           // [2][UBUF]
-    float* Ex = Us + UBUF;                 // exchange area of the region epilogue: U buffer 1 (dead by then) + 32 KB
-    float* Rs = Us + 3 * UBUF;             // [2][4 M blocks][64 couts][2] statistics of the waves' 64 pixels
+    float* Ex = Us + UBUF;                 // exchange area of the region epilogue (64 KB): U buffer 1 (dead by then) + spare
+    float* Rs = Ex + G::EXF;               // [2][4 waves of a half][NCO couts][2] statistics of the waves' pixels
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: scalar branches on h
     const int mb = wv & 3, h = wv >> 2;
-#if defined(W6_PRIO) && W6_PRIO == 1
-    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
-#elif defined(W6_PRIO) && W6_PRIO == 2
-    if (wv < 4) __builtin_amdgcn_s_setprio(1);
-#endif
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
 
@@ -108,51 +116,51 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = lb % ntn;
     const int sp0 = (lb / ntn) * a.kt;
-    const int co_base = tile_n * 64;
+    const int co_base = tile_n * NCO;
     const int my_tiles = min(a.kt, a.nsp - sp0);
-    const int nitems = my_tiles * nch;
     const int per_img = a.tilesY * a.tilesX;
-    if (nitems <= 0) return;               // uniform per workgroup
+    if (my_tiles <= 0) return;             // uniform per workgroup
 
     // ---- loader slots (fixed per thread) ----
-    // halo float4 f -> halo pixel f / 2, channel quad f % 2; slot 1 of the threads past the end repeats another thread's
-    // slot 0 (same address, same data: a benign duplicate instead of a masked store)
-    int h_lds[2];
-    int h_yx;                              // (hy0, hx0, hy1, hx1) packed in bytes
+    // halo float4 f -> halo pixel f / 2, channel quad f % 2; the last slot of the threads past the end repeats another
+    // thread's slot (same address, same data: a benign duplicate instead of a masked store)
     const int c4 = tid & 1;
-    {
-        int pk = 0;
+    auto halo_pixel = [&](int j, int& hy, int& hx) {       // (recomputed where needed: a division by a constant, no register held)
+        int f = tid + j * NT;
+        if (f >= HF) f -= HF;
+        const int hp = f >> 1;
+        hy = hp / HWV;
+        hx = hp - hy * HWV;
+    };
+    int h_lds[LH];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int f = tid + j * NT;
-            if (f >= HF) f -= HF;
-            const int hp = f >> 1, hy = hp / HWV, hx = hp - hy * HWV;
-            h_lds[j] = (hy * HWS + hx) * W6_KPH + c4 * 4;
-            pk |= (hy | (hx << 8)) << (16 * j);
-        }
-        h_yx = pk;
+    for (int j = 0; j < LH; ++j) {
+        int hy, hx;
+        halo_pixel(j, hy, hx);
+        h_lds[j] = (hy * HWS + hx) * W6_KPH + c4 * 4;
     }
-    unsigned h_voff[2];                    // byte offsets of the two slots in the region whose halo is fetched next
+    unsigned h_voff[LH];                   // byte offsets of the slots in the region whose halo is fetched next
     auto region_offsets = [&](int n, int tx, int ty) {
         const int y0 = ty * G::TR - 1, x0 = tx * RW - 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int hy = (h_yx >> (16 * j)) & 0xff, hx = (h_yx >> (16 * j + 8)) & 0xff;
+        for (int j = 0; j < LH; ++j) {
+            int hy, hx;
+            halo_pixel(j, hy, hx);
             const int yy = y0 + hy, xx = x0 + hx;
             const bool ok = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
             const unsigned pix = ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
             h_voff[j] = sel_u32(ok, pix * (unsigned)Cin * 4u + (unsigned)c4 * 16u, 0xFFFFFFFFu);
         }
     };
-    // U float4 f = tid + 512 j -> row = xi * 64 + n = (tid >> 1) + 256 j, channel quad tid & 1
-    const int u_n = (tid >> 1) & 63;
-    // (a wave's slot = 32 couts x 32 bytes = 1 KB in a row of the chunked layout)
-    const unsigned u_voff = (((unsigned)(tid >> 7) * Cout + co_base + u_n) * 8u + c4 * 4) * 4u;
-    const unsigned u_jstride = 4u * Cout * 32u;                            // 4 xi further per slot
+    // U float4 f = tid + 512 j -> row = xi * NCO + n = (tid >> 1) + 256 j, channel quad tid & 1
+    // (a wave's slot = 32 couts x 32 bytes = 1 KB in a row of the chunked layout [Cin / 8][16 xi][Cout][8])
+    const int u_n = (tid >> 1) & (NCO - 1);
+    const unsigned u_voff = (((unsigned)(tid >> 1) / NCO * Cout + co_base + u_n) * 8u + c4 * 4) * 4u;
+    const unsigned u_jstride = (256u / NCO) * Cout * 32u;                  // 256 rows = 256 / NCO xi further per slot
     const unsigned u_cstride = 16u * Cout * 32u;                           // per 8-channel chunk
     const int u_lds = (tid >> 1) * 8 + ((c4 ^ ((u_n >> 3) & 1)) * 4);      // + j * 2048 floats
 
-    float4 rh[2], ru[4];
+    float4 rh[LH], ru[LU];
     auto issue_h = [&](int j, int chunk) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)h_voff[j], chunk * 32, 0);
         unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
@@ -201,15 +209,17 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     // (sg * C is exact, so the fma rounds once like the add / sub it stands for); xi row 3 arrives negated, which the
     // epilogue's h = 1 branch folds into its signs.
     const int rA = h ? 3 : 0, rB = h ? 2 : 1, rC = h ? 1 : 2;
-    const int prow = RW == 32 ? 2 * mb : 2 * (2 * mb + (m >> 3)), pcol = RW == 32 ? 2 * m : 2 * (m & 7);
+    // M block (mb, mbw) of the wave: RW = 32: tile row MBW mb + mbw, columns m; RW = 16: tile rows 2 mb + (m >> 3), columns m & 7
+    const int prow = RW == 32 ? 2 * MBW * mb : 2 * (2 * mb + (m >> 3)), pcol = RW == 32 ? 2 * m : 2 * (m & 7);
+    constexpr int MBW_STEP = 2 * HWS * W6_KPH;             // the wave's second M block: one tile row = two halo rows further
     auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };     // distinct base registers: no ds_read2 merging
     const int a_A = opaque(((prow + rA) * HWS + pcol) * W6_KPH + 2 * q);
     const int a_B = opaque(((prow + rB) * HWS + pcol) * W6_KPH + 2 * q);
     const int a_C = opaque(((prow + rC) * HWS + pcol) * W6_KPH + 2 * q);
     // local xi row 0 = eP: xi row (h ? 3 : 0); local row 1 = eQ: xi row (h ? 2 : 1)
     const int b_swz = ((q >> 1) ^ (m >> 3)) * 4 + (q & 1) * 2;
-    const int b_0 = opaque(((h ? 3 : 0) * 4 * 64 + m) * 8 + b_swz);        // + (cc * 64 + nb * 16) * 8
-    const int b_1 = opaque(((h ? 2 : 1) * 4 * 64 + m) * 8 + b_swz);
+    const int b_0 = opaque(((h ? 3 : 0) * 4 * NCO + m) * 8 + b_swz);       // + (cc * NCO + nb * 16) * 8
+    const int b_1 = opaque(((h ? 2 : 1) * 4 * NCO + m) * 8 + b_swz);
     // sg, mone live in VGPRs the compiler cannot see through: an SGPR operand costs 1.5 x, and a literal -1 would turn the
     // fma back into a subtraction that the vector combiner pairs into v_pk_add_f32 over the two channels of a ds_read_b64
     // (10-15 pipe cycles instead of 2 x 4.4)
@@ -217,56 +227,78 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     { float s = h ? -1.f : 1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(sg) : "v"(s)); }
     { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
 
-    f32x4 acc[8][4];
-    f32x2 bf[2][4];                    // B fragments: xi l in bf[l & 1]; those of an item's last xi cross the barrier
+    f32x4 acc[8][MBW][NBW];
+    f32x2 bf[2][NBW];                  // B fragments: xi l in bf[l & 1]; those of an item's last xi cross the barrier
     f32x2 dcol[2][3];                  // two patch columns in flight: rows A, B, C
-    float e[2][2][4];                  // [channel of the pair][local row][column] after the column pass
-    float v[2][2][8];                  // [parity of the item][channel of the pair][local xi = local row * 4 + column]
+    float e[2][2][4];                  // [channel of the pair][local row][column] after the column pass (one M block at a time)
+    float v[2][MBW][2][8];             // [parity of the item][M block][channel of the pair][local xi = local row * 4 + column]
 
-    auto read_col = [&](const float* Hb, int c) {
-        const float* Hc = Hb + c * W6_KPH;
+    // The input transform of an item = MBW x (16 column operations, 16 row operations), one M block after the other:
+    // operation o of M block w.  Column pass: column o >> 2, (channel, local row) = o & 3; row pass: o - 16.
+    auto read_col = [&](const float* Hb, int w, int c) {
+        const float* Hc = Hb + w * MBW_STEP + c * W6_KPH;
         dcol[c & 1][0] = *(const f32x2*)&Hc[a_A];
         dcol[c & 1][1] = *(const f32x2*)&Hc[a_B];
         dcol[c & 1][2] = *(const f32x2*)&Hc[a_C];
     };
-    auto col_op = [&](int c, int k) {          // k = 0..3: channel k >> 1, local row k & 1
-        const int t = k >> 1;
-        const float dA = dcol[c & 1][0][t], dB = dcol[c & 1][1][t], dC = dcol[c & 1][2][t];
-        if ((k & 1) == 0) e[t][0][c] = __builtin_fmaf(mone, dC, dA);
-        else e[t][1][c] = __builtin_fmaf(sg, dC, dB);
+    auto xform_op = [&](int par, int w, int o) {
+        if (o < 16) {
+            const int c = o >> 2, k = o & 3, t = k >> 1;
+            const float dA = dcol[c & 1][0][t], dB = dcol[c & 1][1][t], dC = dcol[c & 1][2][t];
+            if ((k & 1) == 0) e[t][0][c] = __builtin_fmaf(mone, dC, dA);
+            else e[t][1][c] = __builtin_fmaf(sg, dC, dB);
+        } else {
+            const int k = o - 16, lr = k >> 3, t = (k >> 2) & 1, cc = k & 3;
+            const float e0 = e[t][lr][0], e1 = e[t][lr][1], e2 = e[t][lr][2], e3 = e[t][lr][3];
+            v[par][w][t][lr * 4 + cc] = cc == 0 ? e0 - e2 : cc == 1 ? e1 + e2 : cc == 2 ? e2 - e1 : e1 - e3;
+        }
     };
-    auto row_op = [&](int par, int k) {        // k = 0..15: local row k >> 3, channel (k >> 2) & 1, column k & 3
-        const int lr = k >> 3, t = (k >> 2) & 1, cc = k & 3;
-        const float e0 = e[t][lr][0], e1 = e[t][lr][1], e2 = e[t][lr][2], e3 = e[t][lr][3];
-        v[par][t][lr * 4 + cc] = cc == 0 ? e0 - e2 : cc == 1 ? e1 + e2 : cc == 2 ? e2 - e1 : e1 - e3;
+    // what the transform does beside MFMA position p of an item (reads three positions ahead of a column's first operation);
+    // MBW = 1: positions 32..63; MBW = 2: operation g = 32 w + o at position g + 4, the last four doubled up at 60..63
+    auto xform_slot = [&](const float* Hn, int par, int p) {
+        constexpr int NOPS = 32 * MBW, P0 = MBW == 1 ? 32 : 4;
+        auto op = [&](int g) { xform_op(par, g >> 5, g & 31); };
+        auto rd = [&](int g) {         // the read that must be in flight before operation g: column (g & 31) >> 2 of M block g >> 5
+            if ((g & 31) < 16 && ((g & 31) & 3) == 0) read_col(Hn, g >> 5, (g & 31) >> 2);
+        };
+        // reads: for the column whose first operation sits at position p + 3
+        if (p + 3 - P0 >= 0 && p + 3 - P0 < NOPS) rd(p + 3 - P0);
+        if (p - P0 >= 0 && p - P0 < NOPS && p < 64) {
+            const int g = p - P0;
+            if (P0 + NOPS <= 64 || g < NOPS - 2 * (P0 + NOPS - 64)) op(g);
+            else { const int d = g - (NOPS - 2 * (P0 + NOPS - 64)); op(NOPS - 2 * (P0 + NOPS - 64) + 2 * d); op(NOPS - 2 * (P0 + NOPS - 64) + 2 * d + 1); }
+        }
     };
 
     // ---- prologue: halo of items 0 and 1, U chunk of item 0, operands of item 0 ----
     region_offsets(cn, ctx, cty);
-    issue_h(0, 0); issue_h(1, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) issue_u(j, 0);
-    commit_h(0, Hs); commit_h(1, Hs);
+    for (int j = 0; j < LH; ++j) issue_h(j, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) commit_u(j, Us);
+    for (int j = 0; j < LU; ++j) issue_u(j, 0);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) commit_h(j, Hs);
+#pragma unroll
+    for (int j = 0; j < LU; ++j) commit_u(j, Us);
     region_offsets(n1, tx1, ty1);
-    issue_h(0, ch1); issue_h(1, ch1);
-    commit_h(0, Hs + HBUF); commit_h(1, Hs + HBUF);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) issue_h(j, ch1);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) commit_h(j, Hs + HBUF);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        read_col(Hs, c);
+    for (int w = 0; w < MBW; ++w)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) col_op(c, k);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) row_op(0, k);
+        for (int o = 0; o < 32; ++o) {
+            if (o < 16 && (o & 3) == 0) read_col(Hs, w, o >> 2);
+            xform_op(0, w, o);
+        }
     __syncthreads();                   // halo buffer 0 is overwritten during item 0
     region_offsets(n2, tx2, ty2);
 
-    float bvv[2];                      // bias of the two N blocks this wave finalises: nb = 2 h, 2 h + 1
+    float bvv[NBW / 2];                // bias of the N blocks this wave finalises: nb = h NBW / 2 + i
 #pragma unroll
-    for (int i = 0; i < 2; ++i) bvv[i] = a.bias ? a.bias[co_base + (2 * h + i) * 16 + m] : 0.f;
+    for (int i = 0; i < NBW / 2; ++i) bvv[i] = a.bias ? a.bias[co_base + (h * (NBW / 2) + i) * 16 + m] : 0.f;
     const float lo = a.relu ? 0.f : -__builtin_inff();
     int spar = 0;
 
@@ -280,83 +312,77 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
         float* Hw = Hs + par * HBUF;
         float* Uw = Us + (par ^ 1) * UBUF;
         auto ldb = [&](int l, int nb) {
-            bf[l & 1][nb] = *(const f32x2*)&Uc[(l < 4 ? b_0 : b_1) + ((l & 3) * 64 + nb * 16) * 8];
+            bf[l & 1][nb] = *(const f32x2*)&Uc[(l < 4 ? b_0 : b_1) + ((l & 3) * NCO + nb * 16) * 8];
         };
         auto slot = [&](int p) {       // p = 0..63: MFMA position (compile-time after unrolling)
 #if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_HLOADS)      // timing-only A/B builds (tools/wino_ab.sh): wrong results
-            if (p >= 1 && p < 1 + 2 * W6_LS && (p - 1) % W6_LS == 0) issue_h((p - 1) / W6_LS, ch2);
-            if (p >= W6_CP && p < W6_CP + 2) commit_h(p - W6_CP, Hw);
+            if (p >= 1 && p < 1 + LH * W6_LS && (p - 1) % W6_LS == 0) issue_h((p - 1) / W6_LS, ch2);
+            if (p >= W6_CP && p < W6_CP + LH) commit_h(p - W6_CP, Hw);
 #endif
 #if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_ULOADS)
-            if (p >= 1 + 2 * W6_LS && p < 1 + 6 * W6_LS && (p - 1) % W6_LS == 0) issue_u((p - 1) / W6_LS - 2, ch1);
-            if (p >= W6_CP + 2 && p < W6_CP + 6) commit_u(p - W6_CP - 2, Uw);
+            if (p >= 1 + LH * W6_LS && p < 1 + (LH + LU) * W6_LS && (p - 1) % W6_LS == 0) issue_u((p - 1) / W6_LS - LH, ch1);
+            if (p >= W6_CP + LH && p < W6_CP + LH + LU) commit_u(p - W6_CP - LH, Uw);
 #endif
-#ifdef W6_EXP_NO_XFORM
-            if (true) return;
+#ifndef W6_EXP_NO_XFORM
+            xform_slot(Hn, par ^ 1, p);
 #endif
-            if (p == 29) read_col(Hn, 0);
-            if (p >= 32 && p < 48) {   // column pass: column (p - 32) / 4, one operation per position
-                const int c = (p - 32) >> 2, k = (p - 32) & 3;
-                if (k == 0 && c < 3) read_col(Hn, c + 1);
-                col_op(c, k);
-            }
-            if (p >= 48) row_op(par ^ 1, p - 48);
         };
         // The item's first B fragments are requested right behind the barrier; the eight MFMAs of the PREVIOUS item's last xi
         // (operands and fragments already in registers) run while they arrive - without them every wave of the workgroup
         // would sit through the LDS latency with an idle matrix pipe once per item.
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) { ldb(0, nb); __builtin_amdgcn_sched_barrier(0); }
+        for (int nb = 0; nb < NBW; ++nb) { ldb(0, nb); __builtin_amdgcn_sched_barrier(0); }
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        // MFMA j = 0..7 of an xi: M block j / (2 NBW), k-step (j / NBW) & 1, N block j % NBW (two MFMAs on one accumulator are
+        // NBW >= 2 positions apart)
         if (first) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) slot(p);
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[7][nb] = zero4;
+            for (int w = 0; w < MBW; ++w)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) acc[7][w][nb] = zero4;
         } else {
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    acc[7][nb] = MFMA16(v[par ^ 1][k][7], k == 0 ? bf[1][nb].x : bf[1][nb].y, acc[7][nb]);
-                    slot(k * 4 + nb);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int w = j / (2 * NBW), k = (j / NBW) & 1, nb = j % NBW;
+                acc[7][w][nb] = MFMA16(v[par ^ 1][w][k][7], k == 0 ? bf[1][nb].x : bf[1][nb].y, acc[7][w][nb]);
+                slot(j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int l = 0; l < 7; ++l) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
+            for (int j = 0; j < 8; ++j) {
+                const int w = j / (2 * NBW), k = (j / NBW) & 1, nb = j % NBW;
 #ifndef W6_EXP_NO_BREAD
-                    if (k == 0) ldb(l + 1, nb);          // (l = 6: the fragments of xi 7 stay in bf[1] for the next body)
+                if (j < NBW) ldb(l + 1, nb);             // (l = 6: the fragments of xi 7 stay in bf[1] for the next body)
 #endif
-                    acc[l][nb] = MFMA16(v[par][k][l], k == 0 ? bf[l & 1][nb].x : bf[l & 1][nb].y, (first && k == 0) ? zero4 : acc[l][nb]);
-                    slot(8 + l * 8 + k * 4 + nb);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                acc[l][w][nb] = MFMA16(v[par][w][k][l], k == 0 ? bf[l & 1][nb].x : bf[l & 1][nb].y, (first && k == 0) ? zero4 : acc[l][w][nb]);
+                slot(8 + l * 8 + j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     auto flush = [&]() {               // the last xi of a region's last item (odd parity)
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                acc[7][nb] = MFMA16(v[1][k][7], k == 0 ? bf[1][nb].x : bf[1][nb].y, acc[7][nb]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int w = j / (2 * NBW), k = (j / NBW) & 1, nb = j % NBW;
+            acc[7][w][nb] = MFMA16(v[1][w][k][7], k == 0 ? bf[1][nb].x : bf[1][nb].y, acc[7][w][nb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // Region epilogue of a wave (HH = its xi half): partial y = A^T M_h A over the wave's two xi rows for every (tile, cout)
-    // entry it holds; N blocks 2 HH, 2 HH + 1 are finalised here, the other two go to the partner wave (same mb, other h).
+    // entry it holds; N blocks HH NBW / 2 .. are finalised here, the others go to the partner wave (same mb, other h).
     // C/D layout (16x16): col = lane & 15 (cout), row = 4 (lane >> 4) + r (tile of the M block).
-    auto partial = [&](auto HH, int nb, int r, float* yv) {       // yv[a * 2 + b]
+    auto partial = [&](auto HH, int w, int nb, int r, float* yv) {       // yv[a * 2 + b]
         constexpr int hh = decltype(HH)::value;
         float p0[4], p1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float l0 = acc[j][nb][r], l1 = acc[4 + j][nb][r];
+            const float l0 = acc[j][w][nb][r], l1 = acc[4 + j][w][nb][r];
             if (hh == 0) { p0[j] = l0 + l1; p1[j] = l1; }          // local rows = m0, m1:   m0 + m1 | m1
             else { p0[j] = l1; p1[j] = l0 - l1; }                  // local rows = -m3, m2:  m2 | -m2 - m3
         }
@@ -365,73 +391,86 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
         yv[2] = (p1[0] + p1[1]) + p1[2];
         yv[3] = (p1[1] - p1[2]) - p1[3];
     };
-    // 1. the partner's two N blocks -> exchange area [(mb, destination h)][k = 0..7][lane] float4
+    // 1. the partner's N blocks -> exchange area [(mb, destination h)][k = 0..7][lane] float4, k = (w NBW / 2 + i) 4 + r
     auto epi_send = [&](auto HH) {
         constexpr int hh = decltype(HH)::value;
         float* Xo = Ex + (((mb * 2 + (hh ^ 1)) * 8) * 64 + lane) * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int w = 0; w < MBW; ++w)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float yv[4];
-                partial(HH, hh == 0 ? 2 + i : i, r, yv);
-                float4 o;
-                o.x = yv[0]; o.y = yv[1]; o.z = yv[2]; o.w = yv[3];
-                *(float4*)&Xo[(i * 4 + r) * 256] = o;
-            }
+            for (int i = 0; i < NBW / 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float yv[4];
+                    partial(HH, w, (hh ^ 1) * (NBW / 2) + i, r, yv);
+                    float4 o;
+                    o.x = yv[0]; o.y = yv[1]; o.z = yv[2]; o.w = yv[3];
+                    *(float4*)&Xo[((w * (NBW / 2) + i) * 4 + r) * 256] = o;
+                }
     };
-    // 2. own two N blocks: own partial + the partner's, bias / ReLU, statistics, stores
+    // 2. own N blocks: own partial + the partner's, bias / ReLU, statistics, stores
     auto epi_finish = [&](auto HH) {
         constexpr int hh = decltype(HH)::value;
         const float* Xi = Ex + (((mb * 2 + hh) * 8) * 64 + lane) * 4;
-        // tiles 4 q + r of M block mb: RW = 32: tile row mb, columns 4 q + r; RW = 16: tile row 2 mb + (q >> 1), columns 4 (q & 1) + r
-        const int yrow0 = cty * G::TR + (RW == 32 ? 2 * mb : 2 * (2 * mb + (q >> 1)));
-        const int xcol0 = ctx * RW + (RW == 32 ? 8 * q : 8 * (q & 1));
+        float st1[NBW / 2], st2[NBW / 2];      // statistics of the wave's pixels per finalised N block
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float yv[16];      // [r][a][b]
+        for (int w = 0; w < MBW; ++w) {
+            // tiles 4 q + r of M block (mb, w): RW = 32: tile row MBW mb + w, columns 4 q + r; RW = 16: tile row 2 mb + (q >> 1),
+            // columns 4 (q & 1) + r
+            const int yrow0 = cty * G::TR + (RW == 32 ? 2 * (MBW * mb + w) : 2 * (2 * mb + (q >> 1)));
+            const int xcol0 = ctx * RW + (RW == 32 ? 8 * q : 8 * (q & 1));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float own[4];
-                partial(HH, 2 * hh + i, r, own);
-                const float4 o = *(const float4*)&Xi[(i * 4 + r) * 256];
-                yv[r * 4 + 0] = fmaxf((own[0] + o.x) + bvv[i], lo);
-                yv[r * 4 + 1] = fmaxf((own[1] + o.y) + bvv[i], lo);
-                yv[r * 4 + 2] = fmaxf((own[2] + o.z) + bvv[i], lo);
-                yv[r * 4 + 3] = fmaxf((own[3] + o.w) + bvv[i], lo);
-            }
-            const unsigned co = (unsigned)(co_base + (2 * hh + i) * 16 + m);
+            for (int i = 0; i < NBW / 2; ++i) {
+                float yv[16];      // [r][a][b]
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa) {
-                const int yy = yrow0 + aa;
-                const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cout + co;
-                const int voff = (int)sel_u32(yy < H, base * 4u, 0xFFFFFFFFu);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
-            }
-            if (a.stats) {     // uniform: H % TR == 0 whenever statistics are requested
-                float t1, t2;
-                lane_stats<16>(yv, t1, t2);
-                stat_merge_eq(t1, t2, __shfl_xor(t1, 16, 64), __shfl_xor(t2, 16, 64), 1.f / 32.f);
-                stat_merge_eq(t1, t2, __shfl_xor(t1, 32, 64), __shfl_xor(t2, 32, 64), 1.f / 64.f);
-                if (lane < 16) {
-                    float* R = Rs + spar * (4 * 64 * 2) + (mb * 64 + (2 * hh + i) * 16 + lane) * 2;
-                    R[0] = t1;
-                    R[1] = t2;
+                for (int r = 0; r < 4; ++r) {
+                    float own[4];
+                    partial(HH, w, hh * (NBW / 2) + i, r, own);
+                    const float4 o = *(const float4*)&Xi[((w * (NBW / 2) + i) * 4 + r) * 256];
+                    yv[r * 4 + 0] = fmaxf((own[0] + o.x) + bvv[i], lo);
+                    yv[r * 4 + 1] = fmaxf((own[1] + o.y) + bvv[i], lo);
+                    yv[r * 4 + 2] = fmaxf((own[2] + o.z) + bvv[i], lo);
+                    yv[r * 4 + 3] = fmaxf((own[3] + o.w) + bvv[i], lo);
                 }
+                const unsigned co = (unsigned)(co_base + (hh * (NBW / 2) + i) * 16 + m);
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) {
+                    const int yy = yrow0 + aa;
+                    const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cout + co;
+                    const int voff = (int)sel_u32(yy < H, base * 4u, 0xFFFFFFFFu);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+                }
+                if (a.stats) {     // uniform: H % TR == 0 whenever statistics are requested
+                    float t1, t2;
+                    lane_stats<16>(yv, t1, t2);
+                    stat_merge_eq(t1, t2, __shfl_xor(t1, 16, 64), __shfl_xor(t2, 16, 64), 1.f / 32.f);
+                    stat_merge_eq(t1, t2, __shfl_xor(t1, 32, 64), __shfl_xor(t2, 32, 64), 1.f / 64.f);
+                    if (w == 0) { st1[i] = t1; st2[i] = t2; }
+                    else stat_merge_eq(st1[i], st2[i], t1, t2, 1.f / 128.f);          // the wave's two M blocks: 64 pixels each
+                }
+            }
+        }
+        if (a.stats && lane < 16) {
+#pragma unroll
+            for (int i = 0; i < NBW / 2; ++i) {
+                float* R = Rs + spar * (4 * NCO * 2) + (mb * NCO + (hh * (NBW / 2) + i) * 16 + lane) * 2;
+                R[0] = st1[i];
+                R[1] = st2[i];
             }
         }
     };
     auto fold_stats = [&]() {          // after the barrier that follows epi_finish
         if (!a.stats) return;          // uniform
-        if (tid < 64) {
-            const float* R = Rs + spar * (4 * 64 * 2) + tid * 2;
-            float s1 = R[0], s2 = R[1];              // M blocks of 64 pixels, merged in order
+        if (tid < NCO) {
+            const float* R = Rs + spar * (4 * NCO * 2) + tid * 2;
+            float s1 = R[0], s2 = R[1];              // the four waves' 64 MBW pixels each, merged in order
+            constexpr float PW = 64.f * MBW;
 #pragma unroll
-            for (int r = 1; r < 4; ++r) stat_merge(s1, s2, (float)(64 * r), R[r * 128], R[r * 128 + 1], 64.f);
+            for (int r = 1; r < 4; ++r) stat_merge(s1, s2, PW * r, R[r * NCO * 2], R[r * NCO * 2 + 1], PW);
             const int t = (cn * a.tilesX + ctx) * a.tilesY + cty;
             float* o = a.stats + ((size_t)t * Cout + co_base + tid) * 2;
             o[0] = s1;
@@ -468,7 +507,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
         // region (cn, ctx, cty) is complete
         flush();
 #ifdef W6_EXP_NO_EPI
-        if (acc[3][1][2] == 123.456f)
+        if (acc[3][0][1][2] == 123.456f)
 #endif
         {
         if (h == 0) epi_send(P0{}); else epi_send(P1{});
@@ -484,46 +523,59 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
 
 }  // namespace
 
-// the 64-cout kernel serves a layer whenever its channel counts allow (k_wino_weights then writes the chunked layout)
-bool conv_wino64_ok(int Cin, int Cout) { return g_w64_env != 0 && Cin % 16 == 0 && Cout % 64 == 0; }
-int conv_wino64_stat_tiles(int H, int W) {
-    const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? 8 : 16;
-    return H % tr == 0 ? (H / tr) * (W / rw) : 0;
+// Which workgroup shape serves a layer (0: none - the 32-cout kernel of conv_wino.hip): 64 couts whenever Cout allows, else
+// two M blocks x 32 couts on maps whose width is a multiple of 32.  (Cin % 16: an even number of 8-channel chunks.)
+static int wino64_shape(int Cin, int Cout, int W) {
+    if (!g_w64_env || Cin % 16 != 0) return 0;
+    if (Cout % 64 == 0) return 1;
+    return (Cout % 32 == 0 && W % 32 == 0) ? 2 : 0;
+}
+bool conv_wino64_ok(int Cin, int Cout, int W) { return wino64_shape(Cin, Cout, W) != 0; }
+int conv_wino64_stat_tiles(int Cin, int Cout, int H, int W) {
+    const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? 8 * wino64_shape(Cin, Cout, W) : 16;
+    return tr > 0 && H % tr == 0 ? (H / tr) * (W / rw) : 0;
 }
 
-int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
-                    hipStream_t st, float* stats) {
-    const bool wide = W % 32 == 0;
-    const size_t lds = (size_t)(2 * (wide ? W64Geo<32>::HBUF : W64Geo<16>::HBUF) + 3 * W6_UBUF + 2 * 4 * 64 * 2) * sizeof(float);
-    static_assert((size_t)(2 * W64Geo<16>::HBUF + 3 * W6_UBUF + 2 * 4 * 64 * 2) * sizeof(float) <= 160 * 1024, "buffers do not fit the 160 KB LDS");
+template <int RW, int MBW>
+static int launch_wino64(W64Args& a, hipStream_t st) {
+    using G = W64Geo<RW, MBW>;
+    constexpr size_t lds = G::LDS_FLOATS * sizeof(float);
+    static_assert(lds <= 160 * 1024, "buffers do not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_wino64<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)k_conv_wino64<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino64<RW, MBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             vqw_set_error("conv_wino64: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
         attr_set = true;
     }
+    a.tilesY = ceil_div(a.H, G::TR); a.tilesX = a.W / RW; a.nsp = a.N * a.tilesY * a.tilesX;
+    a.ntn = a.Cout / G::NCO;
+    int groups = g_w64_max_blocks / a.ntn;
+    if (groups < 1) groups = 1;
+    const int even = ceil_div(a.nsp, groups);
+    a.kt = even < 1 ? 1 : even;
+    k_conv_wino64<RW, MBW><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino64");
+    return VQW_OK;
+}
+
+int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
+                    hipStream_t st, float* stats) {
     W64Args a;
     a.x = x; a.u = u; a.bias = bias; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.tilesY = ceil_div(H, wide ? 8 : 16); a.tilesX = W / (wide ? 32 : 16); a.nsp = N * a.tilesY * a.tilesX;
-    a.ntn = Cout / 64; a.nch = Cin / 8;
+    a.nch = Cin / 8;
     a.relu = relu;
     a.stats = stats;
     const long P = (long)N * H * W;
     a.nbx = (unsigned)(P * Cin * 4);
     a.nbu = (unsigned)(16L * Cout * Cin * 4);
     a.nby = (unsigned)(P * Cout * 4);
-    int groups = g_w64_max_blocks / a.ntn;
-    if (groups < 1) groups = 1;
-    const int even = ceil_div(a.nsp, groups);
-    a.kt = even < 1 ? 1 : even;
-    if (wide) k_conv_wino64<32><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
-    else k_conv_wino64<16><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
-    VQW_LAUNCH_CHECK("conv_wino64");
-    return VQW_OK;
+    const int shape = wino64_shape(Cin, Cout, W);
+    if (shape == 2) return launch_wino64<32, 2>(a, st);
+    if (W % 32 == 0) return launch_wino64<32, 1>(a, st);
+    return launch_wino64<16, 1>(a, st);
 }
 
 // =====================================================================================================================
@@ -760,8 +812,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad64(W64WgArgs a) {
     }
 
     // One phase = the 32 MFMAs of k-step s (operand set SET) + the build of the next k-step's operands (set SET ^ 1) from
-    // buffer NB + what LOADS says: 0 commit dY of the next region and issue its X loads, 2 commit that X and issue the dY
-    // loads of the region after it
+    // buffer NB + what LOADS says: 0 commit dY, 1 issue X, 2 commit X (all of the next region), 3 issue dY of the one after it
     auto phase = [&](auto SET, auto SNEXT, auto NBUF, auto DBUFW, auto LOADS) {
         constexpr int set = decltype(SET)::value, sn = decltype(SNEXT)::value, nbuf = decltype(NBUF)::value;
         constexpr int wbuf = decltype(DBUFW)::value, loads = decltype(LOADS)::value;
@@ -776,16 +827,12 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad64(W64WgArgs a) {
 #ifndef W6_EXP_NO_BUILD               // timing-only A/B builds (tools/wino_ab.sh): wrong results
                     build_slot(nbuf, sn, set ^ 1, p);
 #endif
+                    // prefetch: a phase (1 us) between a load and its LDS commit (twice that changed nothing and costs registers)
 #ifndef W6_EXP_NO_WLOADS
-                    // prefetch: ~1.75 phases (2 us) between a load and its LDS commit; the two batches never hold registers together
-#ifndef W6_EXP_NO_WCOMMIT
-                    if (loads == 0 && p >= 2 && p < 6) commit_d(p - 2, wbuf);
-                    if (loads == 2 && p >= 2 && p < 2 + LX) commit_x(p - 2, wbuf);
-#endif
-#ifndef W6_EXP_NO_WISSUE
-                    if (loads == 0 && p >= 10 && p < 10 + 2 * LX && (p & 1) == 0) issue_x((p - 10) >> 1);
-                    if (loads == 2 && p >= 10 && p < 18 && (p & 1) == 0) issue_d((p - 10) >> 1);
-#endif
+                    if (loads == 0 && p >= 8 && p < 12) commit_d(p - 8, wbuf);
+                    if (loads == 1 && p >= 2 && p < 2 + 2 * LX && (p & 1) == 0) issue_x((p - 2) >> 1);
+                    if (loads == 2 && p >= 8 && p < 8 + LX) commit_x(p - 8, wbuf);
+                    if (loads == 3 && p >= 2 && p < 10 && (p & 1) == 0) issue_d((p - 2) >> 1);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -798,14 +845,14 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad64(W64WgArgs a) {
         constexpr int b = decltype(BUF)::value;
         using B = std::integral_constant<int, b>;
         using NB = std::integral_constant<int, b ^ 1>;
-        phase(I0{}, I1{}, B{}, NB{}, I0{});        // k-step 0 (set 0), builds k-step 1; commits dY of the next region, issues its X
-        phase(I1{}, I2{}, B{}, NB{}, I1{});        // k-step 1, builds 2
-        load_advance();
-        phase(I0{}, I3{}, B{}, NB{}, I2{});        // k-step 2, builds 3; commits X; issues dY of the region after the next
+        phase(I0{}, I1{}, B{}, NB{}, I0{});        // k-step 0 (set 0), builds k-step 1; commits dY of the next region
+        phase(I1{}, I2{}, B{}, NB{}, I1{});        // k-step 1, builds 2; issues X of the next region
+        phase(I0{}, I3{}, B{}, NB{}, I2{});        // k-step 2, builds 3; commits X
 #ifndef W6_EXP_NO_WBARRIER
         __syncthreads();                           // the next region's buffers are complete; this region's are read once more
 #endif
-        phase(I1{}, I0{}, NB{}, B{}, I3{});        // k-step 3, builds k-step 0 of the next region
+        load_advance();
+        phase(I1{}, I0{}, NB{}, B{}, I3{});        // k-step 3, builds k-step 0 of the next region; issues dY of the one after
     };
     for (int g = 0; g < my_tiles; g += 2) {        // uniform per workgroup
         region(I0{});

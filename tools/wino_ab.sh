@@ -16,5 +16,5 @@ if [ "$1" = build ]; then
 fi
 for l in $L/libvqwnet_hip.so $(for v in $VARIANTS; do echo $O/libvqwnet_$v.so; done); do
   echo "== $l"
-  VQW_LIB_PATH=$l python3 $R/tools/conv_bench.py ${PASS:+--only $PASS} --filter "k3 d1" 2>/dev/null | grep -E " 64-> 64 k3 d1  @128|128->128 k3 d1  @ 64|256->512 k3 d1  @ 32|512->512 k3 d1  @ 16"
+  VQW_LIB_PATH=$l python3 $R/tools/conv_bench.py ${PASS:+--only $PASS} --filter "k3 d1" 2>/dev/null | grep -E "${SHAPES:- 64-> 64 k3 d1  @128|128->128 k3 d1  @ 64|256->512 k3 d1  @ 32|512->512 k3 d1  @ 16}"
 done
