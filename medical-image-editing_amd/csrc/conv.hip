@@ -307,9 +307,10 @@ extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_
                                      void* stream) {
     VQW_CHECK(dy && ws && dx_low && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_dgrad: bad arguments");
     VQW_CHECK(conv_up2_ok(Cout, Cin, (long)N * h * w), "vqw_conv3x3_up2_dgrad: unsupported shape");
-    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
+    const bool wino = conv_up2_dgrad_is_wino(Cin, Cout, N, h, w);          // nine products per tile instead of sixteen taps
+    const double flops = 2.0 * N * h * w * (wino ? 9.0 : 16.0) * Cout * Cin;
     const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
-    ProfScope ps(0, flops, (hipStream_t)stream, bytes);
+    ProfScope ps(wino ? 4 : 0, flops, (hipStream_t)stream, bytes);
     return conv_up2_dgrad(dy, (const float*)ws, dx_low, N, h, w, Cin, Cout, (hipStream_t)stream);
 }
 

@@ -71,6 +71,12 @@ int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, 
                       hipStream_t st);
 int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st);
+// 3x3 over an up-sampled input in Winograd form, nine of the sixteen products (conv_wino_up.hip)
+bool conv_wino_up_dgrad_ok(int Cin, int Cout, int N, int h, int w);
+size_t conv_wino_up_ws_floats(int Cin, int Cout);
+int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st);
+int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st);
+bool conv_up2_dgrad_is_wino(int Cin, int Cout, int N, int h, int w);
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
 bool conv_up2_ok(int Cin, int Cout, long Plow);
 size_t conv_up2_ws_floats(int Cin, int Cout);

@@ -439,13 +439,15 @@ __global__ void k_collapse_up_weights(const float* __restrict__ w, float* __rest
 bool conv_up2_ok(int Cin, int Cout, long Plow) {
     return (Cin % 4 == 0) && Cin >= 8 && Cout >= 8 && fits_u32(4 * Plow, Cin, Cout);
 }
-size_t conv_up2_ws_floats(int Cin, int Cout) { return (size_t)32 * Cout * Cin; }
+static inline bool up2_has_wino(int Cin, int Cout) { return Cin % 8 == 0 && Cout % 8 == 0; }
+size_t conv_up2_ws_floats(int Cin, int Cout) { return (size_t)32 * Cout * Cin + (up2_has_wino(Cin, Cout) ? conv_wino_up_ws_floats(Cin, Cout) : 0); }
 
-// ws: [4][Cout][4][Cin] forward weights then [Cin][16][Cout] dgrad weights
+// ws: [4][Cout][4][Cin] forward weights, [Cin][16][Cout] dgrad weights, then the nine-product Winograd weights (conv_wino_up.hip)
 int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st) {
     long n = 32L * Cout * Cin;
     k_collapse_up_weights<<<stream_grid(n, 256), 256, 0, st>>>(w, ws, ws + 16L * Cout * Cin, Cout, Cin);
     VQW_LAUNCH_CHECK("collapse_up_weights");
+    if (up2_has_wino(Cin, Cout)) return conv_wino_up_prepare(w, ws + 32L * Cout * Cin, Cin, Cout, st);
     return VQW_OK;
 }
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
@@ -460,7 +462,9 @@ int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* 
     g.out_mode = 1;      // parity = blockIdx.y; tap offsets and the weight block are derived from it in the kernel
     return dispatch_fwd(in, ws, bias, y, N, h, w, Cout, g, relu, st, stats);
 }
+bool conv_up2_dgrad_is_wino(int Cin, int Cout, int N, int h, int w) { return conv_wino_up_dgrad_ok(Cin, Cout, N, h, w); }
 int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st) {
+    if (conv_wino_up_dgrad_ok(Cin, Cout, N, h, w)) return conv_wino_up_dgrad(dy, ws + 32L * Cout * Cin, dx_low, N, h, w, Cin, Cout, st);
     ConvIn in{dy, nullptr, Cout, 0, 0};
     ConvGeom g{};
     g.ntaps = 16;

@@ -1,0 +1,402 @@
+// 3x3 convolution over a nearest x2 up-sampled input (StyledResUpBlock `conv`, `conv1`: blocks.py:100-112) in Winograd
+// F(2x2, 3x3) form: NINE of the sixteen products.
+//
+// A Winograd tile of the full-resolution output starts at even coordinates, so its 4 x 4 input patch of up(x) has the rows
+// (a, b, b, c) of three low-resolution rows (and the same in columns).  B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3) is then
+// (a - b, 2 b, 0, b - c): row 2 and column 2 of V = B^T d B vanish - 9 of the 16 element-wise products remain, a quarter of
+// the direct form's matrix work (the low-resolution "collapsed" form of conv_mfma.hip / conv_halo.hip needs 16 of 36).
+// The same structure on the other two passes:
+//   * input gradient: g_low = sum of the 2 x 2 tile of g = A^T M A, i.e. c^T M c with c = column sums of A^T = (1, 2, 0, -1):
+//     row / column 2 of M is never needed, and with c folded into the transformed weights the nine products ACCUMULATE INTO
+//     ONE accumulator - the input gradient is a single GEMM with K = 9 Cout whose A operand is the transformed dY patch
+//     (no inverse transform, 4 accumulator registers per 16 x 16 block);
+//   * weight gradient: dU[xi] = sum_tiles dM[xi]^T V[xi] is zero wherever V[xi] is.
+// Built like conv_wino64.hip (see there for the accounting): beside fp32 MFMAs every VALU instruction costs 4.4 matrix-pipe
+// cycles, LDS / SALU instructions nothing - per-region load offsets, scalar chunk offsets, immediates everywhere else.
+#include "common.h"
+#include "conv_common.h"
+#include "mfma_util.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+static int env_int_up(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+static const int g_wup_env = env_int_up("VQW_WINOGRAD_UP", 1);
+static const int g_wup_max_blocks = []{ int v = env_int_up("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// the nine positions: (i, j) with i, j in {0, 1, 3}
+__device__ __host__ constexpr int up_row(int s) { return s == 2 ? 3 : s; }       // s = 0, 1, 2 -> Winograd index 0, 1, 3
+
+// Transformed weights of the three passes, all in the chunked layout [K / 8][9][N][8] the kernels stream:
+//   uf (forward):        K = Cin,  N = Cout: (G w G^T)[i][j] x 2^(i == 1) x 2^(j == 1)    (the factor 2 of V's row / column 1)
+//   ud (input gradient): K = Cout, N = Cin:  c_i c_j (G wt G^T)[i][j], wt = w flipped and transposed, c = (1, 2, -1)
+__global__ void k_wino_up_weights(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin) {
+    const long n = (long)Cout * Cin;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(e / Cin), ci = (int)(e % Cin);
+        double g[3][3];
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+        for (int flip = 0; flip < 2; ++flip) {
+            double t[4][3], u[4][4];
+            for (int kx = 0; kx < 3; ++kx) {
+                const double g0 = flip ? g[2][2 - kx] : g[0][kx], g1 = flip ? g[1][2 - kx] : g[1][kx], g2 = flip ? g[0][2 - kx] : g[2][kx];
+                t[0][kx] = g0;
+                t[1][kx] = 0.5 * (g0 + g1 + g2);
+                t[2][kx] = 0.5 * (g0 - g1 + g2);
+                t[3][kx] = g2;
+            }
+            for (int i = 0; i < 4; ++i) {
+                u[i][0] = t[i][0];
+                u[i][1] = 0.5 * (t[i][0] + t[i][1] + t[i][2]);
+                u[i][2] = 0.5 * (t[i][0] - t[i][1] + t[i][2]);
+                u[i][3] = t[i][2];
+            }
+            for (int si = 0; si < 3; ++si)
+                for (int sj = 0; sj < 3; ++sj) {
+                    const int i = up_row(si), j = up_row(sj), xi = si * 3 + sj;
+                    if (!flip) {
+                        const double f = (i == 1 ? 2.0 : 1.0) * (j == 1 ? 2.0 : 1.0);
+                        uf[((((long)(ci >> 3) * 9 + xi) * Cout + co) * 8) + (ci & 7)] = (float)(f * u[i][j]);
+                    } else {
+                        const double ci_ = (i == 0 ? 1.0 : i == 1 ? 2.0 : -1.0), cj_ = (j == 0 ? 1.0 : j == 1 ? 2.0 : -1.0);
+                        ud[((((long)(co >> 3) * 9 + xi) * Cin + ci) * 8) + (co & 7)] = (float)(ci_ * cj_ * u[i][j]);
+                    }
+                }
+        }
+    }
+}
+
+constexpr int WU_KPH = 10;                 // floats per halo pixel in LDS (8 channels + 2)
+
+// =====================================================================================================================
+// Input gradient: g_low[tile][ci] = sum over the nine xi and the couts of ud[xi][ci][co] V[xi][tile][co],  V = B^T dY B
+// =====================================================================================================================
+struct WUpDgArgs {
+    const float* dy;           // (N, H = 2h, W = 2w, Cout) full resolution
+    const float* u;            // ud: [Cout / 8][9][Cin][8]
+    float* g;                  // (N, h, w, Cin) low resolution
+    int N, H, W, Cin, Cout;    // layer channel counts: K = Cout (chunks of 8), N dimension = Cin
+    int tilesY, tilesX, nsp, ntn, nch, kt;
+    unsigned nbd, nbu, nbg;
+};
+
+// Workgroup = 16 x 32 full-resolution pixels (128 tiles = 8 x 16 low-resolution pixels) x NCO = 16 NBW input channels; wave w =
+// tile row w.  One accumulator set (NBW x 4 registers) takes all nine xi.
+template <int NBW>
+__global__ void __launch_bounds__(512, 1) k_conv_wino_up_dgrad(WUpDgArgs a) {
+    constexpr int NT = 512, NCO = 16 * NBW;
+    constexpr int RW = 32, TR = 16, HR = TR + 2, HWV = RW + 2, HWS = 34;
+    constexpr int HBUF = HR * HWS * WU_KPH;            // 6120 floats
+    constexpr int UBUF = 9 * NCO * 8;
+    constexpr int HF = HR * HWV * 2;                   // 1224 float4
+    constexpr int LH = (HF + NT - 1) / NT;             // 3
+    constexpr int UF = 9 * NCO * 2;                    // float4 per U chunk: 2304 / 1152
+    constexpr int LU = (UF + NT - 1) / NT;             // 5 / 3
+    constexpr int NPOS = 18 * NBW;                     // MFMAs per item and wave: 144 / 72
+    constexpr int NOPS = 42;                           // transform: 24 column + 18 row operations
+    constexpr int OPSTEP2 = NBW == 8 ? 3 : 2;          // operation o sits at position T0 + o * OPSTEP2 / 2
+    constexpr int T0 = NPOS - (NOPS * OPSTEP2 + 1) / 2;
+    constexpr int CP = T0 - (LH + LU) - 4;             // first LDS commit of the prefetched data
+    static_assert(1 + 2 * (LH + LU) <= CP, "prefetch loads are issued before their commits");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: halo buffers [2][HBUF], then U buffers [2][UBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const __amdgpu_buffer_rsrc_t rsd = make_rsrc(a.dy, a.nbd), rsu = make_rsrc(a.u, a.nbu), rsg = make_rsrc(a.g, a.nbg);
+
+    const int ntn = a.ntn, nch = a.nch;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % ntn;
+    const int sp0 = (lb / ntn) * a.kt;
+    const int co_base = tile_n * NCO;                  // first input channel (N dimension) of the workgroup
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int per_img = a.tilesY * a.tilesX;
+    if (my_tiles <= 0) return;
+
+    // ---- loader slots ----
+    const int c4 = tid & 1;
+    auto halo_pixel = [&](int j, int& hy, int& hx) {
+        int f = tid + j * NT;
+        if (f >= HF) f -= HF;
+        const int hp = f >> 1;
+        hy = hp / HWV;
+        hx = hp - hy * HWV;
+    };
+    int h_lds[LH];
+#pragma unroll
+    for (int j = 0; j < LH; ++j) {
+        int hy, hx;
+        halo_pixel(j, hy, hx);
+        h_lds[j] = (hy * HWS + hx) * WU_KPH + c4 * 4;
+    }
+    unsigned h_voff[LH];
+    auto region_offsets = [&](int n, int tx, int ty) {
+        const int y0 = ty * TR - 1, x0 = tx * RW - 1;
+#pragma unroll
+        for (int j = 0; j < LH; ++j) {
+            int hy, hx;
+            halo_pixel(j, hy, hx);
+            const int yy = y0 + hy, xx = x0 + hx;
+            const bool ok = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+            const unsigned pix = ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
+            h_voff[j] = sel_u32(ok, pix * (unsigned)Cout * 4u + (unsigned)c4 * 16u, 0xFFFFFFFFu);
+        }
+    };
+    // U float4 f -> row f / 2 = xi * NCO + n, channel quad f % 2; the last slot wraps (duplicates)
+    unsigned u_voff[LU];
+    int u_lds[LU];
+#pragma unroll
+    for (int j = 0; j < LU; ++j) {
+        int f = tid + j * NT;
+        if (f >= UF) f -= UF;
+        const int row = f >> 1, xi = row / NCO, n = row - xi * NCO;
+        u_voff[j] = (((unsigned)xi * Cin + co_base + n) * 8u + c4 * 4) * 4u;
+        u_lds[j] = 2 * HBUF + row * 8 + ((c4 ^ ((n >> 3) & 1)) * 4);
+    }
+    const unsigned u_cstride = 9u * Cin * 32u;         // per 8-channel chunk
+
+    float4 rh[LH], ru[LU];
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+        float4 f;
+        unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        f.x = __uint_as_float(a0); f.y = __uint_as_float(a1); f.z = __uint_as_float(a2); f.w = __uint_as_float(a3);
+        return f;
+    };
+    auto issue_h = [&](int j, int chunk) { rh[j] = ld4(rsd, h_voff[j], chunk * 32); };
+    // (readfirstlane: left alone the compiler multiplies in a VGPR and wraps the load in a waterfall loop)
+    auto issue_u = [&](int j, int chunk) { ru[j] = ld4(rsu, u_voff[j], __builtin_amdgcn_readfirstlane(chunk * u_cstride)); };
+    auto commit_h = [&](int j, int buf) {
+        float* p = smem + buf * HBUF + h_lds[j];
+        f32x2 lo, hi;
+        lo.x = rh[j].x; lo.y = rh[j].y; hi.x = rh[j].z; hi.y = rh[j].w;
+        *(f32x2*)p = lo;
+        *(f32x2*)(p + 2) = hi;
+    };
+    auto commit_u = [&](int j, int buf) { *(float4*)&smem[u_lds[j] + buf * UBUF] = ru[j]; };
+
+    // ---- item cursors ----
+    int cn, ctx, cty, ch = 0;
+    {
+        cn = sp0 / per_img;
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    auto advance = [&](int& n, int& tx, int& ty, int& c) {
+        const int adv = c + 1 == nch ? 1 : 0;
+        c = adv ? 0 : c + 1;
+        const int ty1 = ty + adv, wy = ty1 == a.tilesY ? 1 : 0;
+        ty = wy ? 0 : ty1;
+        const int tx1 = tx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        tx = wx ? 0 : tx1;
+        n += wx;
+    };
+    int n1 = cn, tx1 = ctx, ty1 = cty, ch1 = 0;
+    advance(n1, tx1, ty1, ch1);
+    int n2 = n1, tx2 = tx1, ty2 = ty1, ch2 = ch1;
+    advance(n2, tx2, ty2, ch2);
+
+    // ---- fragments: lane (tile m = lane & 15, channel pair q = lane >> 4); wave = tile row ----
+    const int m = lane & 15, q = lane >> 4;
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    int a_row[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a_row[r] = opaque(((2 * wv + r) * HWS + 2 * m) * WU_KPH + 2 * q);
+    const int b_swz = ((q >> 1) ^ (m >> 3)) * 4 + (q & 1) * 2;
+    // (indices in units of f32x2: a float index that went through `opaque` carries no alignment and the 8-byte fragment read
+    // would be split into ds_read2_b32 with a VALU add each)
+    const int b_u0 = opaque((2 * HBUF + m * 8 + b_swz) / 2), b_u1 = opaque((2 * HBUF + UBUF + m * 8 + b_swz) / 2);      // + (xi * NCO + nb * 16) * 4
+    float mone;
+    { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
+
+    f32x4 acc[NBW];
+    f32x2 bf[2][NBW];
+    f32x2 dcol[2][4];                  // two patch columns in flight
+    float e[2][3][4];                  // [channel][row 0, 1, 3][column] after the column pass
+    float v[2][2][9];                  // [parity][channel][xi]
+
+    auto read_col = [&](int buf, int c) {
+        const float* Hc = smem + buf * HBUF + c * WU_KPH;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dcol[c & 1][r] = *(const f32x2*)&Hc[a_row[r]];
+    };
+    // operation o = 0..41: column pass o < 24: column o / 6, channel (o % 6) / 3, row o % 3; row pass: channel, row, column
+    auto xform_op = [&](int par, int o) {
+        if (o < 24) {
+            const int c = o / 6, t = (o % 6) / 3, s = o % 3;
+            const float d0 = dcol[c & 1][0][t], d1 = dcol[c & 1][1][t], d2 = dcol[c & 1][2][t], d3 = dcol[c & 1][3][t];
+            e[t][s][c] = s == 0 ? __builtin_fmaf(mone, d2, d0) : s == 1 ? d1 + d2 : __builtin_fmaf(mone, d3, d1);
+        } else {
+            const int k = o - 24, t = k / 9, s = (k % 9) / 3, sj = k % 3;
+            const float e0 = e[t][s][0], e1 = e[t][s][1], e2 = e[t][s][2], e3 = e[t][s][3];
+            v[par][t][s * 3 + sj] = sj == 0 ? e0 - e2 : sj == 1 ? e1 + e2 : e1 - e3;
+        }
+    };
+    auto op_pos = [](int o) { return T0 + (o * OPSTEP2) / 2; };
+    auto xform_slot = [&](int buf, int par, int p) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) {
+            if (o < 24 && o % 6 == 0 && op_pos(o) - 3 == p) read_col(buf, o / 6);      // a column's reads three positions ahead
+            if (op_pos(o) == p) xform_op(par, o);
+        }
+    };
+
+    // ---- prologue ----
+    region_offsets(cn, ctx, cty);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) issue_h(j, 0);
+#pragma unroll
+    for (int j = 0; j < LU; ++j) issue_u(j, 0);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) commit_h(j, 0);
+#pragma unroll
+    for (int j = 0; j < LU; ++j) commit_u(j, 0);
+    region_offsets(n1, tx1, ty1);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) issue_h(j, ch1);
+#pragma unroll
+    for (int j = 0; j < LH; ++j) commit_h(j, 1);
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+        if (o < 24 && o % 6 == 0) read_col(0, o / 6);
+        xform_op(0, o);
+    }
+    __syncthreads();
+    region_offsets(n2, tx2, ty2);
+
+    // One item of parity PAR: operands v[PAR], U chunk in U buffer PAR, the next item's halo in halo buffer PAR ^ 1; the halo
+    // of item i+2 goes to halo buffer PAR, the U chunk of item i+1 to U buffer PAR ^ 1.
+    auto body = [&](auto PAR, auto FIRST) {
+        constexpr int par = decltype(PAR)::value;
+        constexpr bool first = decltype(FIRST)::value;
+        auto ldb = [&](int xi, int nb) {
+            bf[xi & 1][nb] = ((const f32x2*)smem)[(par ? b_u1 : b_u0) + (xi * NCO + nb * 16) * 4];
+        };
+        auto slot = [&](int p) {
+            if (p >= 1 && p < 1 + 2 * LH && (p & 1)) issue_h((p - 1) >> 1, ch2);
+            if (p >= 1 + 2 * LH && p < 1 + 2 * (LH + LU) && (p & 1)) issue_u((p - 1 - 2 * LH) >> 1, ch1);
+            if (p >= CP && p < CP + LH) commit_h(p - CP, par);
+            if (p >= CP + LH && p < CP + LH + LU) commit_u(p - CP - LH, par ^ 1);
+            xform_slot(par ^ 1, par ^ 1, p);
+        };
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) { ldb(0, nb); __builtin_amdgcn_sched_barrier(0); }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int xi = 0; xi < 9; ++xi)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    if (k == 0 && xi + 1 < 9) ldb(xi + 1, nb);
+                    acc[nb] = MFMA16(v[par][k][xi], k == 0 ? bf[xi & 1][nb].x : bf[xi & 1][nb].y,
+                                     (first && xi == 0 && k == 0) ? zero4 : acc[nb]);
+                    slot((xi * 2 + k) * NBW + nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    // C/D layout (16x16): col = lane & 15 (channel of the N block), row = 4 (lane >> 4) + r (tile = low-resolution column)
+    auto epilogue = [&]() {
+        const int ylow = cty * (TR / 2) + wv, xlow0 = ctx * (RW / 2) + 4 * q;
+        const unsigned base = (((unsigned)cn * (H >> 1) + (unsigned)ylow) * (W >> 1) + (unsigned)xlow0) * (unsigned)Cin + co_base + m;
+        const int voff = (int)sel_u32(ylow < (H >> 1), base * 4u, 0xFFFFFFFFu);
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[nb][r]), rsg, voff, r * Cin * 4 + nb * 64, 0);
+    };
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto shift = [&]() {
+        cn = n1; ctx = tx1; cty = ty1; ch = ch1;
+        n1 = n2; tx1 = tx2; ty1 = ty2; ch1 = ch2;
+        advance(n2, tx2, ty2, ch2);
+    };
+    for (int reg = 0; reg < my_tiles; ++reg) {     // nch is even: a region is nch / 2 (even, odd) item pairs
+        body(P0{}, std::true_type{});
+        __syncthreads();
+        shift();
+        body(P1{}, std::false_type{});
+        __syncthreads();
+        for (int c = 2; c < nch; c += 2) {
+            shift();
+            if (ch2 == 0) region_offsets(n2, tx2, ty2);
+            body(P0{}, std::false_type{});
+            __syncthreads();
+            shift();
+            body(P1{}, std::false_type{});
+            __syncthreads();
+        }
+        epilogue();
+        shift();
+        if (ch2 == 0) region_offsets(n2, tx2, ty2);
+    }
+}
+
+}  // namespace
+
+// Shapes served: full-resolution width a multiple of 32; Cout % 16 (an even number of 8-channel chunks); Cin % 64.
+bool conv_wino_up_dgrad_ok(int Cin, int Cout, int N, int h, int w) {
+    if (!g_wup_env || Cin % 64 != 0 || Cout % 16 != 0 || (2 * w) % 32 != 0 || h < 1 || N < 1) return false;
+    const long P = (long)N * 4 * h * w;
+    return P * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
+}
+size_t conv_wino_up_ws_floats(int Cin, int Cout) { return (size_t)18 * Cout * Cin; }
+// ws: uf [Cin / 8][9][Cout][8] then ud [Cout / 8][9][Cin][8] (needs Cin % 8 == 0 and Cout % 8 == 0)
+int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st) {
+    const long n = (long)Cout * Cin;
+    k_wino_up_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, ws, ws + 9L * Cout * Cin, Cout, Cin);
+    VQW_LAUNCH_CHECK("wino_up_weights");
+    return VQW_OK;
+}
+
+template <int NBW>
+static int launch_up_dgrad(WUpDgArgs& a, hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * 18 * 34 * WU_KPH + 2 * 9 * 16 * NBW * 8) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "buffers do not fit the 160 KB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino_up_dgrad<NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            vqw_set_error("conv_wino_up_dgrad: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    a.ntn = a.Cin / (16 * NBW);
+    int groups = g_wup_max_blocks / a.ntn;
+    if (groups < 1) groups = 1;
+    const int even = ceil_div(a.nsp, groups);
+    a.kt = even < 1 ? 1 : even;
+    k_conv_wino_up_dgrad<NBW><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino_up_dgrad");
+    return VQW_OK;
+}
+
+// dy (N, 2h, 2w, Cout) -> g_low (N, h, w, Cin); ws as written by conv_wino_up_prepare
+int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st) {
+    WUpDgArgs a;
+    a.dy = dy; a.u = ws + 9L * Cout * Cin; a.g = g_low;
+    a.N = N; a.H = 2 * h; a.W = 2 * w; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = ceil_div(a.H, 16); a.tilesX = a.W / 32; a.nsp = N * a.tilesY * a.tilesX;
+    a.nch = Cout / 8;
+    const long P = (long)N * a.H * a.W;
+    a.nbd = (unsigned)(P * Cout * 4);
+    a.nbu = (unsigned)(9L * Cout * Cin * 4);
+    a.nbg = (unsigned)(P / 4 * Cin * 4);
+    if (Cin % 128 == 0) return launch_up_dgrad<8>(a, st);
+    return launch_up_dgrad<4>(a, st);
+}

@@ -70,6 +70,11 @@ CONV_CASES = [
     (1, 20, 16, 128, 0, False, 64, 3, 1, True, False),
     (1, 256, 320, 16, 0, False, 64, 3, 1, True, False),
     (2, 22, 32, 64, 0, False, 16, 3, 1, False, False),     # its input gradient: 16 -> 64
+    # up-sampled 3x3 in Winograd form with nine products (conv_wino_up.hip): ragged H, the shortest channel walk (two chunks),
+    # several regions per strip and image, both N-tile widths (64 / 128 input channels)
+    (1, 40, 32, 64, 0, True, 16, 3, 1, True, False),
+    (3, 16, 96, 128, 0, True, 32, 3, 1, True, True),
+    (2, 64, 64, 192, 0, True, 96, 3, 1, False, False),
     # 16-cout layers on the 16x16x4 MFMA path of the halo kernel (16 x 32 pixel tiles, ragged H, two sources)
     (2, 32, 32, 16, 0, False, 16, 3, 1, True, True),
     (1, 40, 64, 48, 0, False, 16, 3, 1, True, False),
