@@ -285,9 +285,10 @@ extern "C" int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const flo
                                    int Cout, int relu, void* stream) {
     VQW_CHECK(x_low && ws && y && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_fwd: bad arguments");
     VQW_CHECK(conv_up2_ok(Cin, Cout, (long)N * h * w), "vqw_conv3x3_up2_fwd: unsupported shape (query vqw_conv3x3_up2_supported)");
-    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;       // 4 parities x 4 taps on the low-res grid
+    const bool wino = conv_up2_fwd_is_wino(Cin, Cout, N, h, w);     // nine products per tile | 4 parities x 4 taps on the low-res grid
+    const double flops = 2.0 * N * h * w * (wino ? 9.0 : 16.0) * Cout * Cin;
     const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
-    ProfScope ps(0, flops, (hipStream_t)stream, bytes);
+    ProfScope ps(wino ? 4 : 0, flops, (hipStream_t)stream, bytes);
     return conv_up2_fwd(x_low, (const float*)ws, bias, y, N, h, w, Cin, Cout, relu, (hipStream_t)stream);
 }
 extern "C" int vqw_conv3x3_up2_fwd_stats_parts(int Cin, int Cout, int N, int h, int w) {
@@ -298,9 +299,10 @@ extern "C" int vqw_conv3x3_up2_fwd_stats(const float* x_low, const void* ws, con
                                          int w, int Cin, int Cout, void* stream) {
     VQW_CHECK(x_low && ws && y && part && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_fwd_stats: bad arguments");
     VQW_CHECK(vqw_conv3x3_up2_fwd_stats_parts(Cin, Cout, N, h, w) > 0, "vqw_conv3x3_up2_fwd_stats: shape not served");
-    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
+    const bool wino = conv_up2_fwd_is_wino(Cin, Cout, N, h, w);
+    const double flops = 2.0 * N * h * w * (wino ? 9.0 : 16.0) * Cout * Cin;
     const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
-    ProfScope ps(0, flops, (hipStream_t)stream, bytes);
+    ProfScope ps(wino ? 4 : 0, flops, (hipStream_t)stream, bytes);
     return conv_up2_fwd(x_low, (const float*)ws, bias, y, N, h, w, Cin, Cout, 0, (hipStream_t)stream, part);
 }
 extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,

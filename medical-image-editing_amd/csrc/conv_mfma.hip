@@ -389,6 +389,7 @@ int conv_mfma_stat_tiles(const ConvIn& in, int N, int H, int W, int Cout, int di
     return ((long)H * W) % bm == 0 ? (int)((long)H * W / bm) : 0;
 }
 int conv_up2_stat_tiles(int Cin, int Cout, int N, int h, int w) {
+    if (conv_wino_up_fwd_ok(Cin, Cout, N, h, w) && conv_wino_up_stat_tiles(h, w) > 0) return conv_wino_up_stat_tiles(h, w);
     if (conv_halo_up2_ok(Cin, Cout, N, h, w) && conv_halo_up2_stat_tiles(h, w) > 0) return conv_halo_up2_stat_tiles(h, w);
     ConvIn in{nullptr, nullptr, Cin, 0, 0};
     const int bm = dispatch_bm(in, Cout);
@@ -452,6 +453,10 @@ int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t s
 }
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
                  hipStream_t st, float* stats) {
+    // Winograd form with nine products (conv_wino_up.hip) where the shape allows and the statistics partials (if wanted) come in
+    // the layout conv_up2_stat_tiles announced
+    if (conv_wino_up_fwd_ok(Cin, Cout, N, h, w) && (!stats || conv_wino_up_stat_tiles(h, w) > 0))
+        return conv_wino_up_fwd(x_low, ws + 32L * Cout * Cin, bias, y, N, h, w, Cin, Cout, relu, st, stats);
     // LDS-resident halo tiles (conv_halo.hip, 4-tap form): every input element travels L2 -> LDS 1.3 times per parity
     // instead of 4; only when the statistics partials (if wanted) come in the layout the caller sized for
     if (conv_halo_up2_ok(Cin, Cout, N, h, w) && (!stats || conv_halo_up2_stat_tiles(h, w) > 0))
@@ -463,6 +468,7 @@ int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* 
     return dispatch_fwd(in, ws, bias, y, N, h, w, Cout, g, relu, st, stats);
 }
 bool conv_up2_dgrad_is_wino(int Cin, int Cout, int N, int h, int w) { return conv_wino_up_dgrad_ok(Cin, Cout, N, h, w); }
+bool conv_up2_fwd_is_wino(int Cin, int Cout, int N, int h, int w) { return conv_wino_up_fwd_ok(Cin, Cout, N, h, w); }
 int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st) {
     if (conv_wino_up_dgrad_ok(Cin, Cout, N, h, w)) return conv_wino_up_dgrad(dy, ws + 32L * Cout * Cin, dx_low, N, h, w, Cin, Cout, st);
     ConvIn in{dy, nullptr, Cout, 0, 0};

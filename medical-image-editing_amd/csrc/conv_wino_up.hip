@@ -347,6 +347,304 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_dgrad(WUpDgArgs a) {
     }
 }
 
+
+// =====================================================================================================================
+// Forward: y (full resolution) = A^T [ sum_ci uf[xi][co][ci] V[xi][tile][ci] ] A,  V from the LOW-resolution 3 x 3 patch
+// =====================================================================================================================
+//   rows of B^T d for d = (a, b, b, c): R0 = a - b, R1 = b (its factor 2 sits in uf), R3 = b - c; the same along columns:
+//   12 add / sub per channel and tile for the nine V.  Workgroup = 16 x 32 output pixels (128 tiles, low-resolution halo
+//   10 x 18 pixels) x 64 couts; wave w = tile row w with all nine xi (9 x 4 N blocks x 4 = 144 accumulators): 24 VALU per
+//   72 MFMAs, no xi split and no exchange.
+struct WUpFwArgs {
+    const float* x;            // (N, h, w, Cin) low resolution
+    const float* u;            // uf: [Cin / 8][9][Cout][8]
+    const float* bias;
+    float* y;                  // (N, 2h, 2w, Cout)
+    int N, h, w, Cin, Cout;
+    int tilesY, tilesX, nsp, ntn, nch, kt;
+    int relu;
+    unsigned nbx, nbu, nby;
+    float* stats;              // optional [N][tilesY * tilesX][Cout][2]
+};
+
+constexpr int WF_KPH = 12;                 // floats per low-resolution halo pixel: adjacent tiles are ONE pixel apart (12 m: conflict-free)
+
+__global__ void __launch_bounds__(512, 1) k_conv_wino_up_fwd(WUpFwArgs a) {
+    constexpr int NT = 512, NBW = 4, NCO = 64;
+    constexpr int LR = 10, LWV = 18, LWS = 18;         // low-resolution halo rows / columns of a region
+    constexpr int HBUF = LR * LWS * WF_KPH;            // 2160 floats
+    constexpr int UBUF = 9 * NCO * 8;                  // 4608 floats
+    constexpr int HF = LR * LWV * 2;                   // 360 float4
+    constexpr int UF = 9 * NCO * 2;                    // 1152 float4
+    constexpr int LU = (UF + NT - 1) / NT;             // 3
+    constexpr int NPOS = 72, NOPS = 24, T0 = NPOS - NOPS, CP = 30;
+    static_assert(HF <= NT && 1 + 2 * (1 + LU) <= CP && CP + 1 + LU <= T0 - 3, "slot layout");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: halo buffers [2][HBUF], U buffers [2][UBUF], statistics [2][8 waves][64][2]
+    float* Rs = smem + 2 * HBUF + 2 * UBUF;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = a.h, w = a.w, Cin = a.Cin, Cout = a.Cout;
+    const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
+
+    const int ntn = a.ntn, nch = a.nch;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = lb % ntn;
+    const int sp0 = (lb / ntn) * a.kt;
+    const int co_base = tile_n * NCO;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int per_img = a.tilesY * a.tilesX;
+    if (my_tiles <= 0) return;
+
+    // ---- loader slots: one halo slot (threads past the 360 float4 repeat another thread's), three U slots ----
+    const int c4 = tid & 1;
+    const int hf = tid < HF ? tid : tid - HF;
+    const int h_hy = (hf >> 1) / LWV, h_hx = (hf >> 1) - h_hy * LWV;
+    const int h_lds = (h_hy * LWS + h_hx) * WF_KPH + c4 * 4;
+    unsigned h_voff;
+    auto region_offsets = [&](int n, int tx, int ty) {
+        const int yy = ty * 8 - 1 + h_hy, xx = tx * 16 - 1 + h_hx;
+        const bool ok = ((unsigned)yy < (unsigned)h) & ((unsigned)xx < (unsigned)w);
+        const unsigned pix = ((unsigned)n * h + (unsigned)yy) * w + (unsigned)xx;
+        h_voff = sel_u32(ok, pix * (unsigned)Cin * 4u + (unsigned)c4 * 16u, 0xFFFFFFFFu);
+    };
+    unsigned u_voff[LU];
+    int u_lds[LU];
+#pragma unroll
+    for (int j = 0; j < LU; ++j) {
+        int f = tid + j * NT;
+        if (f >= UF) f -= UF;
+        const int row = f >> 1, xi = row / NCO, n = row - xi * NCO;
+        u_voff[j] = (((unsigned)xi * Cout + co_base + n) * 8u + c4 * 4) * 4u;
+        u_lds[j] = 2 * HBUF + row * 8 + ((c4 ^ ((n >> 3) & 1)) * 4);
+    }
+    const unsigned u_cstride = 9u * Cout * 32u;
+
+    float4 rh, ru[LU];
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+        float4 f;
+        unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        f.x = __uint_as_float(a0); f.y = __uint_as_float(a1); f.z = __uint_as_float(a2); f.w = __uint_as_float(a3);
+        return f;
+    };
+    auto issue_h = [&](int chunk) { rh = ld4(rsx, h_voff, chunk * 32); };
+    auto issue_u = [&](int j, int chunk) { ru[j] = ld4(rsu, u_voff[j], __builtin_amdgcn_readfirstlane(chunk * u_cstride)); };
+    auto commit_h = [&](int buf) { *(float4*)&smem[buf * HBUF + h_lds] = rh; };
+    auto commit_u = [&](int j, int buf) { *(float4*)&smem[u_lds[j] + buf * UBUF] = ru[j]; };
+
+    // ---- item cursors ----
+    int cn, ctx, cty, ch = 0;
+    {
+        cn = sp0 / per_img;
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    auto advance = [&](int& n, int& tx, int& ty, int& c) {
+        const int adv = c + 1 == nch ? 1 : 0;
+        c = adv ? 0 : c + 1;
+        const int ty1 = ty + adv, wy = ty1 == a.tilesY ? 1 : 0;
+        ty = wy ? 0 : ty1;
+        const int tx1 = tx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        tx = wx ? 0 : tx1;
+        n += wx;
+    };
+    int n1 = cn, tx1 = ctx, ty1 = cty, ch1 = 0;
+    advance(n1, tx1, ty1, ch1);
+    int n2 = n1, tx2 = tx1, ty2 = ty1, ch2 = ch1;
+    advance(n2, tx2, ty2, ch2);
+
+    // ---- fragments: lane (tile m = lane & 15 = low-resolution column, channel pair q = lane >> 4); wave = tile row ----
+    const int m = lane & 15, q = lane >> 4;
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    int a_row[3];                      // f32x2 units
+#pragma unroll
+    for (int r = 0; r < 3; ++r) a_row[r] = opaque((((wv + r) * LWS + m) * WF_KPH + 2 * q) / 2);
+    const int b_swz = ((q >> 1) ^ (m >> 3)) * 4 + (q & 1) * 2;
+    const int b_u0 = opaque((2 * HBUF + m * 8 + b_swz) / 2), b_u1 = opaque((2 * HBUF + UBUF + m * 8 + b_swz) / 2);
+    float mone;
+    { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
+
+    f32x4 acc[9][NBW];
+    f32x2 bf[2][NBW];
+    f32x2 dcol[2][3];                  // two patch columns in flight: low-resolution rows a, b, c
+    float rr[2][3][3];                 // [channel][row 0, 1, 3][patch column] after the row combinations
+    float v[2][2][9];                  // [parity][channel][xi]
+
+    auto read_col = [&](int buf, int c) {
+        const f32x2* Hc = (const f32x2*)smem + (buf * HBUF + c * WF_KPH) / 2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dcol[c & 1][r] = Hc[a_row[r]];
+    };
+    // operation o = 0..23: o < 12: patch column o / 4, channel (o % 4) / 2, which = o % 2 (R0 = a - b | R3 = b - c; R1 = b);
+    // o >= 12: channel (o - 12) / 6, row s = ((o - 12) % 6) / 2, which = o % 2 (V[s][0] = R[l] - R[m] | V[s][3] = R[m] - R[r]; V[s][1] = R[m])
+    auto xform_op = [&](int par, int o) {
+        if (o < 12) {
+            const int c = o / 4, t = (o % 4) / 2;
+            const float da = dcol[c & 1][0][t], db = dcol[c & 1][1][t], dc = dcol[c & 1][2][t];
+            if ((o & 1) == 0) { rr[t][0][c] = __builtin_fmaf(mone, db, da); rr[t][1][c] = db; }
+            else rr[t][2][c] = __builtin_fmaf(mone, dc, db);
+        } else {
+            const int k = o - 12, t = k / 6, s = (k % 6) / 2;
+            const float l = rr[t][s][0], mm = rr[t][s][1], r = rr[t][s][2];
+            if ((o & 1) == 0) { v[par][t][s * 3 + 0] = l - mm; v[par][t][s * 3 + 1] = mm; }
+            else v[par][t][s * 3 + 2] = mm - r;
+        }
+    };
+    auto xform_slot = [&](int buf, int par, int p) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) {
+            if (o < 12 && o % 4 == 0 && T0 + o - 3 == p) read_col(buf, o / 4);
+            if (T0 + o == p) xform_op(par, o);
+        }
+    };
+
+    // ---- prologue ----
+    region_offsets(cn, ctx, cty);
+    issue_h(0);
+#pragma unroll
+    for (int j = 0; j < LU; ++j) issue_u(j, 0);
+    commit_h(0);
+#pragma unroll
+    for (int j = 0; j < LU; ++j) commit_u(j, 0);
+    region_offsets(n1, tx1, ty1);
+    issue_h(ch1);
+    commit_h(1);
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+        if (o < 12 && o % 4 == 0) read_col(0, o / 4);
+        xform_op(0, o);
+    }
+    __syncthreads();
+    region_offsets(n2, tx2, ty2);
+
+    float bvv[NBW];
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) bvv[nb] = a.bias ? a.bias[co_base + nb * 16 + m] : 0.f;
+    const float lo = a.relu ? 0.f : -__builtin_inff();
+    int spar = 0;
+
+    auto body = [&](auto PAR, auto FIRST) {
+        constexpr int par = decltype(PAR)::value;
+        constexpr bool first = decltype(FIRST)::value;
+        auto ldb = [&](int xi, int nb) {
+            bf[xi & 1][nb] = ((const f32x2*)smem)[(par ? b_u1 : b_u0) + (xi * NCO + nb * 16) * 4];
+        };
+        auto slot = [&](int p) {
+            if (p == 1) issue_h(ch2);
+            if (p >= 3 && p < 3 + 2 * LU && (p & 1)) issue_u((p - 3) >> 1, ch1);
+            if (p == CP) commit_h(par);
+            if (p > CP && p <= CP + LU) commit_u(p - CP - 1, par ^ 1);
+            xform_slot(par ^ 1, par ^ 1, p);
+        };
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) { ldb(0, nb); __builtin_amdgcn_sched_barrier(0); }
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int xi = 0; xi < 9; ++xi)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    if (k == 0 && xi + 1 < 9) ldb(xi + 1, nb);
+                    acc[xi][nb] = MFMA16(v[par][k][xi], k == 0 ? bf[xi & 1][nb].x : bf[xi & 1][nb].y, (first && k == 0) ? zero4 : acc[xi][nb]);
+                    slot((xi * 2 + k) * NBW + nb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    // Y = A^T M A over the nine M of a (tile, cout) entry: T0[j] = M0j + M1j, T1[j] = M1j - M3j; Y[a][0] = Ta[0] + Ta[1],
+    // Y[a][1] = Ta[1] - Ta[3].  C/D layout (16x16): col = lane & 15 (cout), row = 4 (lane >> 4) + r (tile column).
+    auto epilogue = [&]() {
+        const int yrow0 = cty * 16 + 2 * wv, xcol0 = ctx * 32 + 8 * q;
+        const int H = 2 * h, W = 2 * w;
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            float yv[16];      // [r][a][b]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t0[3], t1[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    t0[j] = acc[j][nb][r] + acc[3 + j][nb][r];
+                    t1[j] = acc[3 + j][nb][r] - acc[6 + j][nb][r];
+                }
+                yv[r * 4 + 0] = fmaxf((t0[0] + t0[1]) + bvv[nb], lo);
+                yv[r * 4 + 1] = fmaxf((t0[1] - t0[2]) + bvv[nb], lo);
+                yv[r * 4 + 2] = fmaxf((t1[0] + t1[1]) + bvv[nb], lo);
+                yv[r * 4 + 3] = fmaxf((t1[1] - t1[2]) + bvv[nb], lo);
+            }
+            const unsigned co = (unsigned)(co_base + nb * 16 + m);
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const int yy = yrow0 + aa;
+                const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cout + co;
+                const int voff = (int)sel_u32(yy < H, base * 4u, 0xFFFFFFFFu);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+            }
+            if (a.stats) {     // uniform: h % 8 == 0 whenever statistics are requested
+                float s1, s2;
+                lane_stats<16>(yv, s1, s2);
+                stat_merge_eq(s1, s2, __shfl_xor(s1, 16, 64), __shfl_xor(s2, 16, 64), 1.f / 32.f);
+                stat_merge_eq(s1, s2, __shfl_xor(s1, 32, 64), __shfl_xor(s2, 32, 64), 1.f / 64.f);
+                if (lane < 16) {
+                    float* R = Rs + spar * (8 * NCO * 2) + (wv * NCO + nb * 16 + lane) * 2;
+                    R[0] = s1;
+                    R[1] = s2;
+                }
+            }
+        }
+        if (a.stats) {
+            __syncthreads();
+            if (tid < NCO) {
+                const float* R = Rs + spar * (8 * NCO * 2) + tid * 2;
+                float s1 = R[0], s2 = R[1];              // the eight tile rows of 64 pixels, merged in order
+#pragma unroll
+                for (int r = 1; r < 8; ++r) stat_merge(s1, s2, 64.f * r, R[r * NCO * 2], R[r * NCO * 2 + 1], 64.f);
+                const int t = (cn * a.tilesX + ctx) * a.tilesY + cty;
+                float* o = a.stats + ((size_t)t * Cout + co_base + tid) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
+            spar ^= 1;
+        }
+    };
+
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    auto shift = [&]() {
+        cn = n1; ctx = tx1; cty = ty1; ch = ch1;
+        n1 = n2; tx1 = tx2; ty1 = ty2; ch1 = ch2;
+        advance(n2, tx2, ty2, ch2);
+    };
+    for (int reg = 0; reg < my_tiles; ++reg) {     // nch is even
+        body(P0{}, std::true_type{});
+        __syncthreads();
+        shift();
+        body(P1{}, std::false_type{});
+        __syncthreads();
+        for (int c = 2; c < nch; c += 2) {
+            shift();
+            if (ch2 == 0) region_offsets(n2, tx2, ty2);
+            body(P0{}, std::false_type{});
+            __syncthreads();
+            shift();
+            body(P1{}, std::false_type{});
+            __syncthreads();
+        }
+        epilogue();
+        shift();
+        if (ch2 == 0) region_offsets(n2, tx2, ty2);
+    }
+}
+
 }  // namespace
 
 // Shapes served: full-resolution width a multiple of 32; Cout % 16 (an even number of 8-channel chunks); Cin % 64.
@@ -399,4 +697,34 @@ int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, in
     a.nbg = (unsigned)(P / 4 * Cin * 4);
     if (Cin % 128 == 0) return launch_up_dgrad<8>(a, st);
     return launch_up_dgrad<4>(a, st);
+}
+
+// Forward: Cin % 16 (an even number of chunks), Cout % 64, full-resolution width a multiple of 32
+bool conv_wino_up_fwd_ok(int Cin, int Cout, int N, int h, int w) {
+    if (!g_wup_env || Cin % 16 != 0 || Cout % 64 != 0 || (2 * w) % 32 != 0 || h < 1 || N < 1) return false;
+    const long P = (long)N * 4 * h * w;
+    return P * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
+}
+int conv_wino_up_stat_tiles(int h, int w) { return (h % 8 == 0 && w % 16 == 0) ? (h / 8) * (w / 16) : 0; }
+int conv_wino_up_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
+                     hipStream_t st, float* stats) {
+    constexpr size_t lds = (size_t)(2 * 10 * 18 * WF_KPH + 2 * 9 * 64 * 8 + 2 * 8 * 64 * 2) * sizeof(float);
+    WUpFwArgs a;
+    a.x = x_low; a.u = ws; a.bias = bias; a.y = y;
+    a.N = N; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = ceil_div(h, 8); a.tilesX = w / 16; a.nsp = N * a.tilesY * a.tilesX;
+    a.ntn = Cout / 64; a.nch = Cin / 8;
+    a.relu = relu;
+    a.stats = stats;
+    const long Pl = (long)N * h * w;
+    a.nbx = (unsigned)(Pl * Cin * 4);
+    a.nbu = (unsigned)(9L * Cout * Cin * 4);
+    a.nby = (unsigned)(4 * Pl * Cout * 4);
+    int groups = g_wup_max_blocks / a.ntn;
+    if (groups < 1) groups = 1;
+    const int even = ceil_div(a.nsp, groups);
+    a.kt = even < 1 ? 1 : even;
+    k_conv_wino_up_fwd<<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino_up_fwd");
+    return VQW_OK;
 }
