@@ -359,8 +359,9 @@ extern "C" int vqw_conv3x3_up2_wgrad(const float* x_low, const float* dy, float*
     VQW_CHECK(x_low && dy && dw_ohwi && ws && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_wgrad: bad arguments");
     VQW_CHECK(conv_up2_wgrad_ok(Cin, Cout, N, h, w), "vqw_conv3x3_up2_wgrad: unsupported shape (query ..._wgrad_supported)");
     VQW_CHECK(ws_bytes >= vqw_conv3x3_up2_wgrad_ws_bytes(Cin, Cout, N, h, w), "vqw_conv3x3_up2_wgrad: workspace too small");
-    const double flops = 2.0 * N * h * w * 16.0 * Cout * Cin;
+    const bool wino = conv_up2_wgrad_is_wino(Cin, Cout, N, h, w);
+    const double flops = 2.0 * N * h * w * (wino ? 9.0 : 16.0) * Cout * Cin;
     const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * Cout + 9.0 * Cout * Cin);
-    ProfScope ps(1, flops, (hipStream_t)stream, bytes);
+    ProfScope ps(wino ? 4 : 1, flops, (hipStream_t)stream, bytes);
     return conv_up2_wgrad(x_low, dy, dw_ohwi, dbias, (float*)ws, N, h, w, Cin, Cout, accumulate, (hipStream_t)stream);
 }

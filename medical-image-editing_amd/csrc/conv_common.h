@@ -78,6 +78,11 @@ int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream
 int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st);
 bool conv_up2_dgrad_is_wino(int Cin, int Cout, int N, int h, int w);
 bool conv_up2_fwd_is_wino(int Cin, int Cout, int N, int h, int w);
+bool conv_up2_wgrad_is_wino(int Cin, int Cout, int N, int h, int w);
+bool conv_wino_up_wgrad_ok(int Cin, int Cout, int N, int h, int w);
+size_t conv_wino_up_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w);
+int conv_wino_up_wgrad(const float* x_low, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,
+                       int acc, hipStream_t st);
 bool conv_wino_up_fwd_ok(int Cin, int Cout, int N, int h, int w);
 int conv_wino_up_stat_tiles(int h, int w);
 int conv_wino_up_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,

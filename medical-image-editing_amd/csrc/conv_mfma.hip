@@ -1054,10 +1054,14 @@ bool conv_up2_wgrad_ok(int Cin, int Cout, int N, int h, int w) {
     return (w % 16 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && Cin >= 8 && Cout >= 8 && fits_u32(4L * N * h * w, Cin, Cout);
 }
 size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) {
+    if (conv_wino_up_wgrad_ok(Cin, Cout, N, h, w)) return conv_wino_up_wgrad_ws_floats(Cin, Cout, N, h, w);
     return (size_t)wgup_split_blocks(Cin, Cout, (long)N * h * w) * 4 * 2 * ((size_t)Cout * 8 * Cin + Cout);
 }
+bool conv_up2_wgrad_is_wino(int Cin, int Cout, int N, int h, int w) { return conv_wino_up_wgrad_ok(Cin, Cout, N, h, w); }
 int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,
                    int acc, hipStream_t st) {
+    if (conv_wino_up_wgrad_ok(Cin, Cout, N, h, w))        // Winograd form, nine products (conv_wino_up.hip)
+        return conv_wino_up_wgrad(xlow, dy, dw, dbias, ws, N, h, w, Cin, Cout, acc, st);
     const long Plow = (long)N * h * w;
     const int n_ci_t = ceil_div(Cin, 32), ntiles = ceil_div(Cout, 32) * n_ci_t;
     const int nsb = wgup_split_blocks(Cin, Cout, Plow);

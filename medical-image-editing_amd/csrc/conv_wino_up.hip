@@ -645,6 +645,316 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_fwd(WUpFwArgs a) {
     }
 }
 
+
+// =====================================================================================================================
+// Weight gradient: dU[xi][co][ci] = sum over tiles of dM[xi][tile][co] V[xi][tile][ci] for the nine xi,  dW = G^T dU G
+// =====================================================================================================================
+//   dM = A dY A^T from the full-resolution 2 x 2 tile of dY: rows (y0., y0. + y1., y1.) x columns (p0, p0 + p1, p1) - 5 add per
+//   16-cout block (the signs of row / column 3 are folded into the final transform); V from the low-resolution 3 x 3 patch of
+//   x as in the forward kernel (12 add / sub per 16-channel block; the factor 2 of row / column 1 folded likewise).
+//   Workgroup = (32 co x 32 ci) block of all nine dU over a run of 8 x 32 pixel regions (64 tiles); its 8 waves split K
+//   (wave = tile row w >> 1, tile columns 8 (w & 1) ..: two k-steps of 4 tiles): 34 VALU per 36 MFMAs, operands built one
+//   k-step ahead of their MFMAs (across the region barrier too).  One slab [Cout][9][Cin] per workgroup + fused bias partial.
+struct WUpWgArgs {
+    const float* x;            // (N, h, w, Cin) low resolution
+    const float* dy;           // (N, 2h, 2w, Cout)
+    float* part;               // [nsb][Cout][9][Cin]
+    float* bias_part;          // [nsb][Cout] or null
+    int N, h, w, Cin, Cout;
+    int tilesY, tilesX, nsp;
+    int n_ci_b, nblk, kt;
+    unsigned nbx, nbd;
+};
+
+constexpr int WW_DP = 40, WW_XP = 48;      // floats per dY pixel (32 co + 8: tiles 2 pixels apart) / per low-res X pixel (32 ci + 16: 1 pixel apart)
+
+__global__ void __launch_bounds__(512, 1) k_conv_wino_up_wgrad(WUpWgArgs a) {
+    constexpr int NT = 512;
+    constexpr int DBUF = 256 * WW_DP;                      // 8 x 32 pixels of dY
+    constexpr int XR = 6, XW = 18, XPIX = XR * XW;         // low-resolution halo of the region's 4 x 16 tiles
+    constexpr int XBUF = XPIX * WW_XP;
+    constexpr int XF = XPIX * 8;                           // 864 float4
+    constexpr int LX = (XF + NT - 1) / NT;                 // 2
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: dY tiles [2][DBUF], X halos [2][XBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int trow = wv >> 1, thalf = wv & 1;
+    const int h = a.h, w = a.w, Cin = a.Cin, Cout = a.Cout;
+    const int H = 2 * h, W = 2 * w;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = lb % a.nblk, sblk = lb / a.nblk;
+    const int co_base = (blk / a.n_ci_b) * 32, ci_base = (blk % a.n_ci_b) * 32;
+    const int sp0 = sblk * a.kt;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int per_img = a.tilesY * a.tilesX;
+    const bool do_bias = a.bias_part != nullptr && ci_base == 0;
+
+    // ---- loader slots ----
+    // dY float4 f = tid + 512 j -> pixel f / 8 = (tid >> 3) + 64 j (two rows of 32 per slot), co quad tid & 7
+    const int d_px = tid >> 3;
+    const unsigned d_fix = ((unsigned)((d_px >> 5) * W + (d_px & 31)) * Cout + co_base + (tid & 7) * 4) * 4u;
+    const unsigned d_jstride = (unsigned)(2 * W) * Cout * 4u;
+    const int d_lds = d_px * WW_DP + (tid & 7) * 4;                       // + j * 64 * WW_DP
+    // X float4 f -> halo pixel f / 8, ci quad f % 8
+    unsigned x_fix[LX];
+    int x_lds[LX];
+    unsigned x_bits = 0;
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+        int f = tid + j * NT;
+        if (f >= XF) f -= XF;
+        const int hp = f >> 3, hy = hp / XW, hx = hp - hy * XW;
+        x_fix[j] = ((unsigned)(hy * w + hx) * Cin + ci_base + (tid & 7) * 4) * 4u;      // against the low-res pixel (y0 - 1, x0 - 1)
+        x_lds[j] = 2 * DBUF + hp * WW_XP + (tid & 7) * 4;
+        x_bits |= (unsigned)((hy == 0 ? 1 : 0) | (hy == XR - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == XW - 1 ? 8 : 0)) << (4 * j);
+    }
+    float4 rd[4], rx[LX];
+    float4 bsum;
+    bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+        float4 f;
+        unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        f.x = __uint_as_float(a0); f.y = __uint_as_float(a1); f.z = __uint_as_float(a2); f.w = __uint_as_float(a3);
+        return f;
+    };
+    __amdgpu_buffer_rsrc_t rsd, rsx;
+    unsigned x_edges = 0;
+    auto region_setup = [&](int n, int tx, int ty) {      // region = full-res rows 8 ty .., columns 32 tx ..; low-res rows 4 ty .., columns 16 tx ..
+        const long dpix = ((long)n * H + 8 * ty) * W + 32 * tx;
+        const long doff = dpix * Cout * 4;
+        rsd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + doff), 0, (int)(unsigned)((long)a.nbd - doff), 0x00020000);
+        const long xpix = ((long)n * h + 4 * ty - 1) * w + 16 * tx - 1;   // may lie before the tensor (first region): masked
+        const long xoff = xpix * Cin * 4;
+        const long xleft = (long)a.nbx - xoff;
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
+        x_edges = ((ty == 0 ? 1u : 0u) | (4 * ty + 4 >= h ? 2u : 0u) | (tx == 0 ? 4u : 0u) | (16 * tx + 16 == w ? 8u : 0u)) * 0x11u;
+    };
+    auto issue_d = [&](int j) { rd[j] = ld4(rsd, d_fix, j * d_jstride); };
+    auto issue_x = [&](int j) {
+        const unsigned vo = (x_bits & x_edges & (0xFu << (4 * j))) ? 0xFFFFFFFFu : x_fix[j];
+        rx[j] = ld4(rsx, vo, 0);
+    };
+    float once_v = 1.f;
+    auto commit_d = [&](int j, int buf) {
+        *(float4*)&smem[d_lds + buf * DBUF + j * 64 * WW_DP] = rd[j];
+        if (do_bias) {
+            bsum.x = __builtin_fmaf(once_v, rd[j].x, bsum.x); bsum.y = __builtin_fmaf(once_v, rd[j].y, bsum.y);
+            bsum.z = __builtin_fmaf(once_v, rd[j].z, bsum.z); bsum.w = __builtin_fmaf(once_v, rd[j].w, bsum.w);
+        }
+    };
+    auto commit_x = [&](int j, int buf) { *(float4*)&smem[x_lds[j] + buf * XBUF] = rx[j]; };
+
+    // ---- fragment addressing: lane (channel idx = lane & 15, tile k = lane >> 4 of the k-step) ----
+    // k-step s of the wave: tile row trow, tile columns 8 thalf + 4 s + k
+    const int idx = lane & 15, k = lane >> 4;
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    const int a_0 = opaque(((2 * trow) * 32 + 2 * (8 * thalf + k)) * WW_DP + idx);            // dY row 2 trow: + s * 8 px, + b px, + cb * 16
+    const int a_1 = opaque(((2 * trow + 1) * 32 + 2 * (8 * thalf + k)) * WW_DP + idx);
+    int x_r[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) x_r[r] = opaque(2 * DBUF + ((trow + r) * XW + 8 * thalf + k) * WW_XP + idx);      // + s * 4 px, + column px, + nbk * 16
+    float mone;
+    { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
+
+    f32x4 acc[9][2][2];                // [xi][co block][ci block]
+#pragma unroll
+    for (int xi = 0; xi < 9; ++xi)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[xi][cb][nb][q] = 0.f;
+    float dm[2][2][9];                 // [operand set][co block][xi]
+    float vv[2][2][9];                 // [operand set][ci block][xi]
+    float ra[2][4], rb[2][9], rc[2][6];        // raw dY / X values of two groups in flight; row combinations of an X group
+
+    // Operand build of k-step s from buffer nbuf: four groups, g = 0, 1 co block g (4 reads, 5 operations), g = 2, 3 ci block
+    // g - 2 (9 reads, 12 operations).  34 operations at positions 2..35 of a phase, a group's reads ahead of them.
+    auto rd_grp = [&](int nbuf, int s, int g, int i) {
+        if (g < 2) {
+            const int o = nbuf * DBUF + (s * 8 + (i & 1)) * WW_DP + g * 16;
+            ra[g & 1][i] = i < 2 ? smem[a_0 + o] : smem[a_1 + o];
+        } else {
+            const int o = nbuf * XBUF + (s * 4 + i % 3) * WW_XP + (g - 2) * 16;
+            rb[g & 1][i] = smem[x_r[i / 3] + o];
+        }
+    };
+    auto op_grp = [&](int set, int g, int i) {
+        if (g < 2) {       // rows (y0., y0. + y1., y1.), columns (p0, p0 + p1, p1)
+            float* d = dm[set][g];
+            const float* y = ra[g & 1];           // y00, y01, y10, y11
+            if (i == 0) { d[3] = y[0] + y[2]; d[0] = y[0]; d[2] = y[1]; }
+            if (i == 1) { d[5] = y[1] + y[3]; d[6] = y[2]; d[8] = y[3]; }
+            if (i == 2) d[1] = y[0] + y[1];
+            if (i == 3) d[4] = d[3] + d[5];
+            if (i == 4) d[7] = y[2] + y[3];
+        } else {           // rows R0 = a - b, R1 = b, R3 = b - c per patch column; then V[s][0] = R[l] - R[m], V[s][1] = R[m], V[s][3] = R[m] - R[r]
+            float* o = vv[set][g - 2];
+            const float* x = rb[g & 1];           // [row][column]
+            float* c = rc[g & 1];                 // [which: 0 = R0, 1 = R3][column]
+            if (i < 3) c[i] = __builtin_fmaf(mone, x[3 + i], x[i]);
+            else if (i < 6) c[i] = __builtin_fmaf(mone, x[6 + (i - 3)], x[3 + (i - 3)]);
+            else {
+                const int s = (i - 6) / 2, wh = (i - 6) & 1;
+                const float l = s == 0 ? c[0] : s == 1 ? x[3] : c[3], mm = s == 0 ? c[1] : s == 1 ? x[4] : c[4], r = s == 0 ? c[2] : s == 1 ? x[5] : c[5];
+                if (wh == 0) { o[s * 3] = l - mm; o[s * 3 + 1] = mm; }
+                else o[s * 3 + 2] = mm - r;
+            }
+        }
+    };
+    auto build_slot = [&](int nbuf, int s, int set, int p) {
+        // positions: 0-1 reads A0 (2 each) | 2-6 ops A0, reads A1 | 7-11 ops A1, reads B0 (2 each, 9) | 12-23 ops B0, reads B1 | 24-35 ops B1
+        if (p < 2) { rd_grp(nbuf, s, 0, 2 * p); rd_grp(nbuf, s, 0, 2 * p + 1); }
+        else if (p < 7) { op_grp(set, 0, p - 2); if (p - 2 < 4) rd_grp(nbuf, s, 1, p - 2); }
+        else if (p < 12) {
+            op_grp(set, 1, p - 7);
+            if (2 * (p - 7) < 9) rd_grp(nbuf, s, 2, 2 * (p - 7));
+            if (2 * (p - 7) + 1 < 9) rd_grp(nbuf, s, 2, 2 * (p - 7) + 1);
+        }
+        else if (p < 24) { op_grp(set, 2, p - 12); if (p - 12 < 9) rd_grp(nbuf, s, 3, p - 12); }
+        else op_grp(set, 3, p - 24);
+    };
+
+    // ---- region cursors ----
+    int cn = sp0 / per_img, ctx, cty;
+    {
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    auto next_region = [&](int& n, int& tx, int& ty) {
+        const int ty1 = ty + 1, wy = ty1 == a.tilesY ? 1 : 0;
+        ty = wy ? 0 : ty1;
+        const int tx1 = tx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        tx = wx ? 0 : tx1;
+        n += wx;
+    };
+    int ln = cn, ltx = ctx, lty = cty, lcount = 0;
+    auto load_advance = [&]() {
+        if (lcount + 1 < my_tiles) { next_region(ln, ltx, lty); ++lcount; once_v = 1.f; } else once_v = 0.f;
+        region_setup(ln, ltx, lty);
+    };
+    if (my_tiles > 0) {
+        region_setup(cn, ctx, cty);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_d(j);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) issue_x(j);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) commit_d(j, 0);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) commit_x(j, 0);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 36; ++p) build_slot(0, 0, 0, p);
+        load_advance();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_d(j);
+    }
+
+    // One phase = the 36 MFMAs of a k-step (operand set SET) + the build of the next k-step's operands (set SET ^ 1) from
+    // buffer NBUF.  LOADS: 0 = first k-step of a region (commits dY of the next region, issues and commits its X),
+    // 1 = second (issues dY of the region after the next).
+    auto phase = [&](auto SET, auto SNEXT, auto NBUF, auto WBUF, auto LOADS) {
+        constexpr int set = decltype(SET)::value, sn = decltype(SNEXT)::value, nbuf = decltype(NBUF)::value;
+        constexpr int wbuf = decltype(WBUF)::value, loads = decltype(LOADS)::value;
+#pragma unroll
+        for (int xi = 0; xi < 9; ++xi)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int p = xi * 4 + cb * 2 + nb;
+                    acc[xi][cb][nb] = MFMA16(dm[set][cb][xi], vv[set][nb][xi], acc[xi][cb][nb]);
+                    build_slot(nbuf, sn, set ^ 1, p);
+                    if (loads == 0 && p >= 1 && p < 1 + 2 * LX && (p & 1)) issue_x((p - 1) >> 1);
+                    if (loads == 0 && p >= 8 && p < 12) commit_d(p - 8, wbuf);
+                    if (loads == 0 && p >= 34 && p < 34 + LX) commit_x(p - 34, wbuf);
+                    if (loads == 1 && p >= 2 && p < 10 && (p & 1) == 0) issue_d((p - 2) >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    auto region = [&](auto BUF) {
+        constexpr int b = decltype(BUF)::value;
+        using B = std::integral_constant<int, b>;
+        using NB = std::integral_constant<int, b ^ 1>;
+        phase(I0{}, I1{}, B{}, NB{}, I0{});        // k-step 0, builds k-step 1; the next region's data land in the other buffers
+        __syncthreads();
+        load_advance();
+        phase(I1{}, I0{}, NB{}, B{}, I1{});        // k-step 1, builds k-step 0 of the next region; issues dY of the one after
+    };
+    for (int g = 0; g < my_tiles; g += 2) {
+        region(I0{});
+        if (g + 1 < my_tiles) region(I1{});
+    }
+
+    // ---- fold: the eight waves' partial sums meet in LDS one xi at a time; thread e keeps entries e and e + 512 of the 32 x 32 block ----
+    __syncthreads();
+    float* red = smem;                     // [8 waves][32 co][32 ci] = 32 KB
+    if (do_bias) {                         // threads with equal (tid & 7) hold the same 4 couts
+        *(float4*)&red[tid * 4] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            const int cq = tid >> 2, comp = tid & 3;
+            float sum = 0.f;
+            for (int i = 0; i < 64; ++i) sum += red[(i * 8 + cq) * 4 + comp];
+            a.bias_part[(size_t)sblk * Cout + co_base + tid] = sum;
+        }
+        __syncthreads();
+    }
+    int fold_w = wv * 1024 + (4 * (lane >> 4)) * 32 + idx, fold_r = tid;
+    asm volatile("" : "+v"(fold_w), "+v"(fold_r));
+    float du[2][9];
+#pragma unroll
+    for (int xi = 0; xi < 9; ++xi) {
+        // C/D layout (16x16): col = lane & 15 (ci), row = 4 (lane >> 4) + q (co within the block)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[fold_w + (cb * 16 + q) * 32 + nb * 16] = acc[xi][cb][nb][q];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int wq = 0; wq < 8; ++wq) t += red[wq * 1024 + e * 512 + fold_r];
+            // what the operands left out: the sign of dM's row / column 3, the factor 2 of V's row / column 1
+            const int si = xi / 3, sj = xi % 3;
+            const float f = (si == 2 ? -1.f : 1.f) * (sj == 2 ? -1.f : 1.f) * (si == 1 ? 2.f : 1.f) * (sj == 1 ? 2.f : 1.f);
+            du[e][xi] = f * t;
+        }
+        __syncthreads();
+    }
+    // dW = G^T dU G with the rows / columns (0, 1, 3) of G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int ent = e * 512 + tid, co = co_base + (ent >> 5), ci = ci_base + (ent & 31);
+        float tc[3][3];                    // [ky][column index 0, 1, 3]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float u0 = du[e][j], u1 = du[e][3 + j], u3 = du[e][6 + j];
+            tc[0][j] = u0 + 0.5f * u1;
+            tc[1][j] = 0.5f * u1;
+            tc[2][j] = u3 + 0.5f * u1;
+        }
+        float* o = a.part + (size_t)sblk * Cout * 9 * Cin + ((size_t)co * 9) * Cin + ci;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            o[(ky * 3 + 0) * Cin] = tc[ky][0] + 0.5f * tc[ky][1];
+            o[(ky * 3 + 1) * Cin] = 0.5f * tc[ky][1];
+            o[(ky * 3 + 2) * Cin] = tc[ky][2] + 0.5f * tc[ky][1];
+        }
+    }
+}
+
 }  // namespace
 
 // Shapes served: full-resolution width a multiple of 32; Cout % 16 (an even number of 8-channel chunks); Cin % 64.
@@ -727,4 +1037,55 @@ int conv_wino_up_fwd(const float* x_low, const float* ws, const float* bias, flo
     k_conv_wino_up_fwd<<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino_up_fwd");
     return VQW_OK;
+}
+
+// Weight gradient: Cin % 32, Cout % 32, low-resolution maps of whole 4 x 16 regions
+bool conv_wino_up_wgrad_ok(int Cin, int Cout, int N, int h, int w) {
+    if (!g_wup_env || Cin % 32 != 0 || Cout % 32 != 0 || w % 16 != 0 || h % 4 != 0 || N < 1) return false;
+    const long P = (long)N * 4 * h * w;
+    return P * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
+}
+static int wup_wgrad_blocks(int Cin, int Cout, int N, int h, int w, int* kt_out) {
+    const int nblk = (Cout / 32) * (Cin / 32);
+    const int nsp = N * (h / 4) * (w / 16);
+    int nsb = g_wup_max_blocks / nblk;
+    if (nsb > nsp) nsb = nsp;
+    if (nsb < 1) nsb = 1;
+    const int kt = ceil_div(nsp, nsb);
+    if (kt_out) *kt_out = kt;
+    return ceil_div(nsp, kt);
+}
+size_t conv_wino_up_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) {
+    return (size_t)wup_wgrad_blocks(Cin, Cout, N, h, w, nullptr) * ((size_t)Cout * 9 * Cin + Cout);
+}
+int conv_wino_up_wgrad(const float* x_low, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,
+                       int acc, hipStream_t st) {
+    constexpr size_t lds = (size_t)(2 * 256 * WW_DP + 2 * 6 * 18 * WW_XP) * sizeof(float);
+    static_assert(lds <= 160 * 1024 && lds >= 36 * 1024, "wgrad tiles / fold area");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino_up_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            vqw_set_error("conv_wino_up_wgrad: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    int kt = 1;
+    const int nsb = wup_wgrad_blocks(Cin, Cout, N, h, w, &kt);
+    const long nout = (long)Cout * 9 * Cin;
+    WUpWgArgs a;
+    a.x = x_low; a.dy = dy; a.part = ws; a.bias_part = dbias ? ws + (size_t)nsb * nout : nullptr;
+    a.N = N; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = h / 4; a.tilesX = w / 16; a.nsp = N * a.tilesY * a.tilesX;
+    a.n_ci_b = Cin / 32; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
+    const long Pl = (long)N * h * w;
+    a.nbx = (unsigned)(Pl * Cin * 4);
+    a.nbd = (unsigned)(4 * Pl * Cout * 4);
+    k_conv_wino_up_wgrad<<<a.nblk * nsb, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino_up_wgrad");
+    if (dbias) {
+        int rc = reduce_rows(a.bias_part, dbias, Cout, nsb, st, acc);
+        if (rc) return rc;
+    }
+    return reduce_rows(ws, dw, nout, nsb, st, acc);
 }
