@@ -1053,9 +1053,14 @@ static inline int wgup_split_blocks(int Cin, int Cout, long Plow) {
 bool conv_up2_wgrad_ok(int Cin, int Cout, int N, int h, int w) {
     return (w % 16 == 0) && (Cin % 4 == 0) && (Cout % 4 == 0) && Cin >= 8 && Cout >= 8 && fits_u32(4L * N * h * w, Cin, Cout);
 }
-size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) {
-    if (conv_wino_up_wgrad_ok(Cin, Cout, N, h, w)) return conv_wino_up_wgrad_ws_floats(Cin, Cout, N, h, w);
+// slabs of k_conv_wgrad_up (also what the 4x4 stride-2 weight gradient below sizes its workspace with)
+static size_t wgup_ws_floats(int Cin, int Cout, int N, int h, int w) {
     return (size_t)wgup_split_blocks(Cin, Cout, (long)N * h * w) * 4 * 2 * ((size_t)Cout * 8 * Cin + Cout);
+}
+size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) {
+    const size_t a = wgup_ws_floats(Cin, Cout, N, h, w);
+    const size_t b = conv_wino_up_wgrad_ok(Cin, Cout, N, h, w) ? conv_wino_up_wgrad_ws_floats(Cin, Cout, N, h, w) : 0;
+    return a > b ? a : b;
 }
 bool conv_up2_wgrad_is_wino(int Cin, int Cout, int N, int h, int w) { return conv_wino_up_wgrad_ok(Cin, Cout, N, h, w); }
 int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,
@@ -1099,7 +1104,7 @@ __global__ void __launch_bounds__(256) k_reduce_wg_k4s2(const float* __restrict_
     }
 }
 bool conv_k4s2_wgrad_ok(int Cin, int Cout, int N, int h, int w) { return conv_up2_wgrad_ok(Cout, Cin, N, h, w); }
-size_t conv_k4s2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) { return conv_up2_wgrad_ws_floats(Cout, Cin, N, h, w); }
+size_t conv_k4s2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w) { return wgup_ws_floats(Cout, Cin, N, h, w); }
 int conv_k4s2_wgrad(const float* x_high, const float* gy_low, float* dw, float* ws, int N, int h, int w, int Cin, int Cout, int acc,
                     hipStream_t st) {
     const long Plow = (long)N * h * w;
