@@ -262,13 +262,18 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino(WinoArgs a) {
     };
 
     // V = B^T d B of the lane's tile at its two channels.  The 64 add / sub of an item's transform are single VALU
-    // instructions placed two per MFMA in the second half of the PREVIOUS item (inline asm: the compiler's SLP pass would
-    // pair them into v_pk_add_f32, which holds the vector issue port twice as long beside MFMAs), column by column as the
-    // patch columns arrive from LDS, then row by row.  Their results are first read by MFMAs of the next item, a barrier
-    // later: the compiler's hazard recogniser does not see VALU writes inside inline asm, so an MFMA must never read
-    // one within a few instructions (k_conv_wino_wgrad below keeps its transform in plain C for that reason).
-    auto fadd = [](float x, float y) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-    auto fsub = [](float x, float y) { float r; asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    // instructions placed two per MFMA in the second half of the PREVIOUS item, column by column as the patch columns arrive
+    // from LDS, then row by row.  They are written as fma with +1 / -1 held in registers the compiler cannot see through:
+    // x + 1 * y and x - 1 * y round exactly like the add / sub they stand for, the vector combiner cannot pair them into
+    // v_pk_add_f32 over the two channels of a ds_read_b64 (which holds the vector issue port 2-3 times as long beside MFMAs),
+    // and - unlike the inline-asm v_add / v_sub this kernel used before - they are ordinary instructions to the compiler's
+    // hazard recogniser (a VALU write inside inline asm followed closely by the MFMA that reads it gave a stale operand in
+    // the weight-gradient kernel below).
+    float pone, mone;
+    { float c = 1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(pone) : "v"(c)); }
+    { float c = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(c)); }
+    auto fadd = [&](float x, float y) { return __builtin_fmaf(pone, y, x); };
+    auto fsub = [&](float x, float y) { return __builtin_fmaf(mone, y, x); };
     f32x2 dcol[2][4];                  // two patch columns in flight
     float e[2][4][4];                  // [channel][row][column] after the column pass
     float v[2][2][16];                 // [parity of the item][channel of the pair][xi]

@@ -217,8 +217,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_dgrad(WUpDgArgs a) {
     // (indices in units of f32x2: a float index that went through `opaque` carries no alignment and the 8-byte fragment read
     // would be split into ds_read2_b32 with a VALU add each)
     const int b_u0 = opaque((2 * HBUF + m * 8 + b_swz) / 2), b_u1 = opaque((2 * HBUF + UBUF + m * 8 + b_swz) / 2);      // + (xi * NCO + nb * 16) * 4
-    float mone;
+    float mone, pone;                  // -1 / +1 the compiler cannot see through: x + pone * y rounds like x + y and is never paired into v_pk_add_f32
     { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
+    { float s = 1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(pone) : "v"(s)); }
 
     f32x4 acc[NBW];
     f32x2 bf[2][NBW];
@@ -236,11 +237,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_dgrad(WUpDgArgs a) {
         if (o < 24) {
             const int c = o / 6, t = (o % 6) / 3, s = o % 3;
             const float d0 = dcol[c & 1][0][t], d1 = dcol[c & 1][1][t], d2 = dcol[c & 1][2][t], d3 = dcol[c & 1][3][t];
-            e[t][s][c] = s == 0 ? __builtin_fmaf(mone, d2, d0) : s == 1 ? d1 + d2 : __builtin_fmaf(mone, d3, d1);
+            e[t][s][c] = s == 0 ? __builtin_fmaf(mone, d2, d0) : s == 1 ? __builtin_fmaf(pone, d2, d1) : __builtin_fmaf(mone, d3, d1);
         } else {
             const int k = o - 24, t = k / 9, s = (k % 9) / 3, sj = k % 3;
             const float e0 = e[t][s][0], e1 = e[t][s][1], e2 = e[t][s][2], e3 = e[t][s][3];
-            v[par][t][s * 3 + sj] = sj == 0 ? e0 - e2 : sj == 1 ? e1 + e2 : e1 - e3;
+            v[par][t][s * 3 + sj] = sj == 0 ? __builtin_fmaf(mone, e2, e0) : sj == 1 ? __builtin_fmaf(pone, e2, e1) : __builtin_fmaf(mone, e3, e1);
         }
     };
     auto op_pos = [](int o) { return T0 + (o * OPSTEP2) / 2; };
@@ -465,8 +466,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_fwd(WUpFwArgs a) {
     for (int r = 0; r < 3; ++r) a_row[r] = opaque((((wv + r) * LWS + m) * WF_KPH + 2 * q) / 2);
     const int b_swz = ((q >> 1) ^ (m >> 3)) * 4 + (q & 1) * 2;
     const int b_u0 = opaque((2 * HBUF + m * 8 + b_swz) / 2), b_u1 = opaque((2 * HBUF + UBUF + m * 8 + b_swz) / 2);
-    float mone;
+    float mone, pone;                  // -1 / +1 the compiler cannot see through: x + pone * y rounds like x + y and is never paired into v_pk_add_f32
     { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
+    { float s = 1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(pone) : "v"(s)); }
 
     f32x4 acc[9][NBW];
     f32x2 bf[2][NBW];
@@ -490,8 +492,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_fwd(WUpFwArgs a) {
         } else {
             const int k = o - 12, t = k / 6, s = (k % 6) / 2;
             const float l = rr[t][s][0], mm = rr[t][s][1], r = rr[t][s][2];
-            if ((o & 1) == 0) { v[par][t][s * 3 + 0] = l - mm; v[par][t][s * 3 + 1] = mm; }
-            else v[par][t][s * 3 + 2] = mm - r;
+            if ((o & 1) == 0) { v[par][t][s * 3 + 0] = __builtin_fmaf(mone, mm, l); v[par][t][s * 3 + 1] = mm; }
+            else v[par][t][s * 3 + 2] = __builtin_fmaf(mone, r, mm);
         }
     };
     auto xform_slot = [&](int buf, int par, int p) {
@@ -756,8 +758,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_wgrad(WUpWgArgs a) {
     int x_r[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) x_r[r] = opaque(2 * DBUF + ((trow + r) * XW + 8 * thalf + k) * WW_XP + idx);      // + s * 4 px, + column px, + nbk * 16
-    float mone;
+    float mone, pone;                  // -1 / +1 the compiler cannot see through: x + pone * y rounds like x + y and is never paired into v_pk_add_f32
     { float s = -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(mone) : "v"(s)); }
+    { float s = 1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(pone) : "v"(s)); }
 
     f32x4 acc[9][2][2];                // [xi][co block][ci block]
 #pragma unroll

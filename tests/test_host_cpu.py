@@ -434,3 +434,37 @@ def test_brats_and_crc_dataset_branches(tmp_path):
     b = next(iter(get_data_loader('train', 'CRCDataset', str(crc), 4, 0, drop_last=True)))
     assert tuple(b["image"].shape) == (4, 1, 8, 8)
     assert torch.allclose(b["image"][b["slice_num"] == 5], torch.tensor(1.0)) and torch.allclose(b["image"][b["slice_num"] == 2], torch.tensor(-0.6))
+
+
+def test_winograd_kernels_hold_no_inline_asm_arithmetic_and_no_packed_adds(tmp_path):
+    """The Winograd kernels run VALU transforms beside MFMAs that read their results.  Two build properties are pinned here on
+    the gfx950 assembly of the three files (hipcc cross-compiles without a GPU):
+      * no arithmetic inside inline asm - the compiler's hazard recogniser cannot see a VALU write made there, and an MFMA
+        that reads it too soon gets a stale operand (it happened in the weight-gradient kernel; the forward kernel used to
+        rely on "a barrier later").  The only inline asm allowed is an empty barrier or a v_mov_b32 of a constant;
+      * no v_pk_add / v_pk_fma / v_pk_mul: beside fp32 MFMAs a packed op costs 10-15 matrix-pipe cycles against 2 x 4.4
+        (profiles/r03_mfma_valu_microbench.txt); the build keeps the SLP pass off for these files and the kernels write the
+        transform so that the vector combiner cannot pair it."""
+    import re, shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "medical-image-editing_amd", "csrc")
+    files = ["conv_wino.hip", "conv_wino64.hip", "conv_wino_up.hip"]
+    procs = []
+    for f in files:
+        out = str(tmp_path / (f + ".s"))
+        procs.append((f, out, subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize",
+                                                "-S", "--offload-device-only", "-I", csrc, os.path.join(csrc, f), "-o", out],
+                                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for f, out, pr in procs:
+        log = pr.communicate(timeout=900)[0].decode()
+        assert pr.returncode == 0, log[-2000:]
+        text = open(out).read()
+        assert "v_mfma_f32_16x16x4_f32" in text, f
+        packed = re.findall(r"^\s*(v_pk_(?:add|fma|mul)_f32)", text, flags=re.M)
+        assert not packed, "%s: %d packed fp32 ops in the kernels" % (f, len(packed))
+        for block in re.findall(r";;#ASMSTART(.*?);;#ASMEND", text, flags=re.S):
+            for line in block.strip().splitlines():
+                line = line.strip()
+                assert line == "" or line.startswith(";") or line.startswith("v_mov_b32"), "%s: inline asm holds %r" % (f, line)
