@@ -160,7 +160,8 @@ def main():
         args.size = int(cfg.dataset.image_size)
     g = cfg.model.vqmodel
     torch.manual_seed(0)                                   # identical replicas on every rank
-    tr = build_first_step_trainer(cfg, device=dev, data_parallel=world > 1 or forced)
+    # (VQW_DP_FORCE_GRADS=0 with VQW_DP_FORCE=1: only the statistics collectives are forced - a measurement aid)
+    tr = build_first_step_trainer(cfg, device=dev, data_parallel=world > 1 or (forced and os.environ.get("VQW_DP_FORCE_GRADS", "1") != "0"))
     pool = [synthetic_batch(args.batch, args.size, 1234 + 1000 * rank + s, dev) for s in range(4)]
 
     # the dependency chain of the step runs on a high-priority stream, the off-chain weight gradients on the (normal
@@ -256,15 +257,15 @@ def main():
             # HBM bytes per launch of that family: NOT measured by this run (PMC counters need rocprofv3 around the
             # process) but read from the committed PMC passes of this same command (tools/pmc_traffic.py); the file
             # names the digest of the kernel sources it was taken with, and a stale or missing file gives null
-            traffic, traffic_source = None, "none: profiles/r02_hbm_traffic.json missing"
+            traffic, traffic_source = None, "none: profiles/r03_hbm_traffic.json missing"
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
                 if tj.get("csrc_digest") == csrc_digest():
                     # per API launch of the family (a call may be several kernel launches): bytes per step / calls per step
                     traffic = tj["families"][dom]["hbm_bytes_per_step"] / primary[dom]["launches_per_step"]
-                    traffic_source = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel sources %s)" % tj["csrc_digest"][:12]
+                    traffic_source = "profiles/r03_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel sources %s)" % tj["csrc_digest"][:12]
                 else:
-                    traffic_source = "none: profiles/r02_hbm_traffic.json was taken with other kernel sources"
+                    traffic_source = "none: profiles/r03_hbm_traffic.json was taken with other kernel sources"
             except Exception:
                 pass
             roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s",

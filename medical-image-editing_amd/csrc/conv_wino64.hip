@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
 #pragma unroll
     for (int i = 0; i < NBW / 2; ++i) bvv[i] = a.bias ? a.bias[co_base + (h * (NBW / 2) + i) * 16 + m] : 0.f;
     const float lo = a.relu ? 0.f : -__builtin_inff();
+    const bool plain = a.bias == nullptr && !a.relu;
     int spar = 0;
 
     // One item; PAR = its parity: operands v[PAR], halo of the NEXT item in buffer PAR ^ 1, U chunk in buffer PAR; the halo of
@@ -427,10 +428,15 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
                     float own[4];
                     partial(HH, w, hh * (NBW / 2) + i, r, own);
                     const float4 o = *(const float4*)&Xi[((w * (NBW / 2) + i) * 4 + r) * 256];
-                    yv[r * 4 + 0] = fmaxf((own[0] + o.x) + bvv[i], lo);
-                    yv[r * 4 + 1] = fmaxf((own[1] + o.y) + bvv[i], lo);
-                    yv[r * 4 + 2] = fmaxf((own[2] + o.z) + bvv[i], lo);
-                    yv[r * 4 + 3] = fmaxf((own[3] + o.w) + bvv[i], lo);
+                    if (plain) {       // uniform: an input-gradient launch (no bias, no ReLU) skips 3 of 4 VALU per output
+                        yv[r * 4 + 0] = own[0] + o.x; yv[r * 4 + 1] = own[1] + o.y;
+                        yv[r * 4 + 2] = own[2] + o.z; yv[r * 4 + 3] = own[3] + o.w;
+                    } else {
+                        yv[r * 4 + 0] = fmaxf((own[0] + o.x) + bvv[i], lo);
+                        yv[r * 4 + 1] = fmaxf((own[1] + o.y) + bvv[i], lo);
+                        yv[r * 4 + 2] = fmaxf((own[2] + o.z) + bvv[i], lo);
+                        yv[r * 4 + 3] = fmaxf((own[3] + o.w) + bvv[i], lo);
+                    }
                 }
                 const unsigned co = (unsigned)(co_base + (hh * (NBW / 2) + i) * 16 + m);
 #pragma unroll

@@ -885,8 +885,11 @@ def force_collectives(on=True):
     return old
 
 
+_FORCE_STATS = os.environ.get("VQW_DP_FORCE_STATS", "1") != "0"      # measurement aid: 0 = a forced one-rank run skips the statistics collectives
+
+
 def _dist_on():
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or (FORCE_COLLECTIVES and _FORCE_STATS))
 
 
 def _all_reduce(t):

@@ -1,17 +1,17 @@
 # Round profile: bench (default + 20 steps), rocprofv3 kernel summaries of the default and the serialised schedule, the two
 # PMC passes for HBM traffic; config 4 (training step + VQ alone) and config 5 (run_recon) with their kernel summaries.
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r02'   ->   gpurun_out/<tag>/...
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'   ->   gpurun_out/<tag>/...
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-# HBM traffic first: the bench lines below read profiles/r02_hbm_traffic.json (tied to the sources by digest)
+# HBM traffic first: the bench lines below read profiles/r03_hbm_traffic.json (tied to the sources by digest)
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 echo "fetch done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
 echo "write done"
-python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $R/profiles/r02_hbm_traffic.json > $O/hbm_traffic.txt
-cp $R/profiles/r02_hbm_traffic.json $O/hbm_traffic.json
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $R/profiles/r03_hbm_traffic.json > $O/hbm_traffic.txt
+cp $R/profiles/r03_hbm_traffic.json $O/hbm_traffic.json
 echo "traffic done"
 timeout -k 10 500 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench default done"
@@ -30,5 +30,15 @@ echo "cfg4 done"
 timeout -k 10 300 python3 $R/tools/recon_bench.py > $O/config5_recon_bench.txt 2> $O/config5.err
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg5 -o t -- python3 $R/tools/recon_bench.py > /dev/null 2> $O/cfg5.err
 echo "cfg5 done"
-rm -f $O/*/*kernel_trace.csv $O/*/*agent_info.csv
+# per-shape table of the three passes, SQ counters of the Winograd kernels on the verdict's shape, the RCCL path on one GPU
+timeout -k 10 300 python3 $R/tools/conv_bench.py > $O/conv_shapes.txt 2> /dev/null
+echo "conv shapes done"
+bash $R/tools/sq_counters.sh "128->128 k3 d1  @ 64" dgrad > $O/sq_dgrad.txt 2>&1
+bash $R/tools/sq_counters.sh "128->128 k3 d1  @ 64" wgrad > $O/sq_wgrad.txt 2>&1
+bash $R/tools/sq_counters.sh "256->128 k3 d1  @ 64 up" "" > $O/sq_up.txt 2>&1
+echo "sq done"
+cd /tmp
+VQW_DP_FORCE=1 timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline > $O/bench_rccl_world1.json 2> $O/bench_rccl_world1.err
+echo "rccl done"
+rm -f $O/*/*kernel_trace.csv $O/*/*agent_info.csv; rm -rf $R/gpurun_out/sq
 ls -la $O | head -40

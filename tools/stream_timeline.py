@@ -14,7 +14,7 @@ import csv
 import re
 import sys
 
-MF = ("k_conv_mfma", "k_conv_wgrad", "k_conv_halo")
+MF = ("k_conv_mfma", "k_conv_wgrad", "k_conv_halo", "k_conv_wino", "k_conv_dil", "k_vq_mfma")
 
 
 def ism(n):
