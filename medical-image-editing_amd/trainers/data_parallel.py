@@ -8,15 +8,30 @@ keep running.  `finish()` waits for the outstanding collectives and scatters the
 
 MI355X sizing: xGMI is point-to-point (7 links per GPU), so a ring all-reduce is per-link bound and the
 61.8 MB of fp32 gradients of the R-cfg model cost ~1 ms in total; few large buckets (default 16 MiB)
-keep launch/latency overhead negligible against a >100 ms step while still overlapping.
+keep launch/latency overhead negligible against a >100 ms step.
+
+Two schedules.  `overlap=False` (default, VQW_DP_OVERLAP=0): the buckets are exchanged in finish(), after the backward pass
+has been enqueued - four back-to-back all-reduces of 16 MiB on the main stream.  On this model the whole exchange is ~1 ms
+of a 98 ms step, while launching buckets from inside the backward pass (`overlap=True`) costs more than it hides: the
+stream that completes a bucket has to wait for every other producer stream of that bucket, which ties the two view streams
+and the weight-gradient lanes together (measured on one GPU with a one-rank RCCL group: +8.5 ms per step overlapped,
+profiles/r03_dp_one_gpu.txt).  The overlapped schedule stays for models whose gradient volume is worth hiding.
 Works unchanged on the gloo backend (CPU tests, world_size 2).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
+_HOST_TIMING = os.environ.get("VQW_DP_HOST_TIMING", "0") == "1"     # measurement aid: host time spent inside dist.all_reduce
+
+
 class GradientAllReducer:
-    def __init__(self, params, bucket_bytes=16 << 20, process_group=None):
+    host_ms_in_all_reduce = 0.0
+
+    def __init__(self, params, bucket_bytes=16 << 20, process_group=None, overlap=None):
+        self.overlap = (os.environ.get("VQW_DP_OVERLAP", "0") != "0") if overlap is None else bool(overlap)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = []       # list of lists of params
@@ -38,16 +53,19 @@ class GradientAllReducer:
         self._flat = [None] * len(self.buckets)
         # gradients that flow through autograd announce themselves via the hook; conv weight gradients written
         # out-of-band on the side stream announce themselves via hipops.ops.grad_ready_listeners (when importable)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
-        for p in params:           # hipops.ops.wgrad_through_autograd: these hooks do not force the autograd route
-            p.__dict__["_vqw_own_hooks"] = p.__dict__.get("_vqw_own_hooks", 0) + 1
+        self._hooks = []
         self._events = {}
         self._armed = False
         self.launches = 0          # gradient-bucket collectives issued (tools/dp_probe)
         self._sync_lanes = None
+        if self.overlap:
+            self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+            for p in params:       # hipops.ops.wgrad_through_autograd: these hooks do not force the autograd route
+                p.__dict__["_vqw_own_hooks"] = p.__dict__.get("_vqw_own_hooks", 0) + 1
         try:
             from hipops import ops as _ops
-            _ops.grad_ready_listeners.append(self._on_grad_listener)
+            if self.overlap:
+                _ops.grad_ready_listeners.append(self._on_grad_listener)
             self._sync_lanes = _ops.sync_wgrad_lanes
         except Exception:       # plain torch modules (CPU tests)
             pass
@@ -56,12 +74,13 @@ class GradientAllReducer:
         """Detach from the parameters: remove the hooks, give back the hook allowance, stop listening to the side stream."""
         for h in self._hooks:
             h.remove()
+        if self._hooks:
+            for b in self.buckets:
+                for p in b:
+                    n = p.__dict__.get("_vqw_own_hooks", 0)
+                    if n > 0:
+                        p.__dict__["_vqw_own_hooks"] = n - 1
         self._hooks = []
-        for b in self.buckets:
-            for p in b:
-                n = p.__dict__.get("_vqw_own_hooks", 0)
-                if n > 0:
-                    p.__dict__["_vqw_own_hooks"] = n - 1
         try:
             from hipops import ops as _ops
             if self._on_grad_listener in _ops.grad_ready_listeners:
@@ -91,7 +110,7 @@ class GradientAllReducer:
             self._on_grad(p)
 
     def _on_grad(self, p):
-        if not self._armed or id(p) in self._seen:
+        if not self.overlap or not self._armed or id(p) in self._seen:
             return          # a parameter may be announced by both the autograd hook and the side-stream listener
         if p.grad is None:
             return          # hook fired for a gradient that is written out-of-band: wait for the listener
@@ -107,7 +126,7 @@ class GradientAllReducer:
 
     def _launch(self, bi):
         grads = [p.grad for p in self.buckets[bi]]
-        if grads[0].is_cuda:
+        if self.overlap and grads[0].is_cuda:
             cur = torch.cuda.current_stream(grads[0].device)
             for p in self.buckets[bi]:
                 ev = self._events.pop(id(p), None)
@@ -120,15 +139,27 @@ class GradientAllReducer:
         # async: on RCCL the collective runs on the process group's own stream, ordered after the producing
         # kernels by the event torch.distributed records, so it overlaps with the rest of backward
         self.launches += 1
+        if _HOST_TIMING:
+            import time
+            t0 = time.perf_counter()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if _HOST_TIMING:
+            self.host_ms_in_all_reduce += (time.perf_counter() - t0) * 1e3
         self._work.append((bi, work))
 
     def finish(self):
         """Wait for every bucket, write the rank-mean back into p.grad."""
         if not self._armed:
             return
+        if not self.overlap:
+            # every gradient has been enqueued and the caller's stream is ordered after all producer streams
+            # (FirstStepTrainer joins the view stream and the weight-gradient lanes first): exchange the buckets now
+            for bi, b in enumerate(self.buckets):
+                if any(p.grad is None for p in b):
+                    raise RuntimeError("gradient bucket %d incomplete: a parameter received no gradient" % bi)
+                self._launch(bi)
         for bi, pend in enumerate(self._pending):
-            if pend != 0:      # parameters without gradient this step: reduce what is there
+            if self.overlap and pend != 0:      # parameters without gradient this step
                 raise RuntimeError("gradient bucket %d incomplete: a parameter received no gradient" % bi)
         inv = 1.0 / self.world
         for bi, work in self._work:

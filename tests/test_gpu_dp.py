@@ -67,7 +67,8 @@ def _run(world, tmp_path, tag, port, cross_w=1.0, extra_env=None):
     return [torch.load(out + ".%d" % r) for r in range(world)]
 
 
-def test_rccl_world_size_one_equals_plain_step(tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_rccl_world_size_one_equals_plain_step(tmp_path, overlap):
     """The data-parallel step over RCCL itself (backend "nccl"), as far as one GPU allows: a process group of ONE rank with
     every collective forced on (VQW_DP_FORCE=1) - the SyncBN statistics of both views on their two streams, the VQ EMA
     statistics, the gradient buckets flattened behind the weight-gradient lanes and all-reduced asynchronously on
@@ -75,7 +76,8 @@ def test_rccl_world_size_one_equals_plain_step(tmp_path):
     divides by 1, so losses, ids, VQ buffers, BN running statistics, averaged gradients and updated parameters must equal the
     non-distributed step BIT FOR BIT; a missing stream dependency shows up as a difference."""
     plain = _run(1, tmp_path, "plain1", 29631)[0]
-    rccl = _run(1, tmp_path, "rccl1", 29632, extra_env={"VQW_DP_FORCE": "1", "VQW_TEST_BACKEND": "nccl"})[0]
+    # overlap "0": the gradient buckets are exchanged in finish() (default); "1": launched from inside the backward pass
+    rccl = _run(1, tmp_path, "rccl1", 29632, extra_env={"VQW_DP_FORCE": "1", "VQW_TEST_BACKEND": "nccl", "VQW_DP_OVERLAP": overlap})[0]
     assert rccl["backend"] == "nccl" and plain["backend"] == ""
     assert plain["collectives"] == (0, 0)
     n_small, n_buckets = rccl["collectives"]

@@ -270,10 +270,12 @@ print("rank", rank, "ok")
 '''
 
 
-def test_data_parallel_gloo_world2(tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_data_parallel_gloo_world2(tmp_path, overlap):
+    """Both schedules of the gradient reducer: buckets exchanged in finish() (default) and launched from the backward pass."""
     script = tmp_path / "w.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="2961%d" % (1 + int(overlap)), WORLD_SIZE="2", VQW_DP_OVERLAP=overlap)
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r))
