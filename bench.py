@@ -143,6 +143,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29655")
     if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # tensors handed to a collective are kept alive by the work object instead of being recorded on RCCL's stream: a
+        # recorded block cannot be reused by the caching allocator until that stream has passed it (pool growth = hipMalloc
+        # stalls inside the step)
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:

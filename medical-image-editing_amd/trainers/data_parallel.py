@@ -24,6 +24,7 @@ import torch
 import torch.distributed as dist
 
 
+_SKIP_COLLECTIVE = os.environ.get("VQW_DP_DEBUG", "") == "noar"
 _HOST_TIMING = os.environ.get("VQW_DP_HOST_TIMING", "0") == "1"     # measurement aid: host time spent inside dist.all_reduce
 
 
@@ -51,6 +52,7 @@ class GradientAllReducer:
         self._pending = None
         self._work = []
         self._flat = [None] * len(self.buckets)
+        self._flat_buf = [None] * len(self.buckets)
         # gradients that flow through autograd announce themselves via the hook; conv weight gradients written
         # out-of-band on the side stream announce themselves via hipops.ops.grad_ready_listeners (when importable)
         self._hooks = []
@@ -134,7 +136,15 @@ class GradientAllReducer:
                     cur.wait_event(ev)
         # flatten in MEMORY order (grads may be channels_last): view each as its dense storage
         views = [_dense_1d(g) for g in grads]
-        flat = torch.cat(views)
+        # One persistent flat buffer per bucket: a fresh 16 MiB tensor per step that ProcessGroupNCCL records on its own
+        # stream cannot be reused by the caching allocator until that stream has passed it, so the pool grew by a device
+        # segment (hipMalloc, a device-wide stall) in most steps: 17 segments / +7 GB inside ten timed steps against 5 of
+        # the plain step, which was most of the data-parallel step's single-GPU cost (profiles/r03_dp_one_gpu.txt).
+        flat = self._flat_buf[bi]
+        n = sum(v.numel() for v in views)
+        if flat is None or flat.numel() != n or flat.device != views[0].device or flat.dtype != views[0].dtype:
+            flat = self._flat_buf[bi] = torch.empty(n, dtype=views[0].dtype, device=views[0].device)
+        torch.cat(views, out=flat)
         self._flat[bi] = (flat, views)
         # async: on RCCL the collective runs on the process group's own stream, ordered after the producing
         # kernels by the event torch.distributed records, so it overlaps with the rest of backward
@@ -142,6 +152,9 @@ class GradientAllReducer:
         if _HOST_TIMING:
             import time
             t0 = time.perf_counter()
+        if _SKIP_COLLECTIVE:       # measurement aid: flatten / scale / scatter without the collective (wrong on > 1 rank)
+            self._work.append((bi, None))
+            return
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if _HOST_TIMING:
             self.host_ms_in_all_reduce += (time.perf_counter() - t0) * 1e3
@@ -163,7 +176,8 @@ class GradientAllReducer:
                 raise RuntimeError("gradient bucket %d incomplete: a parameter received no gradient" % bi)
         inv = 1.0 / self.world
         for bi, work in self._work:
-            work.wait()
+            if work is not None:
+                work.wait()
             flat, views = self._flat[bi]
             flat.mul_(inv)
             pieces, off = [], 0
