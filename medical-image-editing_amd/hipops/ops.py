@@ -492,11 +492,16 @@ class _Conv2d(torch.autograd.Function):
         if want_stats:
             if part is not None:
                 ctx.mark_non_differentiable(part)
+            # (without this autograd hands backward a zero-filled "gradient" of the statistics partials: one fill launch per
+            # convolution and step, 108 of them)
+            ctx.set_materialize_grads(False)
             return y, part
         return y
 
     @staticmethod
     def backward(ctx, gy, *_):
+        if gy is None:             # y itself was not used (only possible with gradient materialisation off)
+            return (None,) * 10
         x0, x1, w, y_relu = ctx.saved_tensors
         dilation, up0, ks, N, H, W, Cout, has_bias = ctx.cfg
         need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
@@ -1064,10 +1069,13 @@ class _ResTail(torch.autograd.Function):
         pooled = empty_nhwc(N, C, H // 2, W // 2, a)
         _lib.check(L.vqw_res_tail_fwd(_p(a), _p(b), _p(out), _p(pooled), N, H, W, C, _st()), "vqw_res_tail_fwd")
         ctx.save_for_backward(out)
+        ctx.set_materialize_grads(False)       # an unused output's gradient arrives as None (the kernel takes a null pointer), not as a zero fill
         return pooled, out
 
     @staticmethod
     def backward(ctx, g_pooled, g_out):
+        if g_pooled is None and g_out is None:
+            return None, None
         (out,) = ctx.saved_tensors
         N, C, H, W = out.shape
         gp = nhwc(g_pooled) if g_pooled is not None else None
@@ -1113,10 +1121,13 @@ class _ResTailNorm(torch.autograd.Function):
         _lib.check(L.vqw_res_tail_norm_fwd(_p(x2), _p(mr2), _p(xid), _p(mrid), _p(out), _p(pooled), N, H, W, C, _st()),
                    "vqw_res_tail_norm_fwd")
         ctx.save_for_backward(x2, xid, mr2, mrid, out)
+        ctx.set_materialize_grads(False)
         return pooled, out
 
     @staticmethod
     def backward(ctx, g_pooled, g_out):
+        if g_pooled is None and g_out is None:
+            return None, None, None, None, None
         x2, xid, mr2, mrid, out = ctx.saved_tensors
         N, C, H, W = out.shape
         L = _L()
@@ -1346,10 +1357,13 @@ class _VQ(torch.autograd.Function):
         _order_end(embed, cur)
         ctx.save_for_backward(x, q)
         ctx.mark_non_differentiable(ids)
+        ctx.set_materialize_grads(False)       # no zero-filled gradient for the ids; an unused q / commit arrives as None
         return q, commit, ids
 
     @staticmethod
     def backward(ctx, gq, gcommit, _gids):
+        if gq is None and gcommit is None:
+            return (None,) * 9
         x, q = ctx.saved_tensors
         gq = nhwc(gq) if gq is not None else None
         gc = gcommit.contiguous() if gcommit is not None else None
