@@ -17,9 +17,10 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
     tr.training_step({"image": img}, noise=noise)
     torch.cuda.synchronize()
+NAMES = tuple(sys.argv[1:]) or ("aten::zero_", "aten::fill_", "aten::zeros", "aten::zeros_like", "aten::ones_like", "aten::full")
 agg = collections.Counter()
 for e in prof.events():
-    if e.name in ("aten::zero_", "aten::fill_", "aten::zeros", "aten::zeros_like", "aten::ones_like", "aten::full"):
+    if e.name in NAMES:
         st = [s for s in (e.stack or []) if "site-packages/torch" not in s and "dist-packages/torch" not in s][:2]
         agg[(e.name, str(e.input_shapes)[:60], " <- ".join(s[-70:] for s in st))] += 1
 for k, v in agg.most_common(25):
