@@ -43,7 +43,7 @@ int vqw_set_conv_backend(int mode);
  * on those events and fills out[6][4] = {launches, total ms, total FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA
  * wgrad, generic fwd, generic wgrad, Winograd-form fwd/dgrad/wgrad, HBM-bound norm / element-wise (bytes = tensor passes as
  * launched)}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of the direct
- * form's).  (ABI 6: the sixth family.)
+ * form's).  (ABI 6: the sixth family.  ABI 7: vqw_conv3x3_wino_fwd_masked.)
  * Not meant for graph capture; off by default.                                                              */
 int vqw_profile_begin(void);
 int vqw_profile_end(double* out);
@@ -119,6 +119,13 @@ size_t vqw_conv3x3_wino_ws_bytes(int Cin, int Cout);
 int vqw_conv3x3_wino_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream);
 int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
                          int relu, void* stream);
+/* ABI 7.  The same convolution with its outputs zeroed where mask <= 0 (mask shaped like y, no bias): the input gradient of
+ * a layer whose forward read the output of a fused ReLU (StyledDenorm's mlp_shared -> mlp_gamma | mlp_beta, blocks.py:63-66,
+ * 85-87) delivered in front of that ReLU - mask = the ReLU's output, i.e. the layer's own saved input - so that the
+ * separate mask pass (vqw_relu_bwd) is not needed.  Served where the 64-cout kernel is (..._masked_supported). */
+int vqw_conv3x3_wino_masked_supported(int Cin, int Cout, int N, int H, int W);
+int vqw_conv3x3_wino_fwd_masked(const float* x, const void* ws, const float* mask, float* y, int N, int H, int W, int Cin,
+                                int Cout, void* stream);
 int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W);
 int vqw_conv3x3_wino_fwd_stats(const float* x, const void* ws, const float* bias, float* y, float* part, int N, int H, int W,
                                int Cin, int Cout, void* stream);

@@ -11,7 +11,7 @@ extern "C" void vqw_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* vqw_last_error(void) { return g_err; }
-extern "C" int vqw_abi_version(void) { return 6; }
+extern "C" int vqw_abi_version(void) { return 7; }
 
 // ---------------------------------------------------------------------------------------------
 template <int RELU>

@@ -45,6 +45,8 @@ SIGNATURES = {
     "vqw_conv3x3_wino_ws_bytes": (c_sz, [c_i, c_i]),
     "vqw_conv3x3_wino_prepare": (c_i, [c_p, c_p, c_sz, c_i, c_i, c_p]),
     "vqw_conv3x3_wino_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_conv3x3_wino_masked_supported": (c_i, [c_i] * 5),
+    "vqw_conv3x3_wino_fwd_masked": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_wino_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_wino_fwd_stats": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_wgrad_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
@@ -128,7 +130,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def load():

@@ -515,6 +515,15 @@ class _Conv2d(torch.autograd.Function):
         return g0, g1, gw, gb, None, None, None, None, None, None
 
 
+# Gradients that arrive already multiplied by a fused ReLU's mask: {gradient data_ptr: data_ptr of the ReLU output it was masked
+# with}.  Written by a consumer whose input-gradient kernel applies the mask in its epilogue (vqw_conv3x3_wino_fwd_masked),
+# read (and removed) by the producer's backward, which then skips its own mask pass.  A gradient that autograd has summed
+# with another one has a different address: the producer masks it as usual (masking twice would be harmless, too).
+_MASKED_GRADS = {}
+FUSE_RELU_MASK = os.environ.get("VQW_FUSE_RELU_MASK", "1") != "0"
+masked_dgrad_calls = 0         # input-gradient launches that applied a ReLU mask in their epilogue (tests)
+
+
 def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb, group=None):
     """Input / weight / bias gradients of conv2d on the current stream -> (g0, g1, gw, gb, masked gy).  x0 / x1 / w are the
     NHWC tensors the forward saw, y_relu its output when the ReLU was fused (the incoming gradient is masked first),
@@ -525,9 +534,12 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
     H, W = (x0.shape[2] * 2, x0.shape[3] * 2) if up0 else (x0.shape[2], x0.shape[3])
     gy = nhwc(gy)
     if y_relu is not None:   # fused ReLU epilogue: mask the incoming gradient first
-        gm = torch.empty_like(y_relu, memory_format=CL)
-        _lib.check(L.vqw_relu_bwd(_p(y_relu), _p(gy), _p(gm), gy.numel(), _st()), "vqw_relu_bwd")
-        gy = gm
+        if _MASKED_GRADS.pop(gy.data_ptr(), None) == y_relu.data_ptr():
+            pass             # the consumer's input-gradient kernel has applied this very mask in its epilogue (_ConvCat.backward)
+        else:
+            gm = torch.empty_like(y_relu, memory_format=CL)
+            _lib.check(L.vqw_relu_bwd(_p(y_relu), _p(gy), _p(gm), gy.numel(), _st()), "vqw_relu_bwd")
+            gy = gm
     C0 = x0.shape[1]
     C1 = 0 if x1 is None else x1.shape[1]
     g0 = g1 = gw = gb = None
@@ -712,8 +724,9 @@ def _deferred_wgrad_cat(wa, ba, wb, bb, x0, gy, ks, N, H, W):
 
 class _ConvCat(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wa, ba, wb, bb, wino_fwd=False):
+    def forward(ctx, x, wa, ba, wb, bb, wino_fwd=False, relu_in=False):
         _dev(x, wa, ba, wb, bb)
+        ctx.relu_in = bool(relu_in)       # x is the output of a fused ReLU and has no other consumer
         x = nhwc(x)
         Ca, Cin, ks, _ = wa.shape
         Cb = wb.shape[0]
@@ -755,8 +768,18 @@ class _ConvCat(torch.autograd.Function):
             gx = empty_nhwc(N, Cin, H, W, gy)
             if ks == 3 and L.vqw_conv3x3_wino_supported(Ct, Cin, N, H, W):
                 ut = _cached(wa, "cat_wino_dgrad", lambda: _wino_weights(L, wt, Ct, Cin), deps=(wb,))
-                _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(gx), N, H, W, Ct, Cin, 0, _st()),
-                           "vqw_conv3x3_wino_fwd(dgrad)")
+                if ctx.relu_in and FUSE_RELU_MASK and L.vqw_conv3x3_wino_masked_supported(Ct, Cin, N, H, W):
+                    # the gradient in FRONT of the producer's ReLU: its mask (x > 0) applied in this kernel's epilogue
+                    _lib.check(L.vqw_conv3x3_wino_fwd_masked(_p(gy), _p(ut), _p(x), _p(gx), N, H, W, Ct, Cin, _st()),
+                               "vqw_conv3x3_wino_fwd_masked(dgrad)")
+                    if len(_MASKED_GRADS) > 64:
+                        _MASKED_GRADS.clear()
+                    _MASKED_GRADS[gx.data_ptr()] = x.data_ptr()
+                    global masked_dgrad_calls
+                    masked_dgrad_calls += 1
+                else:
+                    _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(gx), N, H, W, Ct, Cin, 0, _st()),
+                               "vqw_conv3x3_wino_fwd(dgrad)")
             else:
                 _lib.check(L.vqw_conv2d_fwd(_p(gy), Ct, 0, None, 0, _p(wt), None, _p(gx), N, H, W, Cin, ks, 1, 0, _st()),
                            "vqw_conv2d_fwd(dgrad)")
@@ -767,12 +790,14 @@ class _ConvCat(torch.autograd.Function):
             gb_ = torch.empty(Ct, dtype=torch.float32, device=gy.device)
             _run_wgrad(L, x, None, gy, gw, gb_, False, ks, 1, N, H, W, Ct, False, False)
             gwa, gwb, gba, gbb = gw[:Ca], gw[Ca:], gb_[:Ca], gb_[Ca:]
-        return gx, gwa, gba, gwb, gbb, None
+        return gx, gwa, gba, gwb, gbb, None, None
 
 
-def conv2d_cat(x, weight_a, bias_a, weight_b, bias_b):
-    """[conv(x, weight_a, bias_a) | conv(x, weight_b, bias_b)] along channels (3x3 / 1x1, stride 1, 'same')."""
-    return _ConvCat.apply(x, weight_a, bias_a, weight_b, bias_b, _decide_wino_fwd())
+def conv2d_cat(x, weight_a, bias_a, weight_b, bias_b, relu_input=False):
+    """[conv(x, weight_a, bias_a) | conv(x, weight_b, bias_b)] along channels (3x3 / 1x1, stride 1, 'same').
+    relu_input=True: x is the output of conv2d(..., relu=True) and feeds nothing else - the input gradient then leaves this
+    node already masked by that ReLU (one kernel epilogue instead of a separate pass over the gradient)."""
+    return _ConvCat.apply(x, weight_a, bias_a, weight_b, bias_b, _decide_wino_fwd(), bool(relu_input))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -156,7 +156,7 @@ class StyledDenorm(nn.Module):
         it ahead of / beside the trunk and hand it to forward()."""
         actv = self.mlp_shared[0](style, relu=True)
         if FUSE_GAMMA_BETA:     # one conv with [gamma | beta] output channels
-            return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias), None
+            return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias, relu_input=True), None
         return self.mlp_gamma(actv), self.mlp_beta(actv)
 
     def forward(self, x, style, relu=False, maps=None, residual=None, part=None):

@@ -549,6 +549,37 @@ def test_styled_denorm_gamma_beta_forms(golden, monkeypatch):
             assert gb_.data_ptr() == ga.data_ptr() + 4 * ga.numel()      # halves of one buffer, second pass accumulated in place
 
 
+@pytest.mark.parametrize("C,S", [(128, 32), (64, 64), (32, 64)])
+def test_relu_mask_in_the_gamma_beta_input_gradient_epilogue(monkeypatch, C, S):
+    """StyledDenorm's mlp_shared ReLU (blocks.py:63-66): the mask of its backward is applied in the epilogue of the gamma | beta
+    convolution's input-gradient kernel (vqw_conv3x3_wino_fwd_masked) instead of a separate pass over the gradient.  Same
+    values either way, so every gradient must be bit-equal to the run with the separate pass - and the fused launch must
+    actually have been taken on these shapes (64-cout tile and the 2 x 32-cout tile)."""
+    from networks import blocks as B
+    from hipops import ops
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSE_RELU_MASK", fused)
+        torch.manual_seed(3)
+        mod = B.StyledDenorm(C, C).to(DEV).train()
+        x = torch.randn(2, C, S, S, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        style = torch.randn(2, C, S, S, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        r = torch.randn(2, C, S, S, device=DEV).contiguous(memory_format=torch.channels_last)
+        n0 = ops.masked_dgrad_calls
+        (mod(x, style) * r).sum().backward()
+        torch.cuda.synchronize()
+        grads = {"x": x.grad.clone(), "style": style.grad.clone()}
+        grads.update({k: p.grad.clone() for k, p in mod.named_parameters()})
+        return grads, ops.masked_dgrad_calls - n0
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == 1, (n_ref, n_got)
+    assert not ops._MASKED_GRADS, "a masked gradient was announced and never consumed"
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), "gradient %s differs between the fused and the separate ReLU mask" % k
+    assert float(ref["style"].abs().max()) > 0
+
+
 # --------------------------------------------------------------------------------------------------
 # vector quantiser
 # --------------------------------------------------------------------------------------------------
