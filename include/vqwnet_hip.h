@@ -43,7 +43,7 @@ int vqw_set_conv_backend(int mode);
  * on those events and fills out[6][4] = {launches, total ms, total FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA
  * wgrad, generic fwd, generic wgrad, Winograd-form fwd/dgrad/wgrad, HBM-bound norm / element-wise (bytes = tensor passes as
  * launched)}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of the direct
- * form's).  (ABI 6: the sixth family.  ABI 7: vqw_conv3x3_wino_fwd_masked.)
+ * form's).  (ABI 6: the sixth family.  ABI 7: vqw_conv3x3_wino_fwd_masked, vqw_conv3x3_wino_fwd_acc.)
  * Not meant for graph capture; off by default.                                                              */
 int vqw_profile_begin(void);
 int vqw_profile_end(double* out);
@@ -126,6 +126,11 @@ int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float* bias, floa
 int vqw_conv3x3_wino_masked_supported(int Cin, int Cout, int N, int H, int W);
 int vqw_conv3x3_wino_fwd_masked(const float* x, const void* ws, const float* mask, float* y, int N, int H, int W, int Cin,
                                 int Cout, void* stream);
+/* y += conv(x) (no bias): a later member of a gradient group - several convolutions of one input tensor (ResBlock's 3x3 and
+ * 1x1 branches, blocks.py:14-36; the two mlp_shared convolutions of a StyledResUpBlock's StyledDenorms on one style input,
+ * blocks.py:100-134) - adds its input gradient to the shared buffer in its epilogue instead of leaving the sum to a separate
+ * add pass.  Served where ..._masked_supported says so. */
+int vqw_conv3x3_wino_fwd_acc(const float* x, const void* ws, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
 int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W);
 int vqw_conv3x3_wino_fwd_stats(const float* x, const void* ws, const float* bias, float* y, float* part, int N, int H, int W,
                                int Cin, int Cout, void* stream);

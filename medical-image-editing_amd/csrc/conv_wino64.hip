@@ -55,8 +55,9 @@ struct W64Args {
     int relu;
     unsigned nbx, nbu, nby;
     float* stats;              // optional [N][tilesY*tilesX][Cout][2]: per-region (sum, M2 about the region mean)
-    const float* mask;         // optional, shaped like y: outputs are zeroed where mask <= 0 (the ReLU whose output the layer's
+    const float* mask;         // EPI 1, shaped like y: outputs are zeroed where mask <= 0 (the ReLU whose output the layer's
                                // forward read: an input-gradient launch then delivers the gradient in front of that ReLU)
+                               // EPI 2: y += result (a later member of a gradient group adds to the shared buffer)
 };
 
 constexpr int W6_KPH = 10;                 // floats per halo pixel in LDS (8 channels + 2: conflict-free ds_read_b64 patches)
@@ -90,8 +91,9 @@ template <int RW, int MBW> struct W64Geo {
 #endif
 constexpr int W6_CP = 26;                  // MFMA position of the first LDS commit of the prefetched data
 
-template <int RW, int MBW, bool MASK>
+template <int RW, int MBW, int EPI>
 __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
+    constexpr bool MASK = EPI != 0;        // both forms read 16 values per (M block, N block) at the output positions
     using G = W64Geo<RW, MBW>;
     constexpr int NT = 512, NBW = G::NBW, NCO = G::NCO;
     constexpr int HWS = G::HWS, HWV = G::HWV, HBUF = G::HBUF, UBUF = G::UBUF;
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     const int mb = wv & 3, h = wv >> 2;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
-    const __amdgpu_buffer_rsrc_t rsm = make_rsrc(MASK ? a.mask : a.y, a.nby);      // (an instantiation of its own: the plain kernels keep their registers)
+    const __amdgpu_buffer_rsrc_t rsm = make_rsrc(EPI == 1 ? a.mask : a.y, a.nby);  // (instantiations of their own: the plain kernels keep their registers)
 
     const int ntn = a.ntn, nch = a.nch;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -459,9 +461,12 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
                         yv[r * 4 + 3] = fmaxf((own[3] + o.w) + bvv[i], lo);
                     }
                 }
-                if (MASK) {
+                if (EPI == 1) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) yv[k] = mk[k] > 0.f ? yv[k] : 0.f;
+                } else if (EPI == 2) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) yv[k] = mk[k] + yv[k];
                 }
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa) {
@@ -564,14 +569,14 @@ int conv_wino64_stat_tiles(int Cin, int Cout, int H, int W) {
     return tr > 0 && H % tr == 0 ? (H / tr) * (W / rw) : 0;
 }
 
-template <int RW, int MBW, bool MASK>
+template <int RW, int MBW, int EPI>
 static int launch_wino64(W64Args& a, hipStream_t st) {
     using G = W64Geo<RW, MBW>;
     constexpr size_t lds = G::LDS_FLOATS * sizeof(float);
     static_assert(lds <= 160 * 1024, "buffers do not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_wino64<RW, MBW, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino64<RW, MBW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             vqw_set_error("conv_wino64: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
@@ -583,13 +588,13 @@ static int launch_wino64(W64Args& a, hipStream_t st) {
     if (groups < 1) groups = 1;
     const int even = ceil_div(a.nsp, groups);
     a.kt = even < 1 ? 1 : even;
-    k_conv_wino64<RW, MBW, MASK><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    k_conv_wino64<RW, MBW, EPI><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino64");
     return VQW_OK;
 }
 
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
-                    hipStream_t st, float* stats, const float* mask) {
+                    hipStream_t st, float* stats, const float* mask, int accumulate) {
     W64Args a;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.mask = mask;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -602,13 +607,18 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
     a.nby = (unsigned)(P * Cout * 4);
     const int shape = wino64_shape(Cin, Cout, W);
     if (mask) {
-        if (shape == 2) return launch_wino64<32, 2, true>(a, st);
-        if (W % 32 == 0) return launch_wino64<32, 1, true>(a, st);
-        return launch_wino64<16, 1, true>(a, st);
+        if (shape == 2) return launch_wino64<32, 2, 1>(a, st);
+        if (W % 32 == 0) return launch_wino64<32, 1, 1>(a, st);
+        return launch_wino64<16, 1, 1>(a, st);
     }
-    if (shape == 2) return launch_wino64<32, 2, false>(a, st);
-    if (W % 32 == 0) return launch_wino64<32, 1, false>(a, st);
-    return launch_wino64<16, 1, false>(a, st);
+    if (accumulate) {
+        if (shape == 2) return launch_wino64<32, 2, 2>(a, st);
+        if (W % 32 == 0) return launch_wino64<32, 1, 2>(a, st);
+        return launch_wino64<16, 1, 2>(a, st);
+    }
+    if (shape == 2) return launch_wino64<32, 2, 0>(a, st);
+    if (W % 32 == 0) return launch_wino64<32, 1, 0>(a, st);
+    return launch_wino64<16, 1, 0>(a, st);
 }
 
 // =====================================================================================================================

@@ -522,6 +522,7 @@ class _Conv2d(torch.autograd.Function):
 _MASKED_GRADS = {}
 FUSE_RELU_MASK = os.environ.get("VQW_FUSE_RELU_MASK", "1") != "0"
 masked_dgrad_calls = 0         # input-gradient launches that applied a ReLU mask in their epilogue (tests)
+group_acc_calls = 0            # Winograd input-gradient launches that added to a gradient group's buffer in their epilogue (tests)
 
 
 def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb, group=None):
@@ -555,7 +556,16 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
         wt = _cached(w, "dgrad", _pack)
         if group is not None and need0 and group.buf is not None:
             # a later member of a gradient group (single full-resolution source): add into the shared buffer
-            if L.vqw_conv2d_fwd_acc_supported(Cout, N, H, W, Cin, ks, dilation):
+            if ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W) \
+                    and L.vqw_conv3x3_wino_masked_supported(Cout, Cin, N, H, W):
+                # Winograd form, the shared buffer read and added in the kernel's epilogue
+                ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+                _lib.check(L.vqw_conv3x3_wino_fwd_acc(_p(gy), _p(ut), _p(group.buf), N, H, W, Cout, Cin, _st()),
+                           "vqw_conv3x3_wino_fwd_acc(dgrad)")
+                global group_acc_calls
+                group_acc_calls += 1
+                g_full = None
+            elif L.vqw_conv2d_fwd_acc_supported(Cout, N, H, W, Cin, ks, dilation):
                 _lib.check(L.vqw_conv2d_fwd_acc(_p(gy), Cout, _p(wt), _p(group.buf), N, H, W, Cin, ks, dilation, _st()),
                            "vqw_conv2d_fwd_acc")
                 g_full = None

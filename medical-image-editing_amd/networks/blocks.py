@@ -78,15 +78,18 @@ class ResBlock(nn.Module):
     def forward(self, x):
         # both branches end in an InstanceNorm: the tail kernel normalises their raw conv outputs while it reads them
         dc, ds = self.double_conv, self.downsample
+        # x feeds the 1x1 branch and the first 3x3 convolution: their input gradients are summed in the second one's
+        # epilogue (ops.GradGroup) instead of by an add pass
+        grp = ops.GradGroup(2) if (GRAD_GROUP_BLOCKS and x.requires_grad) else None
         if RES_TAIL_NORM and dc.ends_in_norm_relu() and ds[1].eps == dc.double_conv[4].eps and not ds[1].relu:
-            x2, part2 = dc(x, raw_tail=True)
-            xid, partid = ds[0](x, want_stats=True)
+            x2, part2 = dc(x, raw_tail=True, grad_group=grp)
+            xid, partid = ds[0](x, want_stats=True, grad_group=grp)
             got = ops.res_tail_norm(x2, xid, eps=ds[1].eps, part2=part2, partid=partid)
             if got is not None:
                 return got
             return ops.res_tail(dc.double_conv[4](x2, part=part2), ds[1](xid, part=partid))      # shape not served: separate norms
-        xid, partid = ds[0](x, want_stats=True)
-        return ops.res_tail(dc(x), ds[1](xid, part=partid))      # (pooled, out) with a single backward kernel
+        xid, partid = ds[0](x, want_stats=True, grad_group=grp)
+        return ops.res_tail(dc(x, grad_group=grp), ds[1](xid, part=partid))      # (pooled, out) with a single backward kernel
 
 
 class DoubleConv(nn.Module):
@@ -106,23 +109,23 @@ class DoubleConv(nn.Module):
         m = self.double_conv
         return len(m) == 6 and isinstance(m[4], InstanceNorm2d) and m[4].relu
 
-    def forward(self, x, up2x=False, skip=None, raw_tail=False):
+    def forward(self, x, up2x=False, skip=None, raw_tail=False, grad_group=None):
         """raw_tail=True: stop before the last InstanceNorm(+ReLU) and return (raw conv output, its statistics partials or
         None) for a consumer that normalises while it reads (ResBlock)."""
         # conv -> InstanceNorm pairs: the conv's epilogue leaves the norm's statistics (ops.conv2d want_stats)
         layers = list(self.double_conv)
         if raw_tail:
             layers = layers[:3]
-            x = DoubleConv._run(layers, x, up2x, skip)
+            x = DoubleConv._run(layers, x, up2x, skip, grad_group)
             return self.double_conv[3](x, want_stats=True)
-        return DoubleConv._run(layers, x, up2x, skip)
+        return DoubleConv._run(layers, x, up2x, skip, grad_group)
 
     @staticmethod
-    def _run(layers, x, up2x, skip):
+    def _run(layers, x, up2x, skip, grad_group=None):
         i = 0
         while i < len(layers):
             layer = layers[i]
-            kw = dict(up2x=up2x, skip=skip) if i == 0 else {}
+            kw = dict(up2x=up2x, skip=skip, grad_group=grad_group) if i == 0 else {}
             if isinstance(layer, Conv2d) and i + 1 < len(layers) and isinstance(layers[i + 1], InstanceNorm2d):
                 x, part = layer(x, want_stats=True, **kw)
                 x = layers[i + 1](x, part=part)
@@ -134,6 +137,7 @@ class DoubleConv(nn.Module):
 
 
 FUSE_GAMMA_BETA = os.environ.get("VQW_FUSE_GAMMA_BETA", "1") != "0"
+GRAD_GROUP_BLOCKS = os.environ.get("VQW_GRAD_GROUP_BLOCKS", "1") != "0"     # 0: autograd sums the ResBlock / style-input gradients (A/B)
 RES_TAIL_NORM = os.environ.get("VQW_RES_TAIL_NORM", "1") != "0"      # 0: ResBlock branches apply their norms themselves (A/B)
 
 
@@ -151,10 +155,11 @@ class StyledDenorm(nn.Module):
         self.mlp_gamma = conv3x3(in_channels, in_channels)
         self.mlp_beta = conv3x3(in_channels, in_channels)
 
-    def style_maps(self, style):
+    def style_maps(self, style, grad_group=None):
         """(gamma, beta) of reference blocks.py:85-87: a function of the style input only, so a caller may evaluate
-        it ahead of / beside the trunk and hand it to forward()."""
-        actv = self.mlp_shared[0](style, relu=True)
+        it ahead of / beside the trunk and hand it to forward().  grad_group: the ops.GradGroup of the convolutions that
+        read this style tensor (the two StyledDenorms of a StyledResUpBlock)."""
+        actv = self.mlp_shared[0](style, relu=True, grad_group=grad_group)
         if FUSE_GAMMA_BETA:     # one conv with [gamma | beta] output channels
             return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias, relu_input=True), None
         return self.mlp_gamma(actv), self.mlp_beta(actv)
@@ -210,9 +215,11 @@ class StyledResUpBlock(nn.Module):
 
     def style_maps(self, skip_input):
         """Modulation maps of both StyledDenorms on the branch stream (they do not depend on down_input)."""
+        # both mlp_shared convolutions read skip_input: one gradient group (their input gradients meet in the second one's epilogue)
+        grp = ops.GradGroup(2) if (GRAD_GROUP_BLOCKS and skip_input.requires_grad) else None
         with ops.Branch(skip_input) as br:
-            m1 = self.norm1.style_maps(skip_input)
-            m2 = self.norm2.style_maps(skip_input)
+            m1 = self.norm1.style_maps(skip_input, grad_group=grp)
+            m2 = self.norm2.style_maps(skip_input, grad_group=grp)
         return br, m1, m2
 
     def forward(self, down_input, skip_input, maps=None):

@@ -580,6 +580,42 @@ def test_relu_mask_in_the_gamma_beta_input_gradient_epilogue(monkeypatch, C, S):
     assert float(ref["style"].abs().max()) > 0
 
 
+@pytest.mark.parametrize("which", ["res_block", "styled_res_up"])
+def test_block_inputs_with_two_convolutions_sum_their_gradients_in_the_epilogue(monkeypatch, which):
+    """ResBlock's input feeds the 1x1 branch and the first 3x3 convolution (blocks.py:14-36); a StyledResUpBlock's style input
+    feeds the mlp_shared convolutions of both StyledDenorms (blocks.py:100-134).  Each pair is an ops.GradGroup: the second
+    input gradient is added to the first in the Winograd kernel's epilogue (vqw_conv3x3_wino_fwd_acc) instead of by
+    autograd's add pass.  a + b either way: every gradient bit-equal to the run with the groups off, and the accumulating
+    launch actually taken."""
+    from networks import blocks as B
+    from hipops import ops
+
+    def run(groups):
+        monkeypatch.setattr(B, "GRAD_GROUP_BLOCKS", groups)
+        torch.manual_seed(5)
+        cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+        if which == "res_block":
+            mod = B.ResBlock(64, 64).to(DEV).train()
+            ins = [cl(torch.randn(2, 64, 64, 64, device=DEV)).requires_grad_(True)]
+        else:
+            mod = B.StyledResUpBlock(128, 64, 64).to(DEV).train()
+            ins = [cl(torch.randn(2, 128, 32, 32, device=DEV)).requires_grad_(True),
+                   cl(torch.randn(2, 64, 64, 64, device=DEV)).requires_grad_(True)]
+        n0 = ops.group_acc_calls
+        out = mod(*ins)
+        outs = out if isinstance(out, tuple) else (out,)
+        sum((o * torch.randn_like(o)).sum() for o in outs).backward()
+        torch.cuda.synchronize()
+        grads = {"in%d" % i: t.grad.clone() for i, t in enumerate(ins)}
+        grads.update({k: p.grad.clone() for k, p in mod.named_parameters()})
+        return grads, ops.group_acc_calls - n0
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == 1, (n_ref, n_got)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), "gradient %s differs between grouped and autograd-summed input gradients" % k
+
+
 # --------------------------------------------------------------------------------------------------
 # vector quantiser
 # --------------------------------------------------------------------------------------------------
