@@ -43,7 +43,7 @@ int vqw_set_conv_backend(int mode);
  * on those events and fills out[6][4] = {launches, total ms, total FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA
  * wgrad, generic fwd, generic wgrad, Winograd-form fwd/dgrad/wgrad, HBM-bound norm / element-wise (bytes = tensor passes as
  * launched)}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of the direct
- * form's).  (ABI 6: the sixth family.  ABI 7: vqw_conv3x3_wino_fwd_masked, vqw_conv3x3_wino_fwd_acc.)
+ * form's).  (ABI 6: the sixth family.  ABI 7: vqw_conv3x3_wino_fwd_masked, vqw_conv3x3_wino_fwd_acc, vqw_conv3x3_up2_dgrad_acc.)
  * Not meant for graph capture; off by default.                                                              */
 int vqw_profile_begin(void);
 int vqw_profile_end(double* out);
@@ -103,6 +103,11 @@ int vqw_conv3x3_up2_fwd_stats(const float* x_low, const void* ws, const float* b
                               int Cin, int Cout, void* stream);
 int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
                           void* stream);
+/* ABI 7.  dx_low += the same input gradient: the second of the two up-sampled convolutions that read one tensor (a
+ * StyledResUpBlock's `conv` and `conv1`, blocks.py:100-112) adds to the first one's result in its epilogue. */
+int vqw_conv3x3_up2_dgrad_acc_supported(int Cin, int Cout, int N, int h, int w);
+int vqw_conv3x3_up2_dgrad_acc(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
+                              void* stream);
 /* weight (and bias) gradient of the same layer on the low-resolution grid (needs w % 16 == 0) */
 int vqw_conv3x3_up2_wgrad_supported(int Cin, int Cout, int N, int h, int w);
 size_t vqw_conv3x3_up2_wgrad_ws_bytes(int Cin, int Cout, int N, int h, int w);

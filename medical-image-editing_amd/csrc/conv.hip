@@ -316,6 +316,19 @@ extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_
     return conv_up2_dgrad(dy, (const float*)ws, dx_low, N, h, w, Cin, Cout, (hipStream_t)stream);
 }
 
+extern "C" int vqw_conv3x3_up2_dgrad_acc_supported(int Cin, int Cout, int N, int h, int w) {
+    return (conv_up2_ok(Cout, Cin, (long)N * h * w) && conv_up2_dgrad_is_wino(Cin, Cout, N, h, w)) ? 1 : 0;
+}
+extern "C" int vqw_conv3x3_up2_dgrad_acc(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
+                                         void* stream) {
+    VQW_CHECK(dy && ws && dx_low && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_dgrad_acc: bad arguments");
+    VQW_CHECK(vqw_conv3x3_up2_dgrad_acc_supported(Cin, Cout, N, h, w), "vqw_conv3x3_up2_dgrad_acc: unsupported shape");
+    const double flops = 2.0 * N * h * w * 9.0 * Cout * Cin;
+    const double bytes = 4.0 * (2.0 * N * h * w * Cin + 4.0 * N * h * w * Cout + 16.0 * Cout * Cin);
+    ProfScope ps(4, flops, (hipStream_t)stream, bytes);
+    return conv_up2_dgrad(dy, (const float*)ws, dx_low, N, h, w, Cin, Cout, (hipStream_t)stream, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // plain 3x3 convolution in Winograd F(2x2, 3x3) form (conv_wino.hip)
 extern "C" int vqw_conv3x3_wino_supported(int Cin, int Cout, int N, int H, int W) {

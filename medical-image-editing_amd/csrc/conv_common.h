@@ -76,7 +76,8 @@ int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, 
 bool conv_wino_up_dgrad_ok(int Cin, int Cout, int N, int h, int w);
 size_t conv_wino_up_ws_floats(int Cin, int Cout);
 int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st);
-int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st);
+int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st,
+                       int accumulate = 0);
 bool conv_up2_dgrad_is_wino(int Cin, int Cout, int N, int h, int w);
 bool conv_up2_fwd_is_wino(int Cin, int Cout, int N, int h, int w);
 bool conv_up2_wgrad_is_wino(int Cin, int Cout, int N, int h, int w);
@@ -94,7 +95,8 @@ size_t conv_up2_ws_floats(int Cin, int Cout);
 int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st);
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
                  hipStream_t st, float* stats = nullptr);
-int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st);
+int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st,
+                   int accumulate = 0);      // accumulate: dx_low += result (nine-product kernel only: conv_up2_dgrad_is_wino)
 bool conv_up2_wgrad_ok(int Cin, int Cout, int N, int h, int w);
 size_t conv_up2_wgrad_ws_floats(int Cin, int Cout, int N, int h, int w);
 int conv_up2_wgrad(const float* xlow, const float* dy, float* dw, float* dbias, float* ws, int N, int h, int w, int Cin, int Cout,

@@ -469,8 +469,12 @@ int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* 
 }
 bool conv_up2_dgrad_is_wino(int Cin, int Cout, int N, int h, int w) { return conv_wino_up_dgrad_ok(Cin, Cout, N, h, w); }
 bool conv_up2_fwd_is_wino(int Cin, int Cout, int N, int h, int w) { return conv_wino_up_fwd_ok(Cin, Cout, N, h, w); }
-int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st) {
-    if (conv_wino_up_dgrad_ok(Cin, Cout, N, h, w)) return conv_wino_up_dgrad(dy, ws + 32L * Cout * Cin, dx_low, N, h, w, Cin, Cout, st);
+int conv_up2_dgrad(const float* dy, const float* ws, float* dx_low, int N, int h, int w, int Cin, int Cout, hipStream_t st, int accumulate) {
+    if (conv_wino_up_dgrad_ok(Cin, Cout, N, h, w)) return conv_wino_up_dgrad(dy, ws + 32L * Cout * Cin, dx_low, N, h, w, Cin, Cout, st, accumulate);
+    if (accumulate) {
+        vqw_set_error("conv_up2_dgrad: the accumulating form is served by the nine-product kernel only");
+        return VQW_ERR_ARG;
+    }
     ConvIn in{dy, nullptr, Cout, 0, 0};
     ConvGeom g{};
     g.ntaps = 16;

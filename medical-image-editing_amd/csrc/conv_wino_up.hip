@@ -89,7 +89,7 @@ struct WUpDgArgs {
 
 // Workgroup = 16 x 32 full-resolution pixels (128 tiles = 8 x 16 low-resolution pixels) x NCO = 16 NBW input channels; wave w =
 // tile row w.  One accumulator set (NBW x 4 registers) takes all nine xi.
-template <int NBW>
+template <int NBW, bool ACC>             // ACC: g += result (a later member of a gradient group: conv_common.h)
 __global__ void __launch_bounds__(512, 1) k_conv_wino_up_dgrad(WUpDgArgs a) {
     constexpr int NT = 512, NCO = 16 * NBW;
     constexpr int RW = 32, TR = 16, HR = TR + 2, HWV = RW + 2, HWS = 34;
@@ -313,6 +313,17 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_dgrad(WUpDgArgs a) {
         const int ylow = cty * (TR / 2) + wv, xlow0 = ctx * (RW / 2) + 4 * q;
         const unsigned base = (((unsigned)cn * (H >> 1) + (unsigned)ylow) * (W >> 1) + (unsigned)xlow0) * (unsigned)Cin + co_base + m;
         const int voff = (int)sel_u32(ylow < (H >> 1), base * 4u, 0xFFFFFFFFu);
+        if (ACC) {
+            float old[NBW][4];
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[nb][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsg, voff, r * Cin * 4 + nb * 64, 0));
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[nb][r] = old[nb][r] + acc[nb][r];
+        }
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
@@ -975,13 +986,13 @@ int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream
     return VQW_OK;
 }
 
-template <int NBW>
+template <int NBW, bool ACC>
 static int launch_up_dgrad(WUpDgArgs& a, hipStream_t st) {
     constexpr size_t lds = (size_t)(2 * 18 * 34 * WU_KPH + 2 * 9 * 16 * NBW * 8) * sizeof(float);
     static_assert(lds <= 160 * 1024, "buffers do not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_wino_up_dgrad<NBW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino_up_dgrad<NBW, ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             vqw_set_error("conv_wino_up_dgrad: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
@@ -992,13 +1003,14 @@ static int launch_up_dgrad(WUpDgArgs& a, hipStream_t st) {
     if (groups < 1) groups = 1;
     const int even = ceil_div(a.nsp, groups);
     a.kt = even < 1 ? 1 : even;
-    k_conv_wino_up_dgrad<NBW><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    k_conv_wino_up_dgrad<NBW, ACC><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino_up_dgrad");
     return VQW_OK;
 }
 
 // dy (N, 2h, 2w, Cout) -> g_low (N, h, w, Cin); ws as written by conv_wino_up_prepare
-int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st) {
+int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st,
+                       int accumulate) {
     WUpDgArgs a;
     a.dy = dy; a.u = ws + 9L * Cout * Cin; a.g = g_low;
     a.N = N; a.H = 2 * h; a.W = 2 * w; a.Cin = Cin; a.Cout = Cout;
@@ -1008,8 +1020,9 @@ int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, in
     a.nbd = (unsigned)(P * Cout * 4);
     a.nbu = (unsigned)(9L * Cout * Cin * 4);
     a.nbg = (unsigned)(P / 4 * Cin * 4);
-    if (Cin % 128 == 0) return launch_up_dgrad<8>(a, st);
-    return launch_up_dgrad<4>(a, st);
+    if (accumulate) return Cin % 128 == 0 ? launch_up_dgrad<8, true>(a, st) : launch_up_dgrad<4, true>(a, st);
+    if (Cin % 128 == 0) return launch_up_dgrad<8, false>(a, st);
+    return launch_up_dgrad<4, false>(a, st);
 }
 
 // Forward: Cin % 16 (an even number of chunks), Cout % 64, full-resolution width a multiple of 32

@@ -529,6 +529,7 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
     """Input / weight / bias gradients of conv2d on the current stream -> (g0, g1, gw, gb, masked gy).  x0 / x1 / w are the
     NHWC tensors the forward saw, y_relu its output when the ReLU was fused (the incoming gradient is masked first),
     up_ws the collapsed-weight buffer when the forward took the low-resolution form."""
+    global group_acc_calls
     L = _L()
     Cout, Cin, ks, _ = w.shape
     N = x0.shape[0]
@@ -545,9 +546,18 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
     C1 = 0 if x1 is None else x1.shape[1]
     g0 = g1 = gw = gb = None
     if need0 and up_ws is not None:
-        g0 = torch.empty_like(x0, memory_format=CL)
-        _lib.check(L.vqw_conv3x3_up2_dgrad(_p(gy), _p(up_ws), _p(g0), N, H // 2, W // 2, Cin, Cout, _st()),
-                   "vqw_conv3x3_up2_dgrad")
+        if group is not None and group.buf is not None and L.vqw_conv3x3_up2_dgrad_acc_supported(Cin, Cout, N, H // 2, W // 2):
+            # the other up-sampled convolution of this input has run: add to its gradient in this kernel's epilogue
+            _lib.check(L.vqw_conv3x3_up2_dgrad_acc(_p(gy), _p(up_ws), _p(group.buf), N, H // 2, W // 2, Cin, Cout, _st()),
+                       "vqw_conv3x3_up2_dgrad_acc")
+            group_acc_calls += 1
+            g0 = group.member_done(None)
+        else:
+            g0 = torch.empty_like(x0, memory_format=CL)
+            _lib.check(L.vqw_conv3x3_up2_dgrad(_p(gy), _p(up_ws), _p(g0), N, H // 2, W // 2, Cin, Cout, _st()),
+                       "vqw_conv3x3_up2_dgrad")
+            if group is not None:
+                g0 = group.member_done(g0)
     elif need0 or (need1 and x1 is not None):
         def _pack():
             buf = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
@@ -562,7 +572,6 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
                 ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
                 _lib.check(L.vqw_conv3x3_wino_fwd_acc(_p(gy), _p(ut), _p(group.buf), N, H, W, Cout, Cin, _st()),
                            "vqw_conv3x3_wino_fwd_acc(dgrad)")
-                global group_acc_calls
                 group_acc_calls += 1
                 g_full = None
             elif L.vqw_conv2d_fwd_acc_supported(Cout, N, H, W, Cin, ks, dilation):
@@ -658,6 +667,11 @@ def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, 
     served) holds the statistics of y for the InstanceNorm that follows: instance_norm(y, ..., part=part)."""
     wino = _decide_wino_fwd()
     group = grad_group if (GRAD_GROUPS and skip is None and not up2x) else None
+    if grad_group is not None and group is None and GRAD_GROUPS and up2x and skip is None and weight.shape[2] == 3 and dilation == 1:
+        # an up-sampled single source in its collapsed form (the branch _Conv2d.forward takes for these shapes)
+        Cout_, Cin_ = weight.shape[0], weight.shape[1]
+        if _L().vqw_conv3x3_up2_supported(Cin_, Cout_, x.shape[0], x.shape[2], x.shape[3]):
+            group = grad_group
     if grad_group is not None and group is None:
         grad_group.opt_out()               # this member's gradient goes through autograd: the others must not wait for it
     if want_stats and CONV_STATS:

@@ -228,9 +228,11 @@ class StyledResUpBlock(nn.Module):
             x, up = self.up_sample(down_input), False
         else:
             x, up = down_input, True
-        s, part = self.conv[0](x, up2x=up, want_stats=True)      # the shortcut conv's epilogue leaves its norm's statistics
+        # x feeds the shortcut convolution and conv1: one gradient group (the second input gradient is added in its kernel's epilogue)
+        gx = ops.GradGroup(2) if (GRAD_GROUP_BLOCKS and x.requires_grad) else None
+        s, part = self.conv[0](x, up2x=up, want_stats=True, grad_group=gx)      # the shortcut conv's epilogue leaves its norm's statistics
         s = self.conv[1](s, part=part)
-        h, part1 = self.conv1(x, up2x=up, want_stats=True)      # ... and norm1's batch statistics
+        h, part1 = self.conv1(x, up2x=up, want_stats=True, grad_group=gx)      # ... and norm1's batch statistics
         br.join(*m1, *m2)
         h = self.norm1(h, skip_input, relu=True, maps=m1, part=part1)
         h, part = self.conv2(h, want_stats=True)       # the epilogue leaves norm2's batch statistics
