@@ -87,7 +87,8 @@ template <int RW, int MBW> struct W64Geo {
 #define W6_ITEM_BARRIER() __syncthreads()
 #endif
 #ifndef W6_LS
-#define W6_LS 2                            // MFMA positions between two prefetch loads (a burst of 48 wave-loads stalls their issue)
+#define W6_LS 4                            // MFMA positions between two prefetch loads (a burst of 48 wave-loads stalls their issue;
+                                           // 2 -> 4: 32->64 @256 dgrad 0.447 -> 0.425 ms, 64->128 @128 0.318 -> 0.306, nothing slower)
 #endif
 constexpr int W6_CP = 26;                  // MFMA position of the first LDS commit of the prefetched data
 
@@ -647,6 +648,9 @@ struct W64WgArgs {
     unsigned nbx, nbd;         // bytes of x / dy
 };
 
+#ifndef W6_WLS
+#define W6_WLS 2                           // MFMA positions between two prefetch loads of the weight-gradient kernel
+#endif
 constexpr int WG_DP = 72, WG_XP = 40;     // floats per dY pixel (64 co + 8) / X pixel (32 ci + 8): adjacent tiles 16 banks apart
 template <int RW> struct WgGeo {
     static constexpr int TRP = RW == 32 ? 4 : 8;           // pixel rows per region: 32 tiles
@@ -873,9 +877,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad64(W64WgArgs a) {
                     // prefetch: a phase (1 us) between a load and its LDS commit (twice that changed nothing and costs registers)
 #ifndef W6_EXP_NO_WLOADS
                     if (loads == 0 && p >= 8 && p < 12) commit_d(p - 8, wbuf);
-                    if (loads == 1 && p >= 2 && p < 2 + 2 * LX && (p & 1) == 0) issue_x((p - 2) >> 1);
+                    if (loads == 1 && p >= 2 && p < 2 + W6_WLS * LX && (p - 2) % W6_WLS == 0) issue_x((p - 2) / W6_WLS);
                     if (loads == 2 && p >= 8 && p < 8 + LX) commit_x(p - 8, wbuf);
-                    if (loads == 3 && p >= 2 && p < 10 && (p & 1) == 0) issue_d((p - 2) >> 1);
+                    if (loads == 3 && p >= 2 && p < 2 + W6_WLS * 4 && (p - 2) % W6_WLS == 0) issue_d((p - 2) / W6_WLS);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
