@@ -14,11 +14,12 @@ from . import _lib
 from . import ops as _ops
 
 
-# One multi-tensor launch per parameter group (VQW_ADAM_MULTI=1) needs a pointer table uploaded every step (gradient
-# tensors are new every step).  With the host throttled to two steps in flight (trainers.StepThrottle) it measures +0.2 %
-# (225.8 vs 225.3 images/s, five default bench runs each); off by default: 147 launches of ~5 us behind the last weight
-# gradients cost next to nothing and need no host-to-device copy in the step.
-MULTI_TENSOR = os.environ.get("VQW_ADAM_MULTI", "0") != "0"
+# One multi-tensor launch per parameter group (VQW_ADAM_MULTI, default on since round 3) needs a pointer table uploaded every
+# step (gradient tensors are new every step; a small ring of pinned buffers).  Measured on the 95 ms step of round 3:
+# 95.36 / 95.13 ms per-tensor (147 launches of ~3 us at the very end of the step, where nothing overlaps them) against
+# 95.04 / 94.88 ms multi-tensor.  VQW_ADAM_MULTI=0 restores the per-tensor launches; a group whose tensors do not share a
+# step count or a layout falls back to them by itself.
+MULTI_TENSOR = os.environ.get("VQW_ADAM_MULTI", "1") != "0"
 CHUNK = 1 << 16          # elements per workgroup of the multi-tensor launch
 
 
