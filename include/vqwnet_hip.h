@@ -43,7 +43,8 @@ int vqw_set_conv_backend(int mode);
  * on those events and fills out[6][4] = {launches, total ms, total FLOPs, total algorithmic bytes} for {MFMA fwd/dgrad, MFMA
  * wgrad, generic fwd, generic wgrad, Winograd-form fwd/dgrad/wgrad, HBM-bound norm / element-wise (bytes = tensor passes as
  * launched)}; FLOPs are the ones the kernels execute (collapsed up-sampled and Winograd-form layers: 4/9 of the direct
- * form's).  (ABI 6: the sixth family.  ABI 7: vqw_conv3x3_wino_fwd_masked, vqw_conv3x3_wino_fwd_acc, vqw_conv3x3_up2_dgrad_acc.)
+ * form's).  (ABI 6: the sixth family.  ABI 7: vqw_conv3x3_wino_fwd_masked, vqw_conv3x3_wino_fwd_acc, vqw_conv3x3_up2_dgrad_acc,
+ * vqw_conv3x3_wino_fwd_inbwd, vqw_inorm_bwd_parts.)
  * Not meant for graph capture; off by default.                                                              */
 int vqw_profile_begin(void);
 int vqw_profile_end(double* out);
@@ -136,6 +137,14 @@ int vqw_conv3x3_wino_fwd_masked(const float* x, const void* ws, const float* mas
  * blocks.py:100-134) - adds its input gradient to the shared buffer in its epilogue instead of leaving the sum to a separate
  * add pass.  Served where ..._masked_supported says so. */
 int vqw_conv3x3_wino_fwd_acc(const float* x, const void* ws, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
+/* The input gradient of a layer whose forward read the output of an InstanceNorm (+ReLU) (DoubleConv: conv -> norm -> ReLU ->
+ * conv, blocks.py:39-61): y = the gradient as usual, and part[N][parts][Cout][2] = that norm's backward sums per region,
+ * (sum gm, sum gm * xhat) with xhat = (norm_x - mean) * rstd and gm = the gradient where the norm's ReLU passed - what
+ * vqw_inorm_bwd otherwise reduces in a pass of its own over norm_x and the gradient (vqw_inorm_bwd_parts takes them from here).
+ * norm_x: the norm's raw input, shaped like y; norm_mean_rstd: its (mean, rstd) per (image, channel).  parts = 0: not served. */
+int vqw_conv3x3_wino_fwd_inbwd_parts(int Cin, int Cout, int N, int H, int W);
+int vqw_conv3x3_wino_fwd_inbwd(const float* x, const void* ws, const float* norm_x, const float* norm_mean_rstd, int norm_relu,
+                               float* y, float* part, int N, int H, int W, int Cin, int Cout, void* stream);
 int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W);
 int vqw_conv3x3_wino_fwd_stats(const float* x, const void* ws, const float* bias, float* y, float* part, int N, int H, int W,
                                int Cin, int Cout, void* stream);
@@ -159,6 +168,10 @@ int vqw_inorm_stats(const float* x, float* mean_rstd, void* ws, size_t ws_bytes,
 int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_rstd, int N, int HW, int C, float eps, void* stream);
 int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
                   float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
+/* ABI 7.  The same with the two sums taken from part[N][nparts][C][2] = (sum gm, sum gm * xhat) per region, left by the
+ * consumer convolution's input-gradient launch (vqw_conv3x3_wino_fwd_inbwd); means_ws: N * C * 2 floats of scratch. */
+int vqw_inorm_bwd_parts(const float* x, const float* mean_rstd, const float* gy, const float* part, int nparts, float* means_ws,
+                        float* gx, int N, int HW, int C, int relu, void* stream);
 /* backward of two InstanceNorms fed with the SAME gradient (the two branches in front of a ResBlock tail; a: norm + ReLU,
  * b: norm): the common gradient is read once per pass.  ws: 2 x vqw_plane_ws_bytes(N, C, HW).  C % 4 == 0.          */
 int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float* xb, const float* mrb, const float* gy,

@@ -366,6 +366,18 @@ extern "C" int vqw_conv3x3_wino_fwd_acc(const float* x, const void* ws, float* y
     ProfScope ps(4, 2.0 * px * 4.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + 2.0 * px * Cout + 16.0 * Cout * Cin));
     return conv_wino_fwd(x, (const float*)ws, nullptr, y, N, H, W, Cin, Cout, 0, (hipStream_t)stream, nullptr, nullptr, 1);
 }
+extern "C" int vqw_conv3x3_wino_fwd_inbwd_parts(int Cin, int Cout, int N, int H, int W) {
+    if (!vqw_conv3x3_wino_masked_supported(Cin, Cout, N, H, W)) return 0;
+    return conv_wino64_stat_tiles(Cin, Cout, H, W);
+}
+extern "C" int vqw_conv3x3_wino_fwd_inbwd(const float* x, const void* ws, const float* norm_x, const float* norm_mean_rstd, int norm_relu,
+                                          float* y, float* part, int N, int H, int W, int Cin, int Cout, void* stream) {
+    VQW_CHECK(x && ws && norm_x && norm_mean_rstd && y && part && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_fwd_inbwd: bad arguments");
+    VQW_CHECK(vqw_conv3x3_wino_fwd_inbwd_parts(Cin, Cout, N, H, W) > 0, "vqw_conv3x3_wino_fwd_inbwd: shape not served");
+    const double px = (double)N * H * W;
+    ProfScope ps(4, 2.0 * px * 4.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + 2.0 * px * Cout + 16.0 * Cout * Cin));
+    return conv_wino_fwd(x, (const float*)ws, nullptr, y, N, H, W, Cin, Cout, 0, (hipStream_t)stream, part, norm_x, 0, norm_mean_rstd, norm_relu);
+}
 extern "C" int vqw_conv3x3_wino_fwd_stats_parts(int Cin, int Cout, int N, int H, int W) {
     if (g_conv_backend != 0 || !conv_wino_ok(Cin, Cout, N, H, W)) return 0;
     return conv_wino_stat_tiles(Cin, Cout, H, W);

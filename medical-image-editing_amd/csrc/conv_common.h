@@ -60,10 +60,13 @@ int conv_wino_stat_tiles(int Cin, int Cout, int H, int W);
 bool conv_wino64_ok(int Cin, int Cout, int W);
 int conv_wino64_stat_tiles(int Cin, int Cout, int H, int W);
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
-                    hipStream_t st, float* stats = nullptr, const float* mask = nullptr, int accumulate = 0);
-// accumulate (low-VALU kernel only): y += result.  mask (optional, shaped like y, low-VALU kernel only: conv_wino64_ok): outputs are zeroed where mask <= 0
+                    hipStream_t st, float* stats = nullptr, const float* mask = nullptr, int accumulate = 0,
+                    const float* in_mr = nullptr, int in_relu = 0);
+// in_mr (with mask = the raw input of the InstanceNorm in front of the layer, stats = [N][tiles][Cout][2]): the launch is the
+// layer's input gradient and leaves that norm's backward sums per region.  accumulate (low-VALU kernel only): y += result.  mask (optional, shaped like y, low-VALU kernel only: conv_wino64_ok): outputs are zeroed where mask <= 0
 int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
-                  hipStream_t st, float* stats = nullptr, const float* mask = nullptr, int accumulate = 0);
+                  hipStream_t st, float* stats = nullptr, const float* mask = nullptr, int accumulate = 0,
+                  const float* in_mr = nullptr, int in_relu = 0);
 bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W);
 int conv_wino_wgrad_blocks(const ConvIn& in, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
 bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);

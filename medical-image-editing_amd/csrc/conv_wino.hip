@@ -484,8 +484,8 @@ int conv_wino_stat_tiles(int Cin, int Cout, int H, int W) {
 }
 
 int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
-                  hipStream_t st, float* stats, const float* mask, int accumulate) {
-    if ((mask || accumulate) && !conv_wino64_ok(Cin, Cout, W)) {
+                  hipStream_t st, float* stats, const float* mask, int accumulate, const float* in_mr, int in_relu) {
+    if ((mask || accumulate || in_mr) && !conv_wino64_ok(Cin, Cout, W)) {
         vqw_set_error("conv_wino_fwd: the masked / accumulating forms are served by the 64-cout kernel only");
         return VQW_ERR_ARG;
     }
@@ -498,13 +498,14 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
                 const int nn = N - n0 < g ? N - n0 : (int)g;
                 const size_t px = (size_t)n0 * H * W;
                 const int rc = conv_wino_fwd(x + px * Cin, u, bias, y + px * Cout, nn, H, W, Cin, Cout, relu, st,
-                                             stats ? stats + (size_t)n0 * parts * Cout * 2 : nullptr, mask ? mask + px * Cout : nullptr, accumulate);
+                                             stats ? stats + (size_t)n0 * parts * Cout * 2 : nullptr, mask ? mask + px * Cout : nullptr, accumulate,
+                                             in_mr ? in_mr + (size_t)n0 * Cout * 2 : nullptr, in_relu);
                 if (rc) return rc;
             }
             return VQW_OK;
         }
     }
-    if (conv_wino64_ok(Cin, Cout, W)) return conv_wino64_fwd(x, u, bias, y, N, H, W, Cin, Cout, relu, st, stats, mask, accumulate);
+    if (conv_wino64_ok(Cin, Cout, W)) return conv_wino64_fwd(x, u, bias, y, N, H, W, Cin, Cout, relu, st, stats, mask, accumulate, in_mr, in_relu);
     const bool wide = W % 32 == 0;
     const size_t lds = (size_t)(3 * (wide ? WinoGeo<32>::HBUF : WinoGeo<16>::HBUF) + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float);
     static_assert((size_t)(3 * WinoGeo<16>::HBUF + 2 * 16 * 32 * WN_KPU + 2 * 8 * 32 * 2 + 512 * 4) * sizeof(float) <= 160 * 1024, "Winograd buffers do not fit the 160 KB LDS");

@@ -58,6 +58,12 @@ struct W64Args {
     const float* mask;         // EPI 1, shaped like y: outputs are zeroed where mask <= 0 (the ReLU whose output the layer's
                                // forward read: an input-gradient launch then delivers the gradient in front of that ReLU)
                                // EPI 2: y += result (a later member of a gradient group adds to the shared buffer)
+                               // EPI 3: mask = x, the RAW input of the InstanceNorm (+ReLU) whose output the layer's forward
+                               // read; mr = that norm's (mean, rstd) per (image, channel).  The launch is the layer's input
+                               // gradient g; beside storing it, it leaves the norm's backward sums per region in `stats`:
+                               // (sum gm, sum gm * xhat), gm = g where the norm's ReLU passed (all of g without a ReLU)
+    const float* mr;
+    int in_relu;
 };
 
 constexpr int W6_KPH = 10;                 // floats per halo pixel in LDS (8 channels + 2: conflict-free ds_read_b64 patches)
@@ -116,7 +122,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     const int mb = wv & 3, h = wv >> 2;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
-    const __amdgpu_buffer_rsrc_t rsm = make_rsrc(EPI == 1 ? a.mask : a.y, a.nby);  // (instantiations of their own: the plain kernels keep their registers)
+    const __amdgpu_buffer_rsrc_t rsm = make_rsrc((EPI == 1 || EPI == 3) ? a.mask : a.y, a.nby);  // (instantiations of their own: the plain kernels keep their registers)
+    const __amdgpu_buffer_rsrc_t rsr = make_rsrc(EPI == 3 ? a.mr : a.y, EPI == 3 ? (unsigned)((size_t)a.N * a.Cout * 8) : a.nby);
 
     const int ntn = a.ntn, nch = a.nch;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -468,6 +475,23 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
                 } else if (EPI == 2) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) yv[k] = mk[k] + yv[k];
+                } else if (EPI == 3) {
+                    // the norm's backward sums over this lane's 16 pixels of (image cn, channel co)
+                    const unsigned mo = ((unsigned)cn * (unsigned)Cout + co) * 8u;
+                    const float mean = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsr, (int)mo, 0, 0));
+                    const float rstd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsr, (int)mo, 4, 0));
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float xh = (mk[k] - mean) * rstd;
+                        const float gm = (a.in_relu && !(xh > 0.f)) ? 0.f : yv[k];
+                        s1 += gm;
+                        s2 = __builtin_fmaf(gm, xh, s2);
+                    }
+                    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                    if (w == 0) { st1[i] = s1; st2[i] = s2; }
+                    else { st1[i] += s1; st2[i] += s2; }
                 }
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa) {
@@ -478,7 +502,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
                         for (int b = 0; b < 2; ++b)
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
                 }
-                if (a.stats) {     // uniform: H % TR == 0 whenever statistics are requested
+                if (EPI != 3 && a.stats) {     // uniform: H % TR == 0 whenever statistics are requested
                     float t1, t2;
                     lane_stats<16>(yv, t1, t2);
                     stat_merge_eq(t1, t2, __shfl_xor(t1, 16, 64), __shfl_xor(t2, 16, 64), 1.f / 32.f);
@@ -503,8 +527,13 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
             const float* R = Rs + spar * (4 * NCO * 2) + tid * 2;
             float s1 = R[0], s2 = R[1];              // the four waves' 64 MBW pixels each, merged in order
             constexpr float PW = 64.f * MBW;
+            if (EPI == 3) {
 #pragma unroll
-            for (int r = 1; r < 4; ++r) stat_merge(s1, s2, PW * r, R[r * NCO * 2], R[r * NCO * 2 + 1], PW);
+                for (int r = 1; r < 4; ++r) { s1 += R[r * NCO * 2]; s2 += R[r * NCO * 2 + 1]; }
+            } else {
+#pragma unroll
+                for (int r = 1; r < 4; ++r) stat_merge(s1, s2, PW * r, R[r * NCO * 2], R[r * NCO * 2 + 1], PW);
+            }
             const int t = (cn * a.tilesX + ctx) * a.tilesY + cty;
             float* o = a.stats + ((size_t)t * Cout + co_base + tid) * 2;
             o[0] = s1;
@@ -595,9 +624,9 @@ static int launch_wino64(W64Args& a, hipStream_t st) {
 }
 
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
-                    hipStream_t st, float* stats, const float* mask, int accumulate) {
+                    hipStream_t st, float* stats, const float* mask, int accumulate, const float* in_mr, int in_relu) {
     W64Args a;
-    a.x = x; a.u = u; a.bias = bias; a.y = y; a.mask = mask;
+    a.x = x; a.u = u; a.bias = bias; a.y = y; a.mask = mask; a.mr = in_mr; a.in_relu = in_relu;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.nch = Cin / 8;
     a.relu = relu;
@@ -607,6 +636,11 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
     a.nbu = (unsigned)(16L * Cout * Cin * 4);
     a.nby = (unsigned)(P * Cout * 4);
     const int shape = wino64_shape(Cin, Cout, W);
+    if (in_mr) {               // (mask = the norm's raw input, stats = the backward sums)
+        if (shape == 2) return launch_wino64<32, 2, 3>(a, st);
+        if (W % 32 == 0) return launch_wino64<32, 1, 3>(a, st);
+        return launch_wino64<16, 1, 3>(a, st);
+    }
     if (mask) {
         if (shape == 2) return launch_wino64<32, 2, 1>(a, st);
         if (W % 32 == 0) return launch_wino64<32, 1, 1>(a, st);

@@ -462,6 +462,44 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
     return VQW_OK;
 }
 
+// The same backward with the two sums taken from per-region partials part[N][nparts][C][2] = (sum gm, sum gm * xhat) that the
+// consumer convolution's input-gradient launch left in its epilogue (vqw_conv3x3_wino_fwd_inbwd): no reduction pass over x and
+// gy.  One wave per (n, c) adds the regions in double, then the apply kernel of vqw_inorm_bwd.
+__global__ void __launch_bounds__(256) k_plane_sum_finalize_f(const float* __restrict__ part, float* __restrict__ out, int NC, int C,
+                                                              int nparts, double scale) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;
+    if (i >= NC) return;              // wave-uniform
+    const int n = i / C, c = i % C;
+    double a = 0.0, b = 0.0;
+    for (int t = s; t < nparts; t += 64) {
+        const float* o = part + (((long)n * nparts + t) * C + c) * 2;
+        a += (double)o[0];
+        b += (double)o[1];
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (s != 0) return;
+    out[2 * i] = (float)(a * scale);
+    out[2 * i + 1] = (float)(b * scale);
+}
+
+extern "C" int vqw_inorm_bwd_parts(const float* x, const float* mean_rstd, const float* gy, const float* part, int nparts, float* means_ws,
+                                   float* gx, int N, int HW, int C, int relu, void* stream) {
+    VQW_PROF_HBM(stream, 3, (double)N * HW * C);
+    VQW_CHECK(x && mean_rstd && gy && part && means_ws && gx && nparts > 0 && N > 0 && HW > 0 && C > 0, "vqw_inorm_bwd_parts: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    k_plane_sum_finalize_f<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, means_ws, N * C, C, nparts, 1.0 / (double)HW);
+    const long total = (long)N * HW * C;
+    if ((C & 3) == 0 && ((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)mean_rstd | (uintptr_t)means_ws) & 15) == 0)) {
+        const long t4 = total / 4;
+        if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means_ws, (float4*)gx, t4, HW, C / 4, C / 4, 0);
+        else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means_ws, (float4*)gx, t4, HW, C / 4, C / 4, 0);
+    } else if (relu) k_inorm_bwd_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means_ws, gx, total, HW, C, C, 0);
+    else k_inorm_bwd_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means_ws, gx, total, HW, C, C, 0);
+    VQW_LAUNCH_CHECK("vqw_inorm_bwd_parts");
+    return VQW_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward of TWO InstanceNorms that receive the SAME gradient (the two branches in front of a ResBlock tail: a with
 // its ReLU, b without): one reduction and one apply kernel read the common gradient once instead of twice each.

@@ -415,8 +415,13 @@ def _decide_wino_fwd():
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, dilation, up0, relu, want_stats=False, wino_fwd=False, grad_group=None):
+    def forward(ctx, x0, x1, weight, bias, dilation, up0, relu, want_stats=False, wino_fwd=False, grad_group=None, in_src=None):
         _dev(x0, x1, weight, bias)
+        ctx.in_src = None
+        if in_src is not None and x1 is None and not up0 and grad_group is None and dilation == 1 and weight.shape[2] == 3 \
+                and ctx.needs_input_grad[0] and tuple(in_src[0].shape) == tuple(x0.shape) \
+                and _L().vqw_conv3x3_wino_fwd_inbwd_parts(weight.shape[0], weight.shape[1], x0.shape[0], x0.shape[2], x0.shape[3]) > 0:
+            ctx.in_src = in_src            # (raw input of the InstanceNorm whose output x0 is, its (mean, rstd), its ReLU flag)
         x0 = nhwc(x0)
         x1 = nhwc(x1) if x1 is not None else None
         w = nhwc(weight)
@@ -501,18 +506,18 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, *_):
         if gy is None:             # y itself was not used (only possible with gradient materialisation off)
-            return (None,) * 10
+            return (None,) * 11
         x0, x1, w, y_relu = ctx.saved_tensors
         dilation, up0, ks, N, H, W, Cout, has_bias = ctx.cfg
         need0, need1, needw, needb = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         defer = ctx.defer and (needw or (needb and has_bias))
         g0, g1, gw, gb, gy = conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, ctx.up_ws, need0, need1,
-                                                  needw and not defer, needb and not defer, group=ctx.group)
+                                                  needw and not defer, needb and not defer, group=ctx.group, in_src=ctx.in_src)
         if defer:
             weight, bias = ctx.params
             _deferred_wgrad(weight, bias if (has_bias and bias.requires_grad) else None, x0, x1, gy, up0, ks, dilation,
                             N, H, W, Cout, collapsed=ctx.up_ws is not None)
-        return g0, g1, gw, gb, None, None, None, None, None, None
+        return g0, g1, gw, gb, None, None, None, None, None, None, None
 
 
 # Gradients that arrive already multiplied by a fused ReLU's mask: {gradient data_ptr: data_ptr of the ReLU output it was masked
@@ -521,11 +526,17 @@ class _Conv2d(torch.autograd.Function):
 # with another one has a different address: the producer masks it as usual (masking twice would be harmless, too).
 _MASKED_GRADS = {}
 FUSE_RELU_MASK = os.environ.get("VQW_FUSE_RELU_MASK", "1") != "0"
+# Norm-backward sums that a consumer convolution's input-gradient launch has left per region: {gradient data_ptr: (partials,
+# regions per image, data_ptr of the norm's raw input)} - written by conv2d_backward_impl (vqw_conv3x3_wino_fwd_inbwd), read
+# and removed by _InstanceNorm.backward, which then skips its reduction pass over the activation and the gradient.
+_IN_BWD_PARTS = {}
+FUSE_IN_BWD = os.environ.get("VQW_FUSE_IN_BWD", "1") != "0"
+in_bwd_fused_calls = 0         # InstanceNorm backward calls that took their sums from a convolution's epilogue (tests)
 masked_dgrad_calls = 0         # input-gradient launches that applied a ReLU mask in their epilogue (tests)
 group_acc_calls = 0            # Winograd input-gradient launches that added to a gradient group's buffer in their epilogue (tests)
 
 
-def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb, group=None):
+def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb, group=None, in_src=None):
     """Input / weight / bias gradients of conv2d on the current stream -> (g0, g1, gw, gb, masked gy).  x0 / x1 / w are the
     NHWC tensors the forward saw, y_relu its output when the ReLU was fused (the incoming gradient is masked first),
     up_ws the collapsed-weight buffer when the forward took the low-resolution form."""
@@ -584,6 +595,19 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             g_full = empty_nhwc(N, Cin, H, W, gy)
         if g_full is None:
             pass
+        elif in_src is not None and need0 and group is None and FUSE_IN_BWD \
+                and L.vqw_conv3x3_wino_fwd_inbwd_parts(Cout, Cin, N, H, W) > 0:
+            # x0 is the output of an InstanceNorm (+ReLU) and feeds this layer only: the norm's backward sums ride in this launch
+            global in_bwd_fused_calls
+            nparts = L.vqw_conv3x3_wino_fwd_inbwd_parts(Cout, Cin, N, H, W)
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+            bpart = torch.empty(N * nparts * Cin * 2, dtype=torch.float32, device=gy.device)
+            xraw, mr, nrelu = in_src
+            _lib.check(L.vqw_conv3x3_wino_fwd_inbwd(_p(gy), _p(ut), _p(xraw), _p(mr), int(nrelu), _p(g_full), _p(bpart),
+                                                    N, H, W, Cout, Cin, _st()), "vqw_conv3x3_wino_fwd_inbwd(dgrad)")
+            if len(_IN_BWD_PARTS) > 64:
+                _IN_BWD_PARTS.clear()
+            _IN_BWD_PARTS[g_full.data_ptr()] = (bpart, nparts, xraw.data_ptr())
         elif ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W):
             ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
             _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(g_full), N, H, W, Cout, Cin, 0, _st()),
@@ -661,7 +685,7 @@ class GradGroup:
 GRAD_GROUPS = os.environ.get("VQW_GRAD_GROUPS", "1") != "0"      # 0: autograd sums the branch gradients (A/B timing)
 
 
-def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, want_stats=False, grad_group=None):
+def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, want_stats=False, grad_group=None, norm_input=False):
     """'same' conv (k in {1,3}, stride 1) of the virtual input [up2x(x) | skip] (channel concat);
     relu=True fuses nn.ReLU into the epilogue.  want_stats=True returns (y, part): `part` (or None when the shape is not
     served) holds the statistics of y for the InstanceNorm that follows: instance_norm(y, ..., part=part)."""
@@ -674,9 +698,12 @@ def conv2d(x, weight, bias=None, dilation=1, up2x=False, skip=None, relu=False, 
             group = grad_group
     if grad_group is not None and group is None:
         grad_group.opt_out()               # this member's gradient goes through autograd: the others must not wait for it
+    # norm_input=True: x is the output of instance_norm(...) and feeds this layer ONLY - its input-gradient launch then also
+    # leaves that norm's backward sums (a gradient that autograd had to sum with another consumer's would miss them)
+    in_src = getattr(x, "_vqw_in_src", None) if (norm_input and FUSE_IN_BWD) else None
     if want_stats and CONV_STATS:
-        return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), True, wino, group)
-    y = _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), False, wino, group)
+        return _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), True, wino, group, in_src)
+    y = _Conv2d.apply(x, skip, weight, bias, int(dilation), bool(up2x), bool(relu), False, wino, group, in_src)
     return (y, None) if want_stats else y
 
 
@@ -845,15 +872,29 @@ class _InstanceNorm(torch.autograd.Function):
             _lib.check(L.vqw_inorm_fwd(_p(x), _p(y), C, 0, _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, int(relu), _st()), "vqw_inorm_fwd")
         ctx.save_for_backward(x, mr)
         ctx.relu = relu
-        return y
+        ctx.mark_non_differentiable(mr)
+        ctx.set_materialize_grads(False)
+        return y, mr               # mr = (mean, rstd) per (image, channel): for a consumer that fuses this norm's backward sums
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gmr=None):
+        if gy is None:
+            return None, None, None, None
         x, mr = ctx.saved_tensors
         N, C, H, W = x.shape
         L = _L()
         gy = nhwc(gy)
         gx = torch.empty_like(x, memory_format=CL)
+        ent = _IN_BWD_PARTS.pop(gy.data_ptr(), None)
+        if ent is not None and ent[2] == x.data_ptr():
+            # the only consumer's input-gradient launch has left (sum gm, sum gm * xhat) per region: no reduction pass
+            global in_bwd_fused_calls
+            in_bwd_fused_calls += 1
+            bpart, nparts, _ = ent
+            means = torch.empty(N * C * 2, dtype=torch.float32, device=x.device)
+            _lib.check(L.vqw_inorm_bwd_parts(_p(x), _p(mr), _p(gy), _p(bpart), nparts, _p(means), _p(gx), N, H * W, C,
+                                             int(ctx.relu), _st()), "vqw_inorm_bwd_parts")
+            return gx, None, None, None
         ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
         _lib.check(L.vqw_inorm_bwd(_p(x), _p(mr), _p(gy), C, 0, _p(gx), _p(ws), ws.numel(), N, H * W, C, int(ctx.relu), _st()),
                    "vqw_inorm_bwd")
@@ -861,8 +902,13 @@ class _InstanceNorm(torch.autograd.Function):
 
 
 def instance_norm(x, relu=False, eps=1e-5, part=None):
-    """part: statistics partials from conv2d(..., want_stats=True) of the SAME tensor (skips the reduction pass)."""
-    return _InstanceNorm.apply(x, bool(relu), float(eps), part)
+    """part: statistics partials from conv2d(..., want_stats=True) of the SAME tensor (skips the reduction pass).
+    The result carries `_vqw_in_src` = (raw input, relu): a convolution that is this tensor's ONLY consumer can be told so
+    (conv2d(..., norm_input=True)) and then leaves the norm's backward sums in its input-gradient epilogue."""
+    y, mr = _InstanceNorm.apply(x, bool(relu), float(eps), part)
+    if FUSE_IN_BWD and torch.is_grad_enabled() and y.requires_grad:
+        y._vqw_in_src = (nhwc(x), mr, bool(relu))
+    return y
 
 
 class _InstanceNormCat(torch.autograd.Function):

@@ -28,9 +28,9 @@ class Conv2d(nn.Conv2d):
         # OHWI storage (channels_last); logical shape / state_dict unchanged
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x, up2x=False, skip=None, relu=False, want_stats=False, grad_group=None):
+    def forward(self, x, up2x=False, skip=None, relu=False, want_stats=False, grad_group=None, norm_input=False):
         return ops.conv2d(x, self.weight, self.bias, self.dilation[0], up2x=up2x, skip=skip, relu=relu, want_stats=want_stats,
-                          grad_group=grad_group)
+                          grad_group=grad_group, norm_input=norm_input)
 
 
 def conv3x3(in_channels, out_channels, stride=1, padding=1, bias=True):
@@ -117,7 +117,7 @@ class DoubleConv(nn.Module):
         if raw_tail:
             layers = layers[:3]
             x = DoubleConv._run(layers, x, up2x, skip, grad_group)
-            return self.double_conv[3](x, want_stats=True)
+            return self.double_conv[3](x, want_stats=True, norm_input=True)     # x = the first norm's output, read here only
         return DoubleConv._run(layers, x, up2x, skip, grad_group)
 
     @staticmethod
@@ -125,7 +125,9 @@ class DoubleConv(nn.Module):
         i = 0
         while i < len(layers):
             layer = layers[i]
-            kw = dict(up2x=up2x, skip=skip, grad_group=grad_group) if i == 0 else {}
+            # a convolution behind a norm inside this chain is that norm's only consumer
+            kw = dict(up2x=up2x, skip=skip, grad_group=grad_group) if i == 0 else \
+                (dict(norm_input=True) if isinstance(layer, Conv2d) and i >= 2 and isinstance(layers[i - 2], InstanceNorm2d) else {})
             if isinstance(layer, Conv2d) and i + 1 < len(layers) and isinstance(layers[i + 1], InstanceNorm2d):
                 x, part = layer(x, want_stats=True, **kw)
                 x = layers[i + 1](x, part=part)

@@ -617,6 +617,39 @@ def test_block_inputs_with_two_convolutions_sum_their_gradients_in_the_epilogue(
         assert torch.equal(ref[k], got[k]), "gradient %s differs between grouped and autograd-summed input gradients" % k
 
 
+@pytest.mark.parametrize("C,S,B", [(64, 64, 2), (128, 32, 3), (32, 64, 2)])
+def test_instance_norm_backward_sums_from_the_consumer_convolution(monkeypatch, C, S, B):
+    """DoubleConv (blocks.py:39-61): the first InstanceNorm(+ReLU) feeds the second convolution only, so that convolution's
+    input-gradient launch leaves the norm's backward sums (sum gm, sum gm * xhat) per region in its epilogue
+    (vqw_conv3x3_wino_fwd_inbwd) and the norm's backward skips its reduction pass (vqw_inorm_bwd_parts).  Same sums in another
+    order: gradients within 2e-5 of the run with the separate reduction (and of each other's scale), the fused route actually
+    taken, nothing left in the registry."""
+    from networks import blocks as B_
+    from hipops import ops
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSE_IN_BWD", fused)
+        torch.manual_seed(11)
+        mod = B_.DoubleConv(C, C).to(DEV).train()
+        x = torch.randn(B, C, S, S, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        r = torch.randn(B, C, S, S, device=DEV).contiguous(memory_format=torch.channels_last)
+        n0 = ops.in_bwd_fused_calls
+        (mod(x) * r).sum().backward()
+        torch.cuda.synchronize()
+        grads = {"x": x.grad.clone()}
+        grads.update({k: p.grad.clone() for k, p in mod.named_parameters()})
+        return grads, ops.in_bwd_fused_calls - n0
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == 1, (n_ref, n_got)
+    assert not ops._IN_BWD_PARTS
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for k in ref:
+        if float(ref[k].abs().max()) < 1e-4 * gmax:      # biases in front of a norm: analytically zero, rounding noise only
+            continue
+        assert_close(got[k], ref[k], 2e-5, "gradient %s, norm-backward sums from the convolution's epilogue" % k)
+
+
 # --------------------------------------------------------------------------------------------------
 # vector quantiser
 # --------------------------------------------------------------------------------------------------
