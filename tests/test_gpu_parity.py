@@ -1581,6 +1581,44 @@ def test_host_throttle_bounds_steps_in_flight_and_allocator_pool():
     assert grown <= 0.25 * s0["reserved_bytes.all.current"], "allocator pool grew by %.1f MB over 8 steady-state steps" % (grown / 2**20)
 
 
+def test_full_size_epilogue_fusions_agree_with_the_separate_passes(monkeypatch):
+    """BASELINE config 2's network at 256 x 256 (batch 8): one training step with the backward fusions of round 3 - the ReLU
+    mask in the gamma | beta input-gradient epilogue, gradient-group sums of block inputs, InstanceNorm backward sums from the
+    consumer convolution - against the same step with every one of them as a separate pass.  The forward is untouched (loss
+    and ids bit-equal); mask and group sums are the same additions (a + b), the norm sums are the same terms in another
+    order, so every live gradient agrees to 1e-4 of its norm; and the fused step is bit-deterministic run to run."""
+    import bench
+    from hipops import ops
+    from networks import blocks as B_
+    from trainers import FirstStepTrainer
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSE_RELU_MASK", fused)
+        monkeypatch.setattr(ops, "FUSE_IN_BWD", fused)
+        monkeypatch.setattr(B_, "GRAD_GROUP_BLOCKS", fused)
+        torch.manual_seed(0)
+        tr = FirstStepTrainer(device=DEV)
+        img, noise = bench.synthetic_batch(8, 256, 77, torch.device(DEV))
+        c0 = (ops.masked_dgrad_calls, ops.group_acc_calls, ops.in_bwd_fused_calls)
+        out = tr.training_step({"image": img}, noise=noise)
+        torch.cuda.synchronize()
+        counts = (ops.masked_dgrad_calls - c0[0], ops.group_acc_calls - c0[1], ops.in_bwd_fused_calls - c0[2])
+        grads = {"enc." + k: p.grad.detach().clone() for k, p in tr.encoder.named_parameters()}
+        grads.update({"dec." + k: p.grad.detach().clone() for k, p in tr.decoder.named_parameters()})
+        return float(out["total"].detach()), out["ids_1"].clone(), grads, counts
+    l0, ids0, g0, n0 = run(False)
+    l1, ids1, g1, n1 = run(True)
+    l2, ids2, g2, n2 = run(True)
+    assert n0 == (0, 0, 0) and min(n1) >= 8 and n1 == n2, (n0, n1, n2)
+    assert l0 == l1 == l2 and torch.equal(ids0, ids1)
+    assert all(torch.equal(g1[k], g2[k]) for k in g1), "the fused step is not deterministic"
+    gmax = max(float(v.norm()) for v in g0.values())
+    for k in g0:
+        if float(g0[k].norm()) < 1e-5 * gmax:         # analytically zero (biases in front of a norm): rounding noise only
+            continue
+        assert_close(g1[k], g0[k], 1e-4, "gradient %s with the epilogue fusions" % k)
+
+
 def test_training_step_is_bit_deterministic():
     """Two runs of the same seeded training (fresh modules, three steps, two views on two streams, weight gradients on
     the side stream) end in bit-identical parameters, codebook and losses: no result depends on kernel scheduling
