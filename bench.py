@@ -119,10 +119,15 @@ def main():
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "baseline2_256x256_b32_1gpu.json"),
                     help="reference-style JSON config (configs/); --batch / --size override its dataset section")
     ap.add_argument("--serial-steps", type=int, default=5, help="steps of the serialised per-kernel timing pass")
+    ap.add_argument("--dp-overlap", type=int, choices=(0, 1), default=None,
+                    help="data-parallel gradient exchange: 1 = buckets all-reduced from inside the backward pass (overlapped with the "
+                         "remaining backward kernels), 0 = after the backward pass; default: VQW_DP_OVERLAP or 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
+    if args.dp_overlap is not None:
+        os.environ["VQW_DP_OVERLAP"] = str(args.dp_overlap)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -261,15 +266,15 @@ def main():
             # HBM bytes per launch of that family: NOT measured by this run (PMC counters need rocprofv3 around the
             # process) but read from the committed PMC passes of this same command (tools/pmc_traffic.py); the file
             # names the digest of the kernel sources it was taken with, and a stale or missing file gives null
-            traffic, traffic_source = None, "none: profiles/r03_hbm_traffic.json missing"
+            traffic, traffic_source = None, "none: profiles/r04_hbm_traffic.json missing"
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
                 if tj.get("csrc_digest") == csrc_digest():
                     # per API launch of the family (a call may be several kernel launches): bytes per step / calls per step
                     traffic = tj["families"][dom]["hbm_bytes_per_step"] / primary[dom]["launches_per_step"]
-                    traffic_source = "profiles/r03_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel sources %s)" % tj["csrc_digest"][:12]
+                    traffic_source = "profiles/r04_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, kernel sources %s)" % tj["csrc_digest"][:12]
                 else:
-                    traffic_source = "none: profiles/r03_hbm_traffic.json was taken with other kernel sources"
+                    traffic_source = "none: profiles/r04_hbm_traffic.json was taken with other kernel sources"
             except Exception:
                 pass
             roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=PEAK_FP32_MFMA / 1e12, unit="TFLOP/s",
@@ -284,10 +289,11 @@ def main():
             if dom == "conv_winograd":
                 # this family's FLOPs are the 4/9 of the direct form's that its kernels execute: `achieved` / `frac` are
                 # hardware utilisation; priced at the direct form's (the operator's algorithmic) FLOPs the rate is 2.25x
-                roofline["achieved_in_direct_form_flops"] = ach * 2.25
-                roofline["frac_in_direct_form_flops"] = ach * 2.25 / (PEAK_FP32_MFMA / 1e12)
-                roofline["note"] = ("Winograd F(2x2,3x3) kernels: achieved/frac count the FLOPs executed (4/9 of the direct "
-                                    "form's); *_in_direct_form_flops price the same launches at the operator's FLOPs")
+                roofline["algorithmic_direct_form"] = dict(
+                    achieved=ach * 2.25, ratio_to_peak=ach * 2.25 / (PEAK_FP32_MFMA / 1e12),
+                    note="the same launches priced at the operator's direct-form FLOPs (x 2.25): credit for work the Winograd "
+                         "form avoids, NOT utilisation - the ratio can exceed 1")
+                roofline["note"] = "Winograd F(2x2,3x3) kernels: achieved / frac count the FLOPs executed (4/9 of the direct form's)"
             if kern_x and dom in kern_c:
                 roofline["timed_region_concurrent"] = dict(
                     achieved=kern_c[dom]["tflops"], frac=kern_c[dom]["tflops"] / (PEAK_FP32_MFMA / 1e12),
@@ -325,18 +331,37 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             # whole step against the two rooflines.  "algorithmic" = the reference's conv FLOPs / bytes, i.e.
             # credit for work avoided (collapsed up-sampled and Winograd-form layers); "executed" = FLOPs the kernels ran = hardware utilisation
-            "step_fraction_of_fp32_mfma_roofline": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA if rcfg else None,
-            "step_fraction_of_fp32_mfma_roofline_algorithmic": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA if rcfg else None,
+            # (the un-suffixed key is the EXECUTED fraction = utilisation; the algorithmic one prices Winograd-form and collapsed
+            # layers at operator FLOPs their kernels legitimately do not execute (4/9, 1/4) and can therefore exceed 1)
+            "step_fraction_of_fp32_mfma_roofline": executed / (ms_per_step * 1e-3) / PEAK_FP32_MFMA if executed else None,
             "step_fraction_of_fp32_mfma_roofline_executed": executed / (ms_per_step * 1e-3) / PEAK_FP32_MFMA if executed else None,
+            "step_fraction_of_fp32_mfma_roofline_algorithmic": per_gpu * FLOP_PER_IMAGE * scale / PEAK_FP32_MFMA if rcfg else None,
+            "step_fraction_of_fp32_mfma_roofline_algorithmic_note": "operator FLOPs of the reference's convolutions / peak: credit for "
+                                                                    "work avoided, not utilisation; can exceed 1",
             "step_fraction_of_hbm_roofline": per_gpu * BYTES_PER_IMAGE * scale / PEAK_HBM if rcfg else None,
             "loss_total": total,
             # ranks of the RCCL process group the timed steps ran in (0: no process group - a plain single-GPU run), and the
             # collectives one rank issued per step: SyncBN / VQ statistics all-reduces, gradient-bucket all-reduces
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else 0,
             "collectives_per_step": {"statistics": (coll1[0] - coll0[0]) / args.steps, "gradient_buckets": (coll1[1] - coll0[1]) / args.steps},
+            # how the gradient buckets are exchanged when there is more than one rank ("overlap": launched from inside the
+            # backward pass as each bucket completes; "after_backward": in finish(), after the pass is enqueued); --dp-overlap
+            "dp": (tr.reducer.describe() if tr.reducer is not None else
+                   {"dp_schedule": "none (single rank, no reducer)", "would_be": "overlap" if os.environ.get("VQW_DP_OVERLAP", "0") != "0" else "after_backward"}),
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
         }
+        # launches per step and the fraction of the step with a matrix-core kernel running: from the committed kernel trace of
+        # this same command (tools/stream_timeline.py --json over a rocprofv3 --kernel-trace run), tied to the sources by digest
+        try:
+            tl = json.load(open(os.path.join(ROOT, "profiles", "r04_stream_timeline.json")))
+            stale = tl.get("csrc_digest") != csrc_digest()
+            line["launches_per_step"] = tl["launches_per_step"]
+            line["mfma_active_fraction"] = tl["mfma_active_fraction"]
+            line["timeline_source"] = "profiles/r04_stream_timeline.json (rocprofv3 --kernel-trace of this command)" + \
+                (": taken with other kernel sources" if stale else "")
+        except Exception:
+            line["launches_per_step"] = line["mfma_active_fraction"] = None
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.size)
         print(json.dumps(line), flush=True)

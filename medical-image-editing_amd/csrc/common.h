@@ -9,7 +9,8 @@
 #define VQW_ERR_ARG (-1)
 #define VQW_ERR_HIP (-2)
 
-extern "C" void vqw_set_error(const char* fmt, ...);
+// internal helper: not part of the C ABI (hidden visibility keeps it out of the dynamic symbol table)
+extern "C" __attribute__((visibility("hidden"))) void vqw_set_error(const char* fmt, ...);
 
 #define VQW_CHECK(cond, ...)                                                   \
     do {                                                                       \

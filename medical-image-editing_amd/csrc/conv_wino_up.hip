@@ -973,7 +973,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_wgrad(WUpWgArgs a) {
 
 // Shapes served: full-resolution width a multiple of 32; Cout % 16 (an even number of 8-channel chunks); Cin % 64.
 bool conv_wino_up_dgrad_ok(int Cin, int Cout, int N, int h, int w) {
-    if (!g_wup_env || Cin % 64 != 0 || Cout % 16 != 0 || (2 * w) % 32 != 0 || h < 1 || N < 1) return false;
+    if (!g_wup_env || g_wino_mode != 0 || Cin % 64 != 0 || Cout % 16 != 0 || (2 * w) % 32 != 0 || h < 1 || N < 1) return false;
     const long P = (long)N * 4 * h * w;
     return P * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
 }
@@ -1027,7 +1027,7 @@ int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, in
 
 // Forward: Cin % 16 (an even number of chunks), Cout % 64, full-resolution width a multiple of 32
 bool conv_wino_up_fwd_ok(int Cin, int Cout, int N, int h, int w) {
-    if (!g_wup_env || Cin % 16 != 0 || Cout % 64 != 0 || (2 * w) % 32 != 0 || h < 1 || N < 1) return false;
+    if (!g_wup_env || g_wino_mode != 0 || Cin % 16 != 0 || Cout % 64 != 0 || (2 * w) % 32 != 0 || h < 1 || N < 1) return false;
     const long P = (long)N * 4 * h * w;
     return P * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
 }
@@ -1057,7 +1057,7 @@ int conv_wino_up_fwd(const float* x_low, const float* ws, const float* bias, flo
 
 // Weight gradient: Cin % 32, Cout % 32, low-resolution maps of whole 4 x 16 regions
 bool conv_wino_up_wgrad_ok(int Cin, int Cout, int N, int h, int w) {
-    if (!g_wup_env || Cin % 32 != 0 || Cout % 32 != 0 || w % 16 != 0 || h % 4 != 0 || N < 1) return false;
+    if (!g_wup_env || g_wino_mode != 0 || Cin % 32 != 0 || Cout % 32 != 0 || w % 16 != 0 || h % 4 != 0 || N < 1) return false;
     const long P = (long)N * 4 * h * w;
     return P * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
 }

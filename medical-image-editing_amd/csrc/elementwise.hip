@@ -4,7 +4,7 @@
 #include "../../include/vqwnet_hip.h"
 
 static thread_local char g_err[512] = "";
-extern "C" void vqw_set_error(const char* fmt, ...) {
+extern "C" __attribute__((visibility("hidden"))) void vqw_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);

@@ -108,7 +108,7 @@ def _flat(t):
 # VQW_WGRAD_STREAM=0 disables it (weight gradients then flow through autograd as usual).
 WGRAD_ASYNC = os.environ.get("VQW_WGRAD_STREAM", "1") != "0"
 _side_streams = {}
-_join_queued = False
+_join_queued_for = None        # id of the backward pass (autograd graph task) whose end-of-pass lane join is queued
 grad_ready_listeners = []      # callables(param): the param's gradient is final and enqueued on the side stream
 
 
@@ -208,11 +208,27 @@ def _wgrad_lane(param):
     return lane
 
 
+def _pass_id():
+    """Identity of the running backward pass (autograd graph task); -1 outside of one."""
+    return torch._C._current_graph_task_id()
+
+
 def _join_side_stream():
-    global _join_queued
-    _join_queued = False
+    """Order the current stream after the weight-gradient lanes (idempotent)."""
+    global _join_queued_for
+    _join_queued_for = None
     for st in _side_streams.values():
         torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def _queue_lane_join():
+    """Queue the lane join as an end-of-pass callback, once per backward pass.  The flag holds the pass's id, not a bool: a
+    pass that ended in an exception (the engine skips every callback queued behind one that raises) cannot latch it."""
+    global _join_queued_for
+    tid = _pass_id()
+    if _join_queued_for != tid:
+        _join_queued_for = tid
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -322,7 +338,6 @@ def _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, col
 
 def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, collapsed=False):
     """Enqueue dW (and db) on the side stream, writing into weight.grad / bias.grad."""
-    global _join_queued
     L = _L()
     main = torch.cuda.current_stream()
     side = wgrad_stream(gy.device, _wgrad_lane(weight))
@@ -350,9 +365,7 @@ def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, 
                 fn(weight)
                 if bias is not None:
                     fn(bias)
-    if not _join_queued:
-        _join_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+    _queue_lane_join()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -520,17 +533,59 @@ class _Conv2d(torch.autograd.Function):
         return g0, g1, gw, gb, None, None, None, None, None, None, None
 
 
-# Gradients that arrive already multiplied by a fused ReLU's mask: {gradient data_ptr: data_ptr of the ReLU output it was masked
-# with}.  Written by a consumer whose input-gradient kernel applies the mask in its epilogue (vqw_conv3x3_wino_fwd_masked),
-# read (and removed) by the producer's backward, which then skips its own mask pass.  A gradient that autograd has summed
-# with another one has a different address: the producer masks it as usual (masking twice would be harmless, too).
-_MASKED_GRADS = {}
+class _GradNotes:
+    """Notes that a consumer's input-gradient launch leaves for the producer's backward of the SAME backward pass, keyed by the
+    gradient tensor it hands to autograd.  A note is honoured only when the tensor that reaches the producer is that very
+    gradient, untouched: same address, same version counter (autograd's InputBuffer sums the gradients of a tensor with
+    several consumers IN PLACE when it owns the first one - `old.add_(new)` keeps the address and bumps the version), same
+    backward pass (addresses recur from step to step under the caching allocator).  Whatever is left at the end of a pass is
+    dropped by an end-of-pass callback, and begin_step() drops it again (the engine skips callbacks behind one that raises)."""
+
+    def __init__(self):
+        self.notes = {}
+        self._armed_for = None
+
+    def put(self, grad, payload):
+        tid = _pass_id()
+        if tid >= 0 and self._armed_for != tid:      # (outside a backward pass nobody will take the note: begin_step() drops it)
+            self._armed_for = tid
+            torch.autograd.Variable._execution_engine.queue_callback(self.clear)
+        self.notes[grad.data_ptr()] = (grad._version, tid, payload)
+
+    def take(self, grad):
+        ent = self.notes.pop(grad.data_ptr(), None)
+        if ent is None or ent[0] != grad._version or ent[1] != _pass_id():
+            return None
+        return ent[2]
+
+    def clear(self):
+        self.notes.clear()
+        self._armed_for = None
+
+    def __len__(self):
+        return len(self.notes)
+
+
+# Gradients that arrive already multiplied by a fused ReLU's mask: payload = data_ptr of the ReLU output the gradient was masked
+# with.  Written by a consumer whose input-gradient kernel applies the mask in its epilogue (vqw_conv3x3_wino_fwd_masked),
+# taken by the producer's backward, which then skips its own mask pass.
+_MASKED_GRADS = _GradNotes()
 FUSE_RELU_MASK = os.environ.get("VQW_FUSE_RELU_MASK", "1") != "0"
-# Norm-backward sums that a consumer convolution's input-gradient launch has left per region: {gradient data_ptr: (partials,
-# regions per image, data_ptr of the norm's raw input)} - written by conv2d_backward_impl (vqw_conv3x3_wino_fwd_inbwd), read
-# and removed by _InstanceNorm.backward, which then skips its reduction pass over the activation and the gradient.
-_IN_BWD_PARTS = {}
+# Norm-backward sums that a consumer convolution's input-gradient launch has left per region: payload = (partials, regions per
+# image, data_ptr of the norm's raw input) - written by conv2d_backward_impl (vqw_conv3x3_wino_fwd_inbwd), taken by
+# _InstanceNorm.backward, which then skips its reduction pass over the activation and the gradient.
+_IN_BWD_PARTS = _GradNotes()
 FUSE_IN_BWD = os.environ.get("VQW_FUSE_IN_BWD", "1") != "0"
+
+
+def begin_step():
+    """Call before the forwards of a training step: drops fusion notes and a lane join that a failed backward pass left."""
+    _MASKED_GRADS.clear()
+    _IN_BWD_PARTS.clear()
+    if _join_queued_for is not None:
+        _join_side_stream()
+
+
 in_bwd_fused_calls = 0         # InstanceNorm backward calls that took their sums from a convolution's epilogue (tests)
 masked_dgrad_calls = 0         # input-gradient launches that applied a ReLU mask in their epilogue (tests)
 group_acc_calls = 0            # Winograd input-gradient launches that added to a gradient group's buffer in their epilogue (tests)
@@ -545,9 +600,10 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
     Cout, Cin, ks, _ = w.shape
     N = x0.shape[0]
     H, W = (x0.shape[2] * 2, x0.shape[3] * 2) if up0 else (x0.shape[2], x0.shape[3])
+    masked_with = _MASKED_GRADS.take(gy) if y_relu is not None else None
     gy = nhwc(gy)
     if y_relu is not None:   # fused ReLU epilogue: mask the incoming gradient first
-        if _MASKED_GRADS.pop(gy.data_ptr(), None) == y_relu.data_ptr():
+        if masked_with is not None and masked_with == y_relu.data_ptr():
             pass             # the consumer's input-gradient kernel has applied this very mask in its epilogue (_ConvCat.backward)
         else:
             gm = torch.empty_like(y_relu, memory_format=CL)
@@ -605,9 +661,7 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             xraw, mr, nrelu = in_src
             _lib.check(L.vqw_conv3x3_wino_fwd_inbwd(_p(gy), _p(ut), _p(xraw), _p(mr), int(nrelu), _p(g_full), _p(bpart),
                                                     N, H, W, Cout, Cin, _st()), "vqw_conv3x3_wino_fwd_inbwd(dgrad)")
-            if len(_IN_BWD_PARTS) > 64:
-                _IN_BWD_PARTS.clear()
-            _IN_BWD_PARTS[g_full.data_ptr()] = (bpart, nparts, xraw.data_ptr())
+            _IN_BWD_PARTS.put(g_full, (bpart, nparts, xraw.data_ptr()))
         elif ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W):
             ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
             _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(g_full), N, H, W, Cout, Cin, 0, _st()),
@@ -677,6 +731,10 @@ class GradGroup:
         if self.buf is not None or self.remaining != self.members:
             ran = self.members - self.remaining
             self.buf, self.remaining = None, self.members
+            # the engine skips every callback queued behind one that raises: do the lane join and drop the fusion notes here
+            _join_side_stream()
+            _MASKED_GRADS.clear()
+            _IN_BWD_PARTS.clear()
             raise RuntimeError("GradGroup: only %d of %d members took part in this backward pass - their shared input "
                                "gradient was not delivered (partial backward over grouped branches: set VQW_GRAD_GROUPS=0)"
                                % (ran, self.members))
@@ -733,7 +791,6 @@ def _grad_halves_adjacent(pa, pb, ga, gb_):
 
 
 def _deferred_wgrad_cat(wa, ba, wb, bb, x0, gy, ks, N, H, W):
-    global _join_queued
     L = _L()
     main = torch.cuda.current_stream()
     side = wgrad_stream(gy.device, _wgrad_lane(wa))
@@ -768,9 +825,7 @@ def _deferred_wgrad_cat(wa, ba, wb, bb, x0, gy, ks, N, H, W):
             for fn in grad_ready_listeners:
                 for p in (wa, ba, wb, bb):
                     fn(p)
-    if not _join_queued:
-        _join_queued = True
-        torch.autograd.Variable._execution_engine.queue_callback(_join_side_stream)
+    _queue_lane_join()
 
 
 class _ConvCat(torch.autograd.Function):
@@ -823,9 +878,7 @@ class _ConvCat(torch.autograd.Function):
                     # the gradient in FRONT of the producer's ReLU: its mask (x > 0) applied in this kernel's epilogue
                     _lib.check(L.vqw_conv3x3_wino_fwd_masked(_p(gy), _p(ut), _p(x), _p(gx), N, H, W, Ct, Cin, _st()),
                                "vqw_conv3x3_wino_fwd_masked(dgrad)")
-                    if len(_MASKED_GRADS) > 64:
-                        _MASKED_GRADS.clear()
-                    _MASKED_GRADS[gx.data_ptr()] = x.data_ptr()
+                    _MASKED_GRADS.put(gx, x.data_ptr())
                     global masked_dgrad_calls
                     masked_dgrad_calls += 1
                 else:
@@ -883,9 +936,9 @@ class _InstanceNorm(torch.autograd.Function):
         x, mr = ctx.saved_tensors
         N, C, H, W = x.shape
         L = _L()
+        ent = _IN_BWD_PARTS.take(gy)
         gy = nhwc(gy)
         gx = torch.empty_like(x, memory_format=CL)
-        ent = _IN_BWD_PARTS.pop(gy.data_ptr(), None)
         if ent is not None and ent[2] == x.data_ptr():
             # the only consumer's input-gradient launch has left (sum gm, sum gm * xhat) per region: no reduction pass
             global in_bwd_fused_calls
@@ -1833,7 +1886,9 @@ def neg_mean(logits):
 
 def set_conv_backend(mode):
     """0 = auto (MFMA kernels where shapes allow), 1 = generic VALU kernels only (testing), 2 = no LDS-resident tile kernels,
-    3 = auto without any Winograd-form kernel.  Returns the previous mode."""
+    3 = auto without any Winograd-form kernel (F(2x2, 3x3) forward / input / weight gradients and the nine-product forms of the
+    up-sampled layers: plain direct-form arithmetic everywhere).  Modes 2 and 3 are the A/B references of the tests.  Returns
+    the previous mode."""
     return _L().vqw_set_conv_backend(int(mode))
 
 

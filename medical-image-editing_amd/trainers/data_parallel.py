@@ -24,6 +24,13 @@ import torch
 import torch.distributed as dist
 
 
+# Tensors handed to a collective are kept alive by the work object instead of being recorded on RCCL's stream: a recorded
+# block cannot be reused by the caching allocator until that stream has passed it (pool growth = hipMalloc stalls inside the
+# step, profiles/r03_dp_one_gpu.txt).  ProcessGroupNCCL reads the variable when the group is created, so it is set here, at
+# import of the trainers package (before any trainer can create a group), for training runs and bench.py alike; an explicit
+# setting in the environment wins.
+os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
+
 _SKIP_COLLECTIVE = os.environ.get("VQW_DP_DEBUG", "") == "noar"
 _HOST_TIMING = os.environ.get("VQW_DP_HOST_TIMING", "0") == "1"     # measurement aid: host time spent inside dist.all_reduce
 
@@ -71,6 +78,12 @@ class GradientAllReducer:
             self._sync_lanes = _ops.sync_wgrad_lanes
         except Exception:       # plain torch modules (CPU tests)
             pass
+
+    def describe(self):
+        """What a log line needs to be read without the source: schedule, bucket count and sizes."""
+        sizes = [sum(p.numel() * p.element_size() for p in b) for b in self.buckets]
+        return dict(dp_schedule="overlap" if self.overlap else "after_backward", gradient_buckets=len(self.buckets),
+                    gradient_bucket_bytes=sizes, gradient_bytes=sum(sizes))
 
     def close(self):
         """Detach from the parameters: remove the hooks, give back the hook allowance, stop listening to the side stream."""

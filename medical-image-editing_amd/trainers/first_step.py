@@ -223,6 +223,7 @@ class FirstStepTrainer:
     def training_step(self, batch, noise=None):
         image = batch['image'] if isinstance(batch, dict) else batch
         self.throttle.begin()
+        ops.begin_step()
         if self.reducer is not None:
             ops.reset_pending(self._params)
         out = self.forward_losses(image, noise)

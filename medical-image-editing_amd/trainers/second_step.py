@@ -44,6 +44,7 @@ class SecondStepTrainer:
         image = batch['image'] if isinstance(batch, dict) else batch
         w = self.w
         self.throttle.begin()
+        ops.begin_step()
         if self.dec_reducer is not None:
             ops.reset_pending(self.dec_optim.param_groups[0]["params"])
         self.encoder.eval()

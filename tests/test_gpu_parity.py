@@ -650,6 +650,131 @@ def test_instance_norm_backward_sums_from_the_consumer_convolution(monkeypatch, 
         assert_close(got[k], ref[k], 2e-5, "gradient %s, norm-backward sums from the convolution's epilogue" % k)
 
 
+@pytest.mark.parametrize("second_first", [False, True])
+def test_fusion_notes_are_not_honoured_when_the_activation_has_a_second_consumer(monkeypatch, second_first):
+    """The two epilogue fusions pass a note from the consumer's backward to the producer's, keyed by the gradient tensor
+    (ops._GradNotes).  The callers promise "one consumer" (norm_input=True / relu_input=True); this test breaks that promise
+    on purpose.  With a second consumer autograd's InputBuffer sums the two gradients - IN PLACE into the first one to arrive
+    when it owns it, so the sum can keep the annotated gradient's address (second_first=False: the convolution's gradient
+    arrives first and is the one added into).  The note must then be ignored: gradients equal the run with both fusions off.
+    (Round 3's address-only key took the note in exactly that case and returned a gradient without the second consumer's
+    share in the norm's sums / skipped the ReLU mask on the summed gradient.)"""
+    from hipops import ops
+    C, S = 64, 32
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+    torch.manual_seed(21)
+    w0 = cl(torch.randn(C, C, 3, 3, device=DEV) * 0.05)
+    w1 = cl(torch.randn(C, C, 3, 3, device=DEV) * 0.05)
+    wa, wb = cl(torch.randn(C, C, 3, 3, device=DEV) * 0.05), cl(torch.randn(C, C, 3, 3, device=DEV) * 0.05)
+    ba, bb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    x = cl(torch.randn(2, C, S, S, device=DEV))
+    r1, r2 = cl(torch.randn(2, C, S, S, device=DEV)), cl(torch.randn(2, C, S, S, device=DEV))
+    r3 = cl(torch.randn(2, 2 * C, S, S, device=DEV))
+
+    def run(fused):
+        monkeypatch.setattr(ops, "FUSE_IN_BWD", fused)
+        monkeypatch.setattr(ops, "FUSE_RELU_MASK", fused)
+        out = {}
+        # (1) a norm_input=True activation with a second consumer
+        xs = x.clone(memory_format=torch.channels_last).requires_grad_(True)
+        ws = [w.clone(memory_format=torch.channels_last).requires_grad_(True) for w in (w0, w1)]
+        y, part = ops.conv2d(xs, ws[0], want_stats=True)
+        a = ops.instance_norm(y, relu=True, part=part)
+        if second_first:
+            other = ops.add(a, r2)
+            z = ops.conv2d(a, ws[1], norm_input=True)
+        else:
+            z = ops.conv2d(a, ws[1], norm_input=True)
+            other = ops.add(a, r2)
+        n0 = ops.in_bwd_fused_calls
+        ((z * r1).sum() + (other * r2).sum()).backward()
+        torch.cuda.synchronize()
+        out["norm"] = (xs.grad.clone(), ws[0].grad.clone(), ws[1].grad.clone(), ops.in_bwd_fused_calls - n0)
+        # (2) a relu_input=True activation with a second consumer
+        xs = x.clone(memory_format=torch.channels_last).requires_grad_(True)
+        w = w0.clone(memory_format=torch.channels_last).requires_grad_(True)
+        if second_first:
+            act = ops.conv2d(xs, w, relu=True)
+            other = ops.add(act, r2)
+            gb = ops.conv2d_cat(act, wa, ba, wb, bb, relu_input=True)
+        else:
+            act = ops.conv2d(xs, w, relu=True)
+            gb = ops.conv2d_cat(act, wa, ba, wb, bb, relu_input=True)
+            other = ops.add(act, r2)
+        ((gb * r3).sum() + (other * r1).sum()).backward()
+        torch.cuda.synchronize()
+        out["relu"] = (xs.grad.clone(), w.grad.clone())
+        return out
+    ref = run(False)
+    got = run(True)
+    assert ref["norm"][3] == 0 and got["norm"][3] == 0, "the norm took its backward sums from a consumer that is not its only one"
+    assert not ops._IN_BWD_PARTS and not ops._MASKED_GRADS, "notes must not outlive their backward pass"
+    for k in ("norm", "relu"):
+        for i, (u, v) in enumerate(zip(ref[k][:3], got[k][:3])):
+            assert torch.equal(u, v), "%s case, gradient %d differs from the run with the fusions off" % (k, i)
+    # the same wiring WITH the promise kept still takes the fused routes (the check above is not vacuous)
+    monkeypatch.setattr(ops, "FUSE_IN_BWD", True)
+    xs = x.clone(memory_format=torch.channels_last).requires_grad_(True)
+    ws = [w.clone(memory_format=torch.channels_last).requires_grad_(True) for w in (w0, w1)]
+    y, part = ops.conv2d(xs, ws[0], want_stats=True)
+    n0 = ops.in_bwd_fused_calls
+    (ops.conv2d(ops.instance_norm(y, relu=True, part=part), ws[1], norm_input=True) * r1).sum().backward()
+    torch.cuda.synchronize()
+    assert ops.in_bwd_fused_calls - n0 == 1
+
+
+def test_grad_notes_key_on_address_version_and_pass():
+    """ops._GradNotes in isolation: a note is taken only by the same tensor, unmodified, inside the backward pass that left it."""
+    from hipops import ops
+    notes = ops._GradNotes()
+    seen = {}
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, mode):
+            ctx.mode = mode
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            if ctx.mode == "put":
+                out = g * 2.0
+                notes.put(out, "note")
+                seen["put"] = out.data_ptr()
+                return out, None
+            seen[ctx.mode] = notes.take(g)
+            seen[ctx.mode + "_ptr"] = g.data_ptr()
+            return g, None
+    # one consumer: the producer's backward sees the annotated tensor itself
+    x = torch.randn(8, device=DEV, requires_grad=True)
+    Probe.apply(Probe.apply(x, "single"), "put").sum().backward()
+    assert seen["single"] == "note" and seen["single_ptr"] == seen["put"] and len(notes) == 0
+    # two consumers, the annotated gradient arrives first: summed in place (same address, version bumped) or out of place
+    x = torch.randn(8, device=DEV, requires_grad=True)
+    mid = Probe.apply(x, "double")
+    other = mid * 3.0
+    (Probe.apply(mid, "put").sum() + other.sum()).backward()
+    assert seen["double"] is None, "a summed gradient took the note (address %s, annotated %s)" % (seen["double_ptr"], seen["put"])
+    assert len(notes) == 0, "the end-of-pass callback drops what nobody took"
+    # a note left outside / in another pass is not honoured
+    t = torch.ones(4, device=DEV)
+    notes.put(t, "stale")
+    x = torch.randn(4, device=DEV, requires_grad=True)
+
+    class Take(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            seen["other_pass"] = notes.take(t)
+            return g
+    Take.apply(x).sum().backward()
+    assert seen["other_pass"] is None
+    ops.begin_step()
+
+
 # --------------------------------------------------------------------------------------------------
 # vector quantiser
 # --------------------------------------------------------------------------------------------------
@@ -1672,6 +1797,45 @@ def test_conv_forms_agree_at_baseline_sizes(N, S, Cin, Cout, dil):
         assert_close(ops.conv2d(x, w, b, dilation=dil), r[0], 2e-6, "forward-only form")
 
 
+@pytest.mark.parametrize("N,s,Cin,Cout", [(4, 32, 256, 128), (2, 64, 128, 64), (4, 16, 512, 256)])
+def test_upsampled_winograd_forms_against_the_collapsed_forms(N, s, Cin, Cout):
+    """3x3 over a nearest-x2 up-sampled input (StyledResUpBlock conv / conv1, blocks.py:100-112): the nine-product Winograd
+    kernels (conv_wino_up.hip: forward, input gradient incl. its accumulating form, weight gradient) against the 16-tap
+    collapsed forms on the same tensors.  Backend 3 ("no Winograd-form kernel anywhere") now switches the nine-product
+    kernels off as well, so the 0-vs-3 A/B tests of the step really compare against direct-form arithmetic."""
+    ops = _ops()
+    L = ops._L()
+    g = torch.Generator(device=DEV).manual_seed(N + s + Cin)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+    x = cl(torch.randn(N, Cin, s, s, device=DEV, generator=g))
+    wa = cl(torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (9 * Cin) ** 0.5)
+    wb = cl(torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (9 * Cin) ** 0.5)
+    b = torch.randn(Cout, device=DEV, generator=g)
+    gya = cl(torch.randn(N, Cout, 2 * s, 2 * s, device=DEV, generator=g))
+    gyb = cl(torch.randn(N, Cout, 2 * s, 2 * s, device=DEV, generator=g))
+
+    def run(backend):
+        old = ops.set_conv_backend(backend)
+        try:
+            has_acc = bool(L.vqw_conv3x3_up2_dgrad_acc_supported(Cin, Cout, N, s, s))
+            xs = x.clone(memory_format=torch.channels_last).requires_grad_(True)
+            was, wbs, bs = (t.clone(memory_format=torch.channels_last).requires_grad_(True) for t in (wa, wb, b))
+            grp = ops.GradGroup(2)             # two up-sampled convolutions of one input: the second adds in its epilogue
+            n0 = ops.group_acc_calls
+            ya = ops.conv2d(xs, was, bs, up2x=True, grad_group=grp)
+            yb = ops.conv2d(xs, wbs, None, up2x=True, grad_group=grp)
+            torch.autograd.backward([ya, yb], [gya, gyb])
+            torch.cuda.synchronize()
+            return (ya.detach(), yb.detach(), xs.grad, was.grad, wbs.grad, bs.grad), has_acc, ops.group_acc_calls - n0
+        finally:
+            ops.set_conv_backend(old)
+    (a, acc_a, n_a), (r, acc_r, n_r) = run(0), run(3)
+    assert acc_a and not acc_r, "backend 3 must switch the nine-product kernels off (%s / %s)" % (acc_a, acc_r)
+    assert n_a == 1 and n_r == 0
+    for name, u, v, tol in zip(("ya", "yb", "dx", "dwa", "dwb", "db"), a, r, (2e-6, 2e-6, 3e-6, 1e-5, 1e-5, 1e-5)):
+        assert_close(u, v, tol, "%s: nine-product Winograd form vs collapsed 16-tap form" % name)
+
+
 def test_gradient_group_sums_branch_gradients_in_place():
     """ASPP's five branches read one tensor: with ops.GradGroup their input gradients are summed in place (the row-chain
     kernel's accumulating form for the dilated branches) and autograd sees one gradient; same values as autograd's sum."""
@@ -1717,6 +1881,14 @@ def test_gradient_group_sums_branch_gradients_in_place():
     y1, y2 = ops.conv2d(xs, wts[0], dilation=2, grad_group=grp), ops.conv2d(xs, wts[1], dilation=6, grad_group=grp)
     with pytest.raises(RuntimeError, match="GradGroup"):
         torch.autograd.grad(y1.sum(), xs, retain_graph=True)
+    # the same rejection with leaf weights (their gradients run on the side lanes): the engine skips every end-of-pass callback
+    # queued behind the one that raises, so the group's callback joins the lanes itself and the queue flag cannot latch
+    with pytest.raises(RuntimeError, match="GradGroup"):
+        y1.sum().backward(retain_graph=True)
+    assert ops._join_queued_for is None, "the lane join of a rejected pass stayed queued"
+    (y1 + y2).sum().backward(retain_graph=True)                   # a following pass queues and runs its own join again
+    assert ops._join_queued_for is None
+    torch.cuda.synchronize()
     both = torch.autograd.grad((y1 + y2).sum(), xs)[0]          # the group was re-armed: a complete pass still works
     want = torch.autograd.grad((ops.conv2d(xs, wts[0], dilation=2) + ops.conv2d(xs, wts[1], dilation=6)).sum(), xs)[0]
     torch.cuda.synchronize()

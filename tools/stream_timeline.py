@@ -4,7 +4,10 @@
 then the longest intervals in which no MFMA kernel runs, with what runs instead.
 
     rocprofv3 --kernel-trace --output-format csv -d DIR -o t -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing
-    python tools/stream_timeline.py DIR/t_kernel_trace.csv [bin_ms] [steps_back]
+    python tools/stream_timeline.py DIR/t_kernel_trace.csv [bin_ms] [steps_back] [--json OUT.json]
+
+--json: also write {step_ms, launches_per_step, mfma_active_ms, mfma_active_fraction, exposed_ms, csrc_digest} for bench.py's
+`launches_per_step` / `mfma_active_fraction` fields (profiles/r04_stream_timeline.json).
 
 steps_back: which step to look at, counted from the end (1 = last).  A default `bench.py` run ends with three serialised
 steps (the roofline pass), so its last concurrent step is steps_back = 4.
@@ -42,7 +45,7 @@ def cover(L, a, b):
     return tot
 
 
-def main(path, binms=5.0, back=1):
+def main(path, binms=5.0, back=1, json_out=None):
     rows = list(csv.DictReader(open(path)))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Stream_Id"]) for r in rows)
     adam = [i for i, e in enumerate(ev) if "adam" in e[2].lower()]
@@ -91,7 +94,27 @@ def main(path, binms=5.0, back=1):
             if not ism(e[2]) and e[1] > a and e[0] < c:
                 exposed[short(e[2])] += min(e[1], c) - max(e[0], a)
     print("exposed non-MFMA kernel time (ms):", ", ".join("%s %.2f" % (k, v / 1e6) for k, v in exposed.most_common(14)))
+    if json_out:
+        import json
+        import os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        try:
+            import bench
+            digest = bench.csrc_digest()
+        except Exception:
+            digest = None
+        act = cover(mf, t0, t1)
+        json.dump(dict(step_ms=(t1 - t0) / 1e6, launches_per_step=len(win), mfma_active_ms=act / 1e6,
+                       mfma_active_fraction=act / (t1 - t0), exposed_ms=(t1 - t0 - act) / 1e6,
+                       exposed_by_kernel_ms={k: v / 1e6 for k, v in exposed.most_common(20)},
+                       csrc_digest=digest, trace=os.path.basename(path), steps_back=back), open(json_out, "w"), indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 5.0, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    av = sys.argv[1:]
+    jo = None
+    if "--json" in av:
+        i = av.index("--json")
+        jo = av[i + 1]
+        del av[i:i + 2]
+    main(av[0], float(av[1]) if len(av) > 1 else 5.0, int(av[2]) if len(av) > 2 else 1, jo)
