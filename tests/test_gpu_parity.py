@@ -1819,7 +1819,8 @@ def test_upsampled_winograd_forms_against_the_collapsed_forms(N, s, Cin, Cout):
         try:
             has_acc = bool(L.vqw_conv3x3_up2_dgrad_acc_supported(Cin, Cout, N, s, s))
             xs = x.clone(memory_format=torch.channels_last).requires_grad_(True)
-            was, wbs, bs = (t.clone(memory_format=torch.channels_last).requires_grad_(True) for t in (wa, wb, b))
+            was, wbs = (t.clone(memory_format=torch.channels_last).requires_grad_(True) for t in (wa, wb))
+            bs = b.clone().requires_grad_(True)
             grp = ops.GradGroup(2)             # two up-sampled convolutions of one input: the second adds in its epilogue
             n0 = ops.group_acc_calls
             ya = ops.conv2d(xs, was, bs, up2x=True, grad_group=grp)
