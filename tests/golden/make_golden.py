@@ -242,7 +242,43 @@ def ref_grads_fp64(enc, dec, image, noise, cfg):
     return out, grads
 
 
-def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, momentum=0.999, warm=False):
+def traj_record(enc, dec, out, flipped):
+    """What a later step is compared on: losses, ids and reconstructions (batch order undone), VQ buffers, BatchNorm statistics."""
+    un = (lambda t: t.flip(0)) if flipped else (lambda t: t)
+    r = {k: float(out[k]) for k in ("total", "commit", "cross", "dist", "reg", "recon")}
+    for k in ("ids_1", "ids_2", "recon_1", "recon_2"):
+        r[k] = un(out[k]).detach().clone()
+    for b in ("embed", "cluster_size", "embed_avg"):
+        r["vq." + b] = getattr(enc.vq, b).detach().clone()
+    r["bn"] = torch.cat([v.detach().reshape(-1).float() for k, v in dec.state_dict().items() if "running_" in k])
+    return r
+
+
+def ref_trajectory(enc, dec, cfg, lr, n_steps, batch, size, flip, threads):
+    """The same n_steps training steps on copies of the modules, evaluated in a mathematically equivalent way that changes
+    only the association order of fp32 reductions (batch order reversed and / or one thread): the reference's own spread."""
+    import copy
+    from oracle import vqwnet_ref as O
+    enc, dec = copy.deepcopy(enc), copy.deepcopy(dec)
+    eopt = torch.optim.Adam(filter(lambda p: p.requires_grad, enc.parameters()), lr=lr, betas=(0.5, 0.999), weight_decay=0)
+    dopt = torch.optim.Adam(filter(lambda p: p.requires_grad, dec.parameters()), lr=lr, betas=(0.5, 0.999), weight_decay=0)
+    torch.set_num_threads(threads)
+    recs = []
+    for s in range(n_steps):
+        image, noise = O.synthetic_slices(batch, size, 1234 + s)
+        if flip:
+            image, noise = image.flip(0), noise.flip(0)
+        out, _ = ref_first_step(enc, dec, eopt, dopt, image, noise, cfg)
+        recs.append(traj_record(enc, dec, out, flip))
+    torch.set_num_threads(8)
+    return recs
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, momentum=0.999, warm=False, lr=1e-4, spread=False):
     from oracle import vqwnet_ref as O
     d = {}
     torch.manual_seed(seed)
@@ -256,7 +292,7 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
     d["cfg/K"], d["cfg/size"], d["cfg/batch"] = np.array(K), np.array(size), np.array(batch)
     d["cfg/seed"], d["cfg/n_steps"], d["cfg/border"] = np.array(seed), np.array(n_steps), np.array(2)
     d["cfg/momentum"], d["cfg/margin"] = np.array(momentum), np.array(0.5)
-    d["cfg/lr"], d["cfg/betas"] = np.array(1e-4), np.array([0.5, 0.999])
+    d["cfg/lr"], d["cfg/betas"] = np.array(lr), np.array([0.5, 0.999])
     for pre, m in (("enc", enc), ("dec", dec)):
         for k, v in m.state_dict().items():
             d["init_sum/%s.%s" % (pre, k)] = checksum(v.float())
@@ -270,8 +306,10 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
             enc.vq.embed_avg.copy_(enc.vq.embed.t() * enc.vq.cluster_size[None, :])
         for b in ("embed", "cluster_size", "embed_avg"):
             d["warm/vq." + b] = npy(getattr(enc.vq, b)).copy()
-    eopt = torch.optim.Adam(filter(lambda p: p.requires_grad, enc.parameters()), lr=1e-4, betas=(0.5, 0.999), weight_decay=0)
-    dopt = torch.optim.Adam(filter(lambda p: p.requires_grad, dec.parameters()), lr=1e-4, betas=(0.5, 0.999), weight_decay=0)
+    eopt = torch.optim.Adam(filter(lambda p: p.requires_grad, enc.parameters()), lr=lr, betas=(0.5, 0.999), weight_decay=0)
+    dopt = torch.optim.Adam(filter(lambda p: p.requires_grad, dec.parameters()), lr=lr, betas=(0.5, 0.999), weight_decay=0)
+    # the reference's own multi-step spread (steps > 0 are compared against it, tests/test_oracle_golden.py::check_later_step)
+    trajs = [ref_trajectory(enc, dec, cfg, lr, n_steps, batch, size, f, t) for f, t in ((True, 8), (False, 1))] if spread else []
     # eval-mode forward + mask-guided reconstruction (run_recon.py:179-194) on the INITIAL state (so both sides hold bit-identical weights;
     # after an optimiser step two fp32 implementations drift, see tests/test_oracle_golden.py::check_step)
     enc.eval(); dec.eval()
@@ -304,9 +342,10 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
                 img_v, noi_v = (image.flip(0), noise.flip(0)) if flip else (image, noise)
                 variants.append(ref_first_step(copy.deepcopy(enc), copy.deepcopy(dec), None, None, img_v, noi_v, cfg)[1])
             torch.set_num_threads(8)
-        if s == 0:      # the views of ref_first_step, before the step moves the codebook
-            d["step0/gap_1"] = npy(ref_vq_gaps(enc, image))
-            d["step0/gap_2"] = npy(ref_vq_gaps(enc, torch.flip(image, dims=[3]) + noise))
+        # the views of ref_first_step, before the step moves the codebook (every step: later steps of a warm fixture are
+        # held to bit-equal ids where the reference's own gap is clear, like step 0)
+        d["step%d/gap_1" % s] = npy(ref_vq_gaps(enc, image))
+        d["step%d/gap_2" % s] = npy(ref_vq_gaps(enc, torch.flip(image, dims=[3]) + noise))
         out, grads = ref_first_step(enc, dec, eopt, dopt, image, noise, cfg)
         if s == 0:
             # principled gradient gate (tests/helpers.py::check_grads_vs_fp64): 256 sampled entries of the fp64 gradient and
@@ -336,6 +375,17 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
                 idx = sample_idx(v.numel())
                 d["step%d/after.%s.%s" % (s, pre, k)] = npy(v.reshape(-1)[idx])
                 d["step%d/after_sum.%s.%s" % (s, pre, k)] = checksum(v)
+        if trajs:
+            # distance of each equivalent evaluation of the reference from the run as launched, per compared quantity: the
+            # reference's own reproducibility after s optimiser steps (row i = variant i: batch reversed; one thread)
+            main = traj_record(enc, dec, out, False)
+            d["step%d/bn_running" % s] = npy(main["bn"])
+            for k in ("total", "commit", "cross", "dist", "reg", "recon"):
+                d["step%d/spread.%s" % (s, k)] = np.array([abs(t[s][k] - main[k]) / (abs(main[k]) + 1e-30) for t in trajs])
+            for k in ("recon_1", "recon_2", "vq.embed", "vq.cluster_size", "vq.embed_avg", "bn"):
+                d["step%d/spread.%s" % (s, k)] = np.array([rel(t[s][k], main[k]) for t in trajs])
+            for k in ("ids_1", "ids_2"):
+                d["step%d/spread.%s" % (s, k)] = np.array([float((t[s][k] != main[k]).double().mean()) for t in trajs])
     save(name, d)
 
 
@@ -530,7 +580,15 @@ if __name__ == "__main__":
         gen_step("step_small.npz", [16, 16, 32, 32, 32], [16, 32, 32, 32, 64], 6, 32, 2, 3, seed=7,
                  momentum=0.9)
         gen_step("step_rcfg32.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 32, 4, 1, seed=0)
-        gen_step("step_rcfg64_warm.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 64, 2, 1, seed=0, warm=True)
+        # three steps from a warm VQ state: the reference itself is stable there, so Adam's bias correction at t >= 2, the
+        # BatchNorm running-statistics momentum and the second / third EMA update are pinned by its own multi-step output
+        gen_step("step_rcfg64_warm.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 64, 2, 3, seed=0, warm=True, spread=True)
+        # the same three steps at lr = 1e-6.  Adam's first steps move every element by ~lr along sign(g), whatever |g|: elements
+        # whose gradient is rounding noise move by +-lr at random, and at lr = 1e-4 that alone changes the next step's
+        # reconstruction by 23 % between two equivalent evaluations of the reference (spread.* above).  At 1e-6 the reference
+        # reproduces itself over three steps, so this fixture holds later steps to real tolerances.
+        gen_step("step_rcfg64_warm_lr1e-6.npz", [16, 32, 64, 128, 256], [32, 64, 128, 256, 512], 10, 64, 2, 3, seed=0, warm=True,
+                 lr=1e-6, spread=True)
     if "cfg4" in what:
         # BASELINE config 4 scaled down spatially (enc_filters[0] = emb_dim = 256, dict_size 1024)
         gen_step("step_cfg4_32.npz", [256, 64, 128, 256, 512], [32, 64, 128, 256, 512], 1024, 32, 2, 1, seed=0,

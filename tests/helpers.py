@@ -148,7 +148,11 @@ def grad_gate(truth, variants, test, factor=2.0, what="", max_over_frac=0.10):
 
     def err(g, k):
         return float((g.detach().double().cpu() - truth[k]).norm() / truth[k].norm())
-    spread = {k: max(err(v[k], k) for v in variants) for k in live}
+    # a parameter's spread is the MEDIAN over the variants like check_grads_vs_fp64's (round 4; it was their maximum): the
+    # one-thread evaluations sit far further from fp64 than the run as launched, and a gate scaled by the worst of them would
+    # let an indexing error through.  SPREAD_STAT = "max" restores the looser gate for comparison.
+    stat = max if SPREAD_STAT == "max" else (lambda xs: float(np.median(list(xs))))
+    spread = {k: stat([err(v[k], k) for v in variants]) for k in live}
     floor = float(np.median(list(spread.values())))
     ratios, over = [], []
     for k in live:
@@ -156,9 +160,12 @@ def grad_gate(truth, variants, test, factor=2.0, what="", max_over_frac=0.10):
         ref_e = max(spread[k], floor)
         ratios.append(e / ref_e)
         msg = "%s grad %s: %.3e from the fp64 gradient, fp32 spread of the oracle %.3e (median %.3e)" % (what, k, e, spread[k], floor)
-        assert e <= 3 * factor * ref_e, msg
         if e > factor * ref_e:
-            over.append(msg)
-    assert len(over) <= max(2, int(max_over_frac * len(ratios))), "\n".join(over)
+            over.append((e / ref_e, msg))
+    print("%s gradient gate: median ratio %.2f, max %.2f, %d of %d parameters beyond %.0fx (allowed %d)" % (
+        what, float(np.median(ratios)), float(np.max(ratios)), len(over), len(ratios), factor, max(2, int(max_over_frac * len(ratios)))))
+    worst = max(over)[1] if over else ""
+    assert float(np.max(ratios)) <= 3 * factor, worst
+    assert len(over) <= max(2, int(max_over_frac * len(ratios))), "\n".join(m for _, m in sorted(over, reverse=True)[:8])
     assert float(np.median(ratios)) <= factor, "median error ratio %.2f" % float(np.median(ratios))
     return float(np.median(ratios)), float(np.max(ratios))

@@ -14,8 +14,10 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import assert_close, build_models, check_init, step_cfg, check_grads_vs_fp64, grad_gate, assert_ids_equal_where_clear
-from test_oracle_golden import check_step, GRAD_TOL, apply_warm_state
+from helpers import rel_err, assert_close, build_models, check_init, step_cfg, check_grads_vs_fp64, grad_gate, assert_ids_equal_where_clear
+from test_oracle_golden import check_step, check_later_step, GRAD_TOL, apply_warm_state
+
+EVAL_RECON_TOL = 5e-3          # eval / mask-guided reconstructions against the reference fixture (the oracle meets 1e-3)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -995,7 +997,7 @@ def _hip_trainer(g):
     return tr, cfg
 
 
-@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg32.npz", "step_cfg4_32.npz"])
+@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg64_warm_lr1e-6.npz", "step_rcfg32.npz", "step_cfg4_32.npz"])
 def test_first_step_golden(golden, name):
     from oracle import vqwnet_ref as O
     g = golden(name)
@@ -1006,14 +1008,16 @@ def test_first_step_golden(golden, name):
         q, _, ids = tr.encoder(g.t("eval/image", DEV))
         rec = tr.decoder(q)
         assert_ids_equal_where_clear(ids, g["eval/ids"], g["eval/gap"], "eval-mode ids (%s)" % name)
-        assert_close(rec, g["eval/recon"], 5e-3, "eval recon")
+        print(name, "HIP eval recon rel %.2e" % rel_err(rec, g["eval/recon"]))
+        assert_close(rec, g["eval/recon"], EVAL_RECON_TOL, "eval recon")
         from hipops import ops
         mask, ids0, scale = ops.mask_scale(g.t("recon/label_map", DEV))
         emb = ops.vq_lookup(ids0, tr.encoder.vq.embed, mask=mask, scale=scale)
         assert_close(emb, g["recon/embed"], 1e-6, "masked embed")
-        assert_close(tr.decoder(emb), g["recon/recon"], 5e-3, "mask-guided recon")
+        print(name, "HIP mask-guided recon rel %.2e" % rel_err(tr.decoder(emb), g["recon/recon"]))
+        assert_close(tr.decoder(emb), g["recon/recon"], EVAL_RECON_TOL, "mask-guided recon")
         from run_recon import reconstruct
-        assert_close(reconstruct(tr.encoder, tr.decoder, g.t("recon/label_map", DEV)), g["recon/recon"], 5e-3, "run_recon")
+        assert_close(reconstruct(tr.encoder, tr.decoder, g.t("recon/label_map", DEV)), g["recon/recon"], EVAL_RECON_TOL, "run_recon")
         e2 = tr.encoder.get_embed_from_ids(ids0)
         assert_close(e2 * mask[:, None].float() * scale, g["recon/embed"], 1e-6, "get_embed_from_ids")
     tr.encoder.train(); tr.decoder.train()
@@ -1029,6 +1033,13 @@ def test_first_step_golden(golden, name):
         rec["grads_dec"] = {k: p.grad for k, p in tr.decoder.named_parameters()}
         PE = dict(tr.encoder.state_dict())
         PD = dict(tr.decoder.state_dict())
+        if s > 0 and "step%d/spread.total" % s in g.files:
+            # later steps against the reference's own multi-step output, within its own multi-step spread (real tolerances on
+            # the lr = 1e-6 fixture, where the reference reproduces itself: test_oracle_golden.py::check_later_step)
+            print(name, "HIP, step", s, {k: "%.2e" % v for k, v in check_later_step(g, s, rec, PE, PD, lr, what="HIP").items()})
+            continue
+        if s == 0:
+            print(name, "HIP step 0 recon rel", ["%.2e" % rel_err(rec["recon_" + v], g["step0/recon_" + v]) for v in ("1", "2")])
         check_step(g, s, rec, PE, PD, lr, tight=(s == 0), tol=5e-4, grad_tol=max(gt, 5e-3), max_loose=ml + 2,
                    loose_bound=lb)
         if s == 0:
@@ -1075,6 +1086,7 @@ def test_step_vs_oracle_128(B, S):
     assert_close(sc["recon"], float(ref["recon"]), 5e-4, "recon")
     for v in ("1", "2"):
         assert_ids_equal_where_clear(out["ids_" + v], ref["ids_" + v], ref["gap_" + v], "ids_" + v)
+        print("B%d S%d HIP recon_%s rel %.2e" % (B, S, v, rel_err(out["recon_" + v], ref["recon_" + v])))
         assert_close(out["recon_" + v], ref["recon_" + v], 5e-3, "recon_" + v)
     # gradients: at most twice as far from the oracle's fp64 gradient as the oracle's own fp32 evaluations are (default
     # threads, one thread, batch reversed) - the gate of tests/helpers.py, here with the oracle as the reference
@@ -1104,7 +1116,7 @@ def test_step_vs_oracle_128(B, S):
     # gradient of every layer upstream of it (the whole down path, a third of the parameters) to ~2.5x the spread - the
     # per-parameter cap (6x the spread) and the median (2x) still hold
     print("B%d S%d HIP grad error / oracle fp32 spread (median, max):" % (B, S),
-          grad_gate(truth, variants, test, 2.0, "HIP", max_over_frac=0.10 if S >= 96 else 0.40))
+          grad_gate(truth, variants, test, 2.0, "HIP B%d S%d" % (B, S), max_over_frac=0.10 if S >= 96 else 0.20))
 
 
 def test_full_size_properties():

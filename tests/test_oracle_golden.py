@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import check_grads_vs_fp64, assert_close, build_models, check_init, step_cfg, sample_idx, checksum, assert_ids_equal_where_clear
+from helpers import rel_err, check_grads_vs_fp64, assert_close, build_models, check_init, step_cfg, sample_idx, checksum, assert_ids_equal_where_clear
 from oracle import vqwnet_ref as O
 
 TOL = 2e-5     # fp32, CPU vs CPU, different summation orders only
@@ -214,10 +214,83 @@ def check_step(g, s, out, PE, PD, lr, tight, tol=2e-4, grad_tol=2e-3, max_loose=
             assert abs(checksum(v.float())[1] - c[1]) <= 1e-4 * c[1] + 1e-6, "after-step " + k
 
 
+def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, state_floor=1e-4, what=""):
+    """Steps > 0 of a fixture that carries the reference's OWN multi-step spread (`step<s>/spread.*`: the same steps run by the
+    reference with the batch reversed and on one thread - mathematically identical, only fp32 association orders change).
+
+    Every compared quantity must be within max(F x that spread, floor) of the reference's run as launched; the floors are the
+    step-0 tolerances; F = 2 where the reference reproduces itself, 4 where it does not (two variants are a small sample of a
+    chaotic spread: the oracle - the same ATen kernels as the reference - lands 2.3 x the two-variant spread from it at step 2).  Where the reference reproduces itself (lr = 1e-6 fixture: spread <= 3e-5 on everything, ids identical)
+    this is a real multi-step pin: losses to `loss_floor`, ids bit-equal wherever the reference's gap is clear, VQ buffers
+    after the 2nd / 3rd EMA update and BatchNorm running statistics after 2 / 3 momentum updates to 1e-4, parameters after
+    Adam's t = 2, 3 updates elementwise.  Where it does not (lr = 1e-4: Adam moves elements whose gradient is rounding noise
+    by +-lr at random and the reference's own reconstructions differ by 16 % after one step, 66 % after two) the bound is
+    what the reference itself supports.  Returns the measured errors (printed by the callers)."""
+    def val(k):
+        return float(out[k].detach()) if torch.is_tensor(out[k]) else float(out[k])
+
+    def sp(*keys):
+        return max(float(np.max(g["step%d/spread.%s" % (s, k)])) for k in keys)
+    rep = {}
+    rsp = sp("recon_1", "recon_2")
+    F = 2.0 if rsp < 1e-3 else 4.0
+    for k in ("total", "commit", "cross", "dist", "reg", "recon"):
+        ref = float(g["step%d/%s" % (s, k)])
+        rep[k] = abs(val(k) - ref) / (abs(ref) + 1e-30)
+        bound = max(F * sp(k), loss_floor)
+        assert rep[k] <= bound, "%s step %d %s: rel %.3e > bound %.3e (reference spread %.3e)" % (what, s, k, rep[k], bound, sp(k))
+    ids_spread = sp("ids_1", "ids_2")
+    for v in ("1", "2"):
+        ids = out["ids_" + v].cpu().numpy()
+        ref = g["step%d/ids_%s" % (s, v)]
+        rep["ids_" + v] = float(np.mean(ids != ref))
+        if ids_spread == 0.0:       # the reference reproduces its ids: bit-equal wherever its top-1 / top-2 gap is clear
+            assert_ids_equal_where_clear(ids, ref, g["step%d/gap_%s" % (s, v)], "%s ids_%s step %d" % (what, v, s))
+        else:
+            assert rep["ids_" + v] <= F * ids_spread + 1e-3, "%s ids_%s step %d: %.4f differ (reference spread %.4f)" % (
+                what, v, s, rep["ids_" + v], ids_spread)
+    for v in ("1", "2"):
+        rep["recon_" + v] = rel_err(out["recon_" + v], g["step%d/recon_%s" % (s, v)])
+        bound = max(F * rsp, recon_floor)
+        assert rep["recon_" + v] <= bound, "%s recon_%s step %d: rel %.3e > %.3e" % (what, v, s, rep["recon_" + v], bound)
+    for key in ("vq.embed", "vq.cluster_size", "vq.embed_avg"):
+        v = PE[key].detach().cpu().float()
+        c = g["step%d/after_sum.enc.%s" % (s, key)]
+        idx = sample_idx(v.numel())
+        rep[key] = max(rel_err(v.reshape(-1)[idx], g["step%d/after.enc.%s" % (s, key)]), abs(checksum(v)[1] - c[1]) / c[1])
+        bound = max(F * sp(key), state_floor)
+        assert rep[key] <= bound, "%s %s after step %d: rel %.3e > %.3e" % (what, key, s, rep[key], bound)
+    bn = torch.cat([v.detach().reshape(-1).float().cpu() for k, v in PD.items() if "running_" in k])
+    rep["bn"] = rel_err(bn, g["step%d/bn_running" % s])
+    assert rep["bn"] <= max(F * sp("bn"), state_floor), "%s BatchNorm running statistics after step %d: rel %.3e (spread %.3e)" % (
+        what, s, rep["bn"], sp("bn"))
+    if rsp < 1e-3:
+        # the reference's trajectory is reproducible: parameters after Adam's step t = s + 1, elementwise on the sampled entries.
+        # An update is ~lr whatever |g|; elements whose gradient is rounding noise move at random, so the statistic is the
+        # fraction of sampled entries within 0.1 lr, over parameters with a real gradient
+        gmax = max(float(g[k]) for k in g.files if k.startswith("step%d/gnorm." % s))
+        fracs = []
+        for pre, P in (("enc", PE), ("dec", PD)):
+            for k, p in P.items():
+                key = "step%d/gnorm.%s.%s" % (s, pre, k)
+                if key not in g.files or float(g[key]) < 1e-6 * gmax:
+                    continue
+                pv = p.detach().cpu().float().reshape(-1)
+                d = (pv[sample_idx(pv.numel())] - g.t("step%d/after.%s.%s" % (s, pre, k))).abs()
+                fracs.append((float((d < 0.1 * lr).float().mean()), float((d < 0.5 * lr).float().mean()), pre + "." + k))
+        rep["params_within_0.1lr_median"] = float(np.median([f[0] for f in fracs]))
+        rep["params_within_0.1lr_min"] = min(fracs)[0]
+        rep["params_within_0.5lr_min"] = min(f[1] for f in fracs)
+        assert rep["params_within_0.1lr_median"] >= 0.9, (what, s, rep)
+        assert rep["params_within_0.5lr_min"] >= 0.75, (what, s, rep, sorted(fracs, key=lambda f: f[1])[:3])
+    return rep
+
+
 GRAD_TOL["step_cfg4_32.npz"] = (2e-3, 2, 0.25)      # BASELINE config 4 scaled down (K = 1024, D = 256), warm VQ state
+GRAD_TOL["step_rcfg64_warm_lr1e-6.npz"] = GRAD_TOL["step_rcfg64_warm.npz"]
 
 
-@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg32.npz", "step_cfg4_32.npz"])
+@pytest.mark.parametrize("name", ["step_small.npz", "step_rcfg64_warm.npz", "step_rcfg64_warm_lr1e-6.npz", "step_rcfg32.npz", "step_cfg4_32.npz"])
 def test_first_step(golden, name):
     """Full first training step(s): losses, ids, recon, sampled grads, params/buffers after Adam."""
     g = golden(name)
@@ -242,6 +315,9 @@ def test_first_step(golden, name):
     lr = float(g["cfg/lr"])
     for s in range(int(g["cfg/n_steps"])):
         out = tr.step(g.t("step%d/image" % s), g.t("step%d/noise" % s))
+        if s > 0 and "step%d/spread.total" % s in g.files:
+            print(name, "oracle, step", s, {k: "%.2e" % v for k, v in check_later_step(g, s, out, PE, PD, lr, loss_floor=2e-4, recon_floor=1e-3, what="oracle").items()})
+            continue
         check_step(g, s, out, PE, PD, lr, tight=(s == 0), grad_tol=gt, max_loose=ml, loose_bound=lb)
         if s == 0:      # the oracle is one more fp32 implementation: at most 2x the reference's own distance from fp64
             grads = {"enc." + k: v for k, v in out["grads_enc"].items()}
