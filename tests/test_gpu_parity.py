@@ -5,7 +5,9 @@ Tolerances (relative L2 unless stated): fp32 everywhere.
   single kernels vs torch CPU ............ 2e-5
   block forward / backward vs golden ..... 1e-4 / 1e-3
   VQ ids ................................. bit-exact wherever the top-1/top-2 score gap > 1e-4*(1+|gap|)
-  training step (step 0) ................. losses 5e-4, recon 5e-3, gradients per fixture (GRAD_TOL)
+  training step (step 0) ................. losses 5e-4, recon 4e-4 (eval forward 3e-5), gradients per fixture (GRAD_TOL) + fp64 gate
+  training steps 1, 2 .................... within the reference's own multi-step spread (check_later_step; lr = 1e-6 fixture: losses 5e-4,
+                                           ids bit-exact where clear, VQ / BatchNorm state 1e-4, parameters elementwise)
 """
 import os
 
@@ -17,7 +19,11 @@ import torch.nn.functional as F
 from helpers import rel_err, assert_close, build_models, check_init, step_cfg, check_grads_vs_fp64, grad_gate, assert_ids_equal_where_clear
 from test_oracle_golden import check_step, check_later_step, GRAD_TOL, apply_warm_state
 
-EVAL_RECON_TOL = 5e-3          # eval / mask-guided reconstructions against the reference fixture (the oracle meets 1e-3)
+# Reconstructions against the reference fixtures (round 4: the measured errors are printed by the tests; the bounds are ~2.5x
+# the largest of them, down from 5e-3).  Measured: eval / mask-guided forward 5e-6 ... 1.2e-5 on all five fixtures; training
+# step 0: 5e-6 (small), 1.1e-5 (64^2 warm), 3.2e-5 (config 4), 1.5e-4 (32^2 cold start: cluster_size = 0).
+EVAL_RECON_TOL = 3e-5
+STEP0_RECON_TOL = 4e-4
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -1041,7 +1047,7 @@ def test_first_step_golden(golden, name):
         if s == 0:
             print(name, "HIP step 0 recon rel", ["%.2e" % rel_err(rec["recon_" + v], g["step0/recon_" + v]) for v in ("1", "2")])
         check_step(g, s, rec, PE, PD, lr, tight=(s == 0), tol=5e-4, grad_tol=max(gt, 5e-3), max_loose=ml + 2,
-                   loose_bound=lb)
+                   loose_bound=lb, recon_tol=STEP0_RECON_TOL)
         if s == 0:
             # the principled gate: at most twice as far from the reference's fp64 gradient as the reference's own fp32
             # evaluations are (tests/helpers.py::check_grads_vs_fp64)
@@ -1087,7 +1093,7 @@ def test_step_vs_oracle_128(B, S):
     for v in ("1", "2"):
         assert_ids_equal_where_clear(out["ids_" + v], ref["ids_" + v], ref["gap_" + v], "ids_" + v)
         print("B%d S%d HIP recon_%s rel %.2e" % (B, S, v, rel_err(out["recon_" + v], ref["recon_" + v])))
-        assert_close(out["recon_" + v], ref["recon_" + v], 5e-3, "recon_" + v)
+        assert_close(out["recon_" + v], ref["recon_" + v], 5e-5, "recon_" + v)      # measured 1.6e-5 ... 1.9e-5
     # gradients: at most twice as far from the oracle's fp64 gradient as the oracle's own fp32 evaluations are (default
     # threads, one thread, batch reversed) - the gate of tests/helpers.py, here with the oracle as the reference
     def oracle_grads(dtype, threads, flip):
@@ -1112,11 +1118,15 @@ def test_step_vs_oracle_128(B, S):
                      oracle_grads(torch.float32, 3, False), oracle_grads(torch.float32, 5, True)]
     test = {"enc." + k: p.grad for k, p in tr.encoder.named_parameters()}
     test.update({"dec." + k: p.grad for k, p in tr.decoder.named_parameters()})
-    # 80x80 has 5x5 planes at the bottom: ONE ReLU / max-pool decision there that differs from the oracle's moves the
-    # gradient of every layer upstream of it (the whole down path, a third of the parameters) to ~2.5x the spread - the
-    # per-parameter cap (6x the spread) and the median (2x) still hold
+    # Round 4: a parameter's spread is the MEDIAN over the oracle's fp32 evaluations (it was their maximum, which the
+    # one-thread run dominates at 5-20x the others).  Against that far tighter scale the HIP gradients sit at a median ratio of
+    # 1.1 / 1.6 / 1.6 (128 / 96 / 80) with the largest 2.2 / 2.5 / 3.9 - the per-parameter cap (6) and the median (2) hold with
+    # room; what does not fit the old 10 % is the COUNT of parameters between 2x and 4x: 15 / 10 / 33 of 105.  They come in one
+    # group: 80x80 has 5x5 planes at the bottom, and ONE ReLU / max-pool decision there that differs from the oracle's moves
+    # the gradient of every layer upstream of it (the whole down path, a third of the parameters) together.  Allowed: 20 % at
+    # 128 / 96, 35 % at 80 (the count is printed).
     print("B%d S%d HIP grad error / oracle fp32 spread (median, max):" % (B, S),
-          grad_gate(truth, variants, test, 2.0, "HIP B%d S%d" % (B, S), max_over_frac=0.10 if S >= 96 else 0.20))
+          grad_gate(truth, variants, test, 2.0, "HIP B%d S%d" % (B, S), max_over_frac=0.20 if S >= 96 else 0.35))
 
 
 def test_full_size_properties():

@@ -152,7 +152,7 @@ def apply_warm_state(g, sd_enc):
             sd_enc["vq." + b].copy_(g.t("warm/vq." + b))
 
 
-def check_step(g, s, out, PE, PD, lr, tight, tol=2e-4, grad_tol=2e-3, max_loose=2, loose_bound=0.25):
+def check_step(g, s, out, PE, PD, lr, tight, tol=2e-4, grad_tol=2e-3, max_loose=2, loose_bound=0.25, recon_tol=None):
     """Compare one training step with the golden record.
 
     Step 0 is the tight gate.  Later steps are inherently chaotic in the REFERENCE itself: (1) cluster_size
@@ -178,7 +178,7 @@ def check_step(g, s, out, PE, PD, lr, tight, tol=2e-4, grad_tol=2e-3, max_loose=
             assert_ids_equal_where_clear(ids, ref, g["step%d/gap_%s" % (s, v)], "ids_%s step %d" % (v, s))
         else:
             assert np.mean(ids == ref) > 0.999, "ids_%s agreement %.5f" % (v, np.mean(ids == ref))
-        assert_close(out["recon_" + v], g["step%d/recon_%s" % (s, v)], 10 * tol, "recon_" + v)
+        assert_close(out["recon_" + v], g["step%d/recon_%s" % (s, v)], 10 * tol if recon_tol is None else recon_tol, "recon_" + v)
     gmax = max(float(g[k]) for k in g.files if k.startswith("step%d/gnorm." % s))
     n_checked, loose = 0, []
     for pre, grads, P in (("enc", out["grads_enc"], PE), ("dec", out["grads_dec"], PD)):
@@ -218,54 +218,55 @@ def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, s
     """Steps > 0 of a fixture that carries the reference's OWN multi-step spread (`step<s>/spread.*`: the same steps run by the
     reference with the batch reversed and on one thread - mathematically identical, only fp32 association orders change).
 
-    Every compared quantity must be within max(F x that spread, floor) of the reference's run as launched; the floors are the
-    step-0 tolerances; F = 2 where the reference reproduces itself, 4 where it does not (two variants are a small sample of a
-    chaotic spread: the oracle - the same ATen kernels as the reference - lands 2.3 x the two-variant spread from it at step 2).  Where the reference reproduces itself (lr = 1e-6 fixture: spread <= 3e-5 on everything, ids identical)
-    this is a real multi-step pin: losses to `loss_floor`, ids bit-equal wherever the reference's gap is clear, VQ buffers
-    after the 2nd / 3rd EMA update and BatchNorm running statistics after 2 / 3 momentum updates to 1e-4, parameters after
-    Adam's t = 2, 3 updates elementwise.  Where it does not (lr = 1e-4: Adam moves elements whose gradient is rounding noise
-    by +-lr at random and the reference's own reconstructions differ by 16 % after one step, 66 % after two) the bound is
-    what the reference itself supports.  Returns the measured errors (printed by the callers)."""
+    Every compared quantity must be within max(F x that spread, floor) of the reference's run as launched.
+    * Where the reference reproduces itself (lr = 1e-6 fixture: spread <= 3e-5 on everything, ids identical) F = 2, the floors
+      are the step-0 tolerances and this is a real multi-step pin: losses to `loss_floor`, ids bit-equal wherever the
+      reference's gap is clear, VQ buffers after the 2nd / 3rd EMA update and BatchNorm running statistics after 2 / 3 momentum
+      updates to 1e-4, parameters after Adam's t = 2, 3 updates elementwise.
+    * Where it does not (lr = 1e-4: Adam moves elements whose gradient is rounding noise by +-lr at random, and the
+      reference's own reconstructions differ by 16 % after one step and 66 % after two) the bound is what the reference itself
+      supports: F = 4 (two variants sample a chaotic spread thinly: the oracle - the same ATen kernels as the reference -
+      lands 2.3 x the two-variant spread from it at step 2) and floors ten times the step-0 tolerances.
+    Returns the measured errors (printed by the callers)."""
     def val(k):
         return float(out[k].detach()) if torch.is_tensor(out[k]) else float(out[k])
 
     def sp(*keys):
         return max(float(np.max(g["step%d/spread.%s" % (s, k)])) for k in keys)
-    rep = {}
+    rep, bad = {}, []
     rsp = sp("recon_1", "recon_2")
-    F = 2.0 if rsp < 1e-3 else 4.0
+    stable = rsp < 1e-3
+    F = 2.0 if stable else 4.0
+    if not stable:
+        loss_floor, recon_floor, state_floor = 10 * loss_floor, 10 * recon_floor, 10 * state_floor
+
+    def hold(key, err, bound, note=""):
+        rep[key] = err
+        if not err <= bound:
+            bad.append("%s step %d %s: %.3e > bound %.3e %s" % (what, s, key, err, bound, note))
     for k in ("total", "commit", "cross", "dist", "reg", "recon"):
         ref = float(g["step%d/%s" % (s, k)])
-        rep[k] = abs(val(k) - ref) / (abs(ref) + 1e-30)
-        bound = max(F * sp(k), loss_floor)
-        assert rep[k] <= bound, "%s step %d %s: rel %.3e > bound %.3e (reference spread %.3e)" % (what, s, k, rep[k], bound, sp(k))
+        hold(k, abs(val(k) - ref) / (abs(ref) + 1e-30), max(F * sp(k), loss_floor), "(reference spread %.3e)" % sp(k))
     ids_spread = sp("ids_1", "ids_2")
     for v in ("1", "2"):
         ids = out["ids_" + v].cpu().numpy()
         ref = g["step%d/ids_%s" % (s, v)]
-        rep["ids_" + v] = float(np.mean(ids != ref))
         if ids_spread == 0.0:       # the reference reproduces its ids: bit-equal wherever its top-1 / top-2 gap is clear
+            rep["ids_" + v] = float(np.mean(ids != ref))
             assert_ids_equal_where_clear(ids, ref, g["step%d/gap_%s" % (s, v)], "%s ids_%s step %d" % (what, v, s))
-        else:
-            # (chaotic regime: one flipped Adam sign in the encoder moves a handful of pixels across a code boundary)
-            assert rep["ids_" + v] <= F * ids_spread + 5e-3, "%s ids_%s step %d: %.4f differ (reference spread %.4f)" % (
-                what, v, s, rep["ids_" + v], ids_spread)
+        else:                       # (one flipped Adam sign in the encoder moves a handful of pixels across a code boundary)
+            hold("ids_" + v, float(np.mean(ids != ref)), F * ids_spread + 5e-3, "(fraction of differing ids, reference spread %.4f)" % ids_spread)
     for v in ("1", "2"):
-        rep["recon_" + v] = rel_err(out["recon_" + v], g["step%d/recon_%s" % (s, v)])
-        bound = max(F * rsp, recon_floor)
-        assert rep["recon_" + v] <= bound, "%s recon_%s step %d: rel %.3e > %.3e" % (what, v, s, rep["recon_" + v], bound)
+        hold("recon_" + v, rel_err(out["recon_" + v], g["step%d/recon_%s" % (s, v)]), max(F * rsp, recon_floor))
     for key in ("vq.embed", "vq.cluster_size", "vq.embed_avg"):
         v = PE[key].detach().cpu().float()
         c = g["step%d/after_sum.enc.%s" % (s, key)]
         idx = sample_idx(v.numel())
-        rep[key] = max(rel_err(v.reshape(-1)[idx], g["step%d/after.enc.%s" % (s, key)]), abs(checksum(v)[1] - c[1]) / c[1])
-        bound = max(F * sp(key), state_floor)
-        assert rep[key] <= bound, "%s %s after step %d: rel %.3e > %.3e" % (what, key, s, rep[key], bound)
+        hold(key, max(rel_err(v.reshape(-1)[idx], g["step%d/after.enc.%s" % (s, key)]), abs(checksum(v)[1] - c[1]) / c[1]),
+             max(F * sp(key), state_floor))
     bn = torch.cat([v.detach().reshape(-1).float().cpu() for k, v in PD.items() if "running_" in k])
-    rep["bn"] = rel_err(bn, g["step%d/bn_running" % s])
-    assert rep["bn"] <= max(F * sp("bn"), state_floor), "%s BatchNorm running statistics after step %d: rel %.3e (spread %.3e)" % (
-        what, s, rep["bn"], sp("bn"))
-    if rsp < 1e-3:
+    hold("bn", rel_err(bn, g["step%d/bn_running" % s]), max(F * sp("bn"), state_floor), "(BatchNorm running statistics, spread %.3e)" % sp("bn"))
+    if stable:
         # the reference's trajectory is reproducible: parameters after Adam's step t = s + 1, elementwise on the sampled entries.
         # An update is ~lr whatever |g|; elements whose gradient is rounding noise move at random, so the statistic is the
         # fraction of sampled entries within 0.1 lr, over parameters with a real gradient
@@ -279,11 +280,10 @@ def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, s
                 pv = p.detach().cpu().float().reshape(-1)
                 d = (pv[sample_idx(pv.numel())] - g.t("step%d/after.%s.%s" % (s, pre, k))).abs()
                 fracs.append((float((d < 0.1 * lr).float().mean()), float((d < 0.5 * lr).float().mean()), pre + "." + k))
-        rep["params_within_0.1lr_median"] = float(np.median([f[0] for f in fracs]))
         rep["params_within_0.1lr_min"] = min(fracs)[0]
-        rep["params_within_0.5lr_min"] = min(f[1] for f in fracs)
-        assert rep["params_within_0.1lr_median"] >= 0.9, (what, s, rep)
-        assert rep["params_within_0.5lr_min"] >= 0.75, (what, s, rep, sorted(fracs, key=lambda f: f[1])[:3])
+        hold("params_within_0.1lr_median (1 - x)", 1.0 - float(np.median([f[0] for f in fracs])), 0.1)
+        hold("params_within_0.5lr_min (1 - x)", 1.0 - min(f[1] for f in fracs), 0.25, str(sorted(fracs, key=lambda f: f[1])[:3]))
+    assert not bad, "\n".join(bad + [str({k: "%.2e" % v for k, v in rep.items()})])
     return rep
 
 
