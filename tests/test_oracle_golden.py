@@ -265,7 +265,8 @@ def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, s
         hold(key, max(rel_err(v.reshape(-1)[idx], g["step%d/after.enc.%s" % (s, key)]), abs(checksum(v)[1] - c[1]) / c[1]),
              max(F * sp(key), state_floor))
     bn = torch.cat([v.detach().reshape(-1).float().cpu() for k, v in PD.items() if "running_" in k])
-    hold("bn", rel_err(bn, g["step%d/bn_running" % s]), max(F * sp("bn"), state_floor), "(BatchNorm running statistics, spread %.3e)" % sp("bn"))
+    # (chaotic regime: the running statistics follow the decoder's activations, which differ by tens of per cent: floor 5e-3)
+    hold("bn", rel_err(bn, g["step%d/bn_running" % s]), max(F * sp("bn"), state_floor if stable else 5e-3), "(BatchNorm running statistics, spread %.3e)" % sp("bn"))
     if stable:
         # the reference's trajectory is reproducible: parameters after Adam's step t = s + 1, elementwise on the sampled entries.
         # An update is ~lr whatever |g|; elements whose gradient is rounding noise move at random, so the statistic is the
