@@ -356,6 +356,21 @@ int vqw_window_mse_fwd(const float* a, const float* b, float* loss, void* ws, si
 int vqw_window_mse_bwd(const float* a, const float* b, const float* gloss, float* ga, long n, float alpha, float beta,
                        float lo, float hi, void* stream);
 
+/* ---- deferred split-K folds of the weight gradients (ABI 8).  Every conv weight-gradient entry point ends in one or two
+ * short fold launches (dW and dbias slabs -> the gradient).  With vqw_fold_defer(1) those folds are only recorded - the
+ * caller must then keep the `ws` buffers of the weight-gradient calls alive - and vqw_fold_flush_host() folds everything
+ * recorded so far in ONE launch on `stream` (which must be ordered after the recorded calls' streams).  Two recorded folds
+ * into the same output (overwrite, then accumulate: the two views of a training step) are summed in recording order; a
+ * third one is an error (flush first).  table_host: pinned host buffer, table_dev: device buffer, both of at least
+ * vqw_fold_table_bytes() bytes, both untouched by the caller until the launch has run.  Process-wide state (backward nodes
+ * and end-of-pass callbacks run on different host threads).  Replaces nothing upstream: plumbing behind F.conv2d's weight
+ * gradient (see the convolution section). */
+int vqw_fold_defer(int on);              /* returns the previous setting */
+int vqw_fold_pending(void);              /* number of recorded, unflushed fold records */
+size_t vqw_fold_table_bytes(void);
+int vqw_fold_discard(void);              /* drop the recorded folds (after an aborted backward pass); returns how many */
+int vqw_fold_flush_host(void* table_host, void* table_dev, size_t table_bytes, void* stream);
+
 /* ---- optimiser: torch.optim.Adam as built in trainers/base.py:165-175 */
 int vqw_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,

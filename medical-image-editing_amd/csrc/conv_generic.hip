@@ -3,6 +3,7 @@
 // MFMA implicit-GEMM kernels (conv_mfma.hip) do not take (Cin or Cout not a multiple of 16, e.g. the 1-channel
 // stem and the 32->1 head), and the on-device cross-check for them in the tests.
 #include "common.h"
+#include <string.h>
 #include "conv_common.h"
 #include "../../include/vqwnet_hip.h"
 
@@ -166,7 +167,174 @@ __global__ void __launch_bounds__(256) k_reduce_rows_few(const float4* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deferred slab folds.  Every weight-gradient kernel leaves split-K slabs and ends in reduce_rows (two short launches per
+// layer: dW and dbias, ~250 per training step, each a dependent launch behind its MFMA kernel on a weight-gradient lane).
+// With deferral on, reduce_rows only RECORDS the job; vqw_fold_flush_host() then folds everything recorded since the last
+// flush in ONE launch (k_fold_multi).  Jobs that target the same output (the two views of a step: overwrite, then
+// accumulate) are merged into one record whose segments are summed in recording order, so the result is what the separate
+// launches would have produced in that order - fixed, bit-reproducible.  The slab buffers must stay alive until the flush
+// (the Python side keeps them).  Process-wide state behind a mutex: autograd runs backward nodes on its own device thread
+// and the end-of-pass callback that flushes on the thread that called backward().
+#include <mutex>
+#include <vector>
+namespace {
+struct FoldRec {            // device-visible record, 64 bytes
+    const float* p0; const float* p1; float* out; long n;
+    int rows0, rows1, acc, vec;
+    long blk0;               // first workgroup of this record in the launch
+    long pad;
+};
+std::mutex g_fold_mu;
+std::vector<FoldRec> g_fold_jobs;
+bool g_fold_defer = false;
+constexpr int FOLD_COLS = 256;       // floats per workgroup
+
+// one workgroup = FOLD_COLS consecutive output elements of one record: lane = 4 columns, 4 row groups walk the slabs
+// (rows g, g + 4, ...), fixed-order fold of the groups through LDS; segment 1 (the second view) after segment 0
+__global__ void __launch_bounds__(256) k_fold_multi(const FoldRec* __restrict__ recs, int nrec) {
+    __shared__ float4 sm[2][4][64];
+    int lo = 0, hi = nrec - 1;
+    while (lo < hi) {                          // last record whose first workgroup is <= blockIdx.x
+        int mid = (lo + hi + 1) >> 1;
+        if (recs[mid].blk0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const FoldRec r = recs[lo];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long c0 = ((long)blockIdx.x - r.blk0) * FOLD_COLS + lane * 4;
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg) {
+        const float* p = seg ? r.p1 : r.p0;
+        const int rows = seg ? r.rows1 : r.rows0;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (p && c0 < r.n) {
+            if (r.vec) {
+                int q = g;
+                for (; q + 4 < rows; q += 8) {
+                    float4 u = *(const float4*)(p + (long)q * r.n + c0), v = *(const float4*)(p + (long)(q + 4) * r.n + c0);
+                    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+                }
+                if (q < rows) {
+                    float4 u = *(const float4*)(p + (long)q * r.n + c0);
+                    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+                }
+            } else {
+                for (int q = g; q < rows; q += 4) {
+                    const float* s = p + (long)q * r.n + c0;
+                    a.x += s[0];
+                    if (c0 + 1 < r.n) a.y += s[1];
+                    if (c0 + 2 < r.n) a.z += s[2];
+                    if (c0 + 3 < r.n) a.w += s[3];
+                }
+            }
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        sm[seg][g][lane] = a;
+    }
+    __syncthreads();
+    if (g == 0 && c0 < r.n) {
+        float4 t[2];
+#pragma unroll
+        for (int seg = 0; seg < 2; ++seg) {
+            float4 u0 = sm[seg][0][lane], u1 = sm[seg][1][lane], u2 = sm[seg][2][lane], u3 = sm[seg][3][lane];
+            t[seg] = make_float4((u0.x + u1.x) + (u2.x + u3.x), (u0.y + u1.y) + (u2.y + u3.y), (u0.z + u1.z) + (u2.z + u3.z),
+                                 (u0.w + u1.w) + (u2.w + u3.w));
+        }
+        float* o = r.out + c0;
+        float4 v = t[0];
+        if (r.acc) {
+            if (r.vec) { float4 w = *(const float4*)o; v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+            else {
+                v.x += o[0];
+                if (c0 + 1 < r.n) v.y += o[1];
+                if (c0 + 2 < r.n) v.z += o[2];
+                if (c0 + 3 < r.n) v.w += o[3];
+            }
+        }
+        if (r.p1) { v.x += t[1].x; v.y += t[1].y; v.z += t[1].z; v.w += t[1].w; }
+        if (r.vec) *(float4*)o = v;
+        else {
+            o[0] = v.x;
+            if (c0 + 1 < r.n) o[1] = v.y;
+            if (c0 + 2 < r.n) o[2] = v.z;
+            if (c0 + 3 < r.n) o[3] = v.w;
+        }
+    }
+}
+
+int reduce_rows_now(const float* part, float* out, long n, int rows, hipStream_t st, int acc);
+}  // namespace
+
+extern "C" int vqw_fold_defer(int on) {
+    std::lock_guard<std::mutex> lk(g_fold_mu);
+    int old = g_fold_defer ? 1 : 0;
+    g_fold_defer = on != 0;
+    return old;
+}
+extern "C" int vqw_fold_pending(void) {
+    std::lock_guard<std::mutex> lk(g_fold_mu);
+    return (int)g_fold_jobs.size();
+}
+extern "C" size_t vqw_fold_table_bytes(void) {
+    std::lock_guard<std::mutex> lk(g_fold_mu);
+    return g_fold_jobs.size() * sizeof(FoldRec) + 64;
+}
+extern "C" int vqw_fold_discard(void) {
+    std::lock_guard<std::mutex> lk(g_fold_mu);
+    int n = (int)g_fold_jobs.size();
+    g_fold_jobs.clear();
+    return n;
+}
+extern "C" int vqw_fold_flush_host(void* table_host, void* table_dev, size_t table_bytes, void* stream) {
+    std::lock_guard<std::mutex> lk(g_fold_mu);
+    if (g_fold_jobs.empty()) return VQW_OK;
+    const size_t need = g_fold_jobs.size() * sizeof(FoldRec);
+    VQW_CHECK(table_host && table_dev && table_bytes >= need, "vqw_fold_flush_host: table buffers too small (%zu < %zu)", table_bytes, need);
+    long blk = 0;
+    for (auto& r : g_fold_jobs) {
+        r.blk0 = blk;
+        blk += (r.n + FOLD_COLS - 1) / FOLD_COLS;
+    }
+    memcpy(table_host, g_fold_jobs.data(), need);
+    const int nrec = (int)g_fold_jobs.size();
+    g_fold_jobs.clear();
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, st) != hipSuccess) {
+        vqw_set_error("vqw_fold_flush_host: table upload failed");
+        return VQW_ERR_HIP;
+    }
+    VQW_CHECK(blk < (1L << 31), "vqw_fold_flush_host: too many workgroups");
+    k_fold_multi<<<(unsigned)blk, 256, 0, st>>>((const FoldRec*)table_dev, nrec);
+    VQW_LAUNCH_CHECK("fold_multi");
+    return VQW_OK;
+}
+
 int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st, int acc) {
+    {
+        std::lock_guard<std::mutex> lk(g_fold_mu);
+        if (g_fold_defer) {
+            const int vec = ((n & 3) == 0 && ((((uintptr_t)part | (uintptr_t)out) & 15) == 0)) ? 1 : 0;
+            for (auto& r : g_fold_jobs) {
+                if (r.out == out) {
+                    // a second job for the same output (the other view of the step): summed after the first, in one record
+                    if (r.n == n && r.p1 == nullptr && acc) {
+                        r.p1 = part; r.rows1 = rows; r.vec = r.vec && vec;
+                        return VQW_OK;
+                    }
+                    vqw_set_error("reduce_rows: more than two deferred folds into one output (flush first)");
+                    return VQW_ERR_ARG;
+                }
+            }
+            g_fold_jobs.push_back(FoldRec{part, nullptr, out, n, rows, 0, acc, vec, 0, 0});
+            return VQW_OK;
+        }
+    }
+    return reduce_rows_now(part, out, n, rows, st, acc);
+}
+
+namespace {
+int reduce_rows_now(const float* part, float* out, long n, int rows, hipStream_t st, int acc) {
     if (rows <= 48 && (n & 3) == 0 && n >= 4096 && ((((uintptr_t)part | (uintptr_t)out) & 15) == 0)) {
         k_reduce_rows_few<<<stream_grid(n / 4, 256), 256, 0, st>>>((const float4*)part, (float4*)out, n / 4, rows, acc);
         VQW_LAUNCH_CHECK("reduce_rows_few");
@@ -176,6 +344,7 @@ int reduce_rows(const float* part, float* out, long n, int rows, hipStream_t st,
     VQW_LAUNCH_CHECK("reduce_rows");
     return VQW_OK;
 }
+}  // namespace
 
 int conv_direct_wgrad_splits(long nout, long P) {
     int s = ceil_div(4096, nout);

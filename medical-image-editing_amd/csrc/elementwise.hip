@@ -11,7 +11,7 @@ extern "C" __attribute__((visibility("hidden"))) void vqw_set_error(const char* 
     va_end(ap);
 }
 extern "C" const char* vqw_last_error(void) { return g_err; }
-extern "C" int vqw_abi_version(void) { return 7; }
+extern "C" int vqw_abi_version(void) { return 8; }
 
 // ---------------------------------------------------------------------------------------------
 template <int RELU>

@@ -129,6 +129,11 @@ SIGNATURES = {
     "vqw_seg_ws_bytes": (c_sz, [c_i]),
     "vqw_seg_losses_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p]),
     "vqw_seg_losses_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p]),
+    "vqw_fold_defer": (c_i, [c_i]),
+    "vqw_fold_pending": (c_i, []),
+    "vqw_fold_table_bytes": (c_sz, []),
+    "vqw_fold_discard": (c_i, []),
+    "vqw_fold_flush_host": (c_i, [c_p, c_p, c_sz, c_p]),
     "vqw_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
     "vqw_adam_multi": (c_i, [c_p, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
 }
@@ -136,7 +141,7 @@ SIGNATURES = {
 _lib = None
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def load():

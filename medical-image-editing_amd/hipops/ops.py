@@ -214,11 +214,61 @@ def _pass_id():
 
 
 def _join_side_stream():
-    """Order the current stream after the weight-gradient lanes (idempotent)."""
+    """Order the current stream after the weight-gradient lanes (idempotent), then fold the split-K slabs the lanes' weight
+    gradient kernels have left (one launch for the whole pass, see _fold_flush)."""
     global _join_queued_for
     _join_queued_for = None
     for st in _side_streams.values():
         torch.cuda.current_stream(st.device).wait_stream(st)
+    _fold_flush()
+
+
+# Deferred slab folds (VQW_FOLD_DEFER=0: every weight-gradient call folds its own slabs, two short launches per layer).
+# A weight-gradient kernel leaves split-K slabs; folding them is a short, dependent launch behind every one of the ~110
+# weight-gradient kernels of a step (dW and dbias: ~250 launches).  On the lanes the library only records the folds
+# (vqw_fold_defer) and the end-of-pass lane join folds them all in ONE launch; the two views' folds into one gradient are
+# summed in recording order (overwrite, then accumulate) - the same values in a fixed order.  The slab buffers are kept alive
+# here until that launch is enqueued.  Off while a gradient-ready listener is registered (the overlapped data-parallel
+# schedule needs a parameter's gradient final when it is announced).
+FOLD_DEFER = os.environ.get("VQW_FOLD_DEFER", "1") != "0"
+_fold_keep = []                # slab workspaces of the recorded folds
+_fold_slots = []               # ring of [pinned host table, device table, event of the launch that read them]
+_fold_next = 0
+fold_flushes = 0               # batched fold launches since import (tests)
+
+
+def _fold_active():
+    return FOLD_DEFER and not grad_ready_listeners
+
+
+def _fold_flush():
+    """Fold every recorded slab set in one launch on the current stream (which the caller has ordered after the lanes)."""
+    global _fold_next, fold_flushes
+    lib = _lib.load()
+    if not _fold_keep and lib.vqw_fold_pending() == 0:
+        return
+    need = int(lib.vqw_fold_table_bytes())
+    cur = torch.cuda.current_stream()
+    if len(_fold_slots) < 4:
+        _fold_slots.append(None)
+        _fold_next = len(_fold_slots) - 1
+    slot = _fold_slots[_fold_next]
+    if slot is not None:
+        slot[2].synchronize()          # the launch that read this slot's tables has run (only ever waits when > 4 passes are in flight)
+    if slot is None or slot[0].numel() < need or slot[1].device != cur.device:
+        size = max(need, 1 << 16)
+        slot = [torch.empty(size, dtype=torch.uint8, pin_memory=True), torch.empty(size, dtype=torch.uint8, device=cur.device), None]
+    _lib.check(lib.vqw_fold_flush_host(ctypes.c_void_p(slot[0].data_ptr()), ctypes.c_void_p(slot[1].data_ptr()), slot[0].numel(),
+                                       ctypes.c_void_p(cur.cuda_stream)), "vqw_fold_flush_host")
+    slot[2] = cur.record_event()
+    _fold_slots[_fold_next] = slot
+    _fold_next = (_fold_next + 1) % 4
+    fold_flushes += 1
+    # the slab buffers belong to the lanes' memory pools: order the lanes after this launch before the pools may reuse them
+    for st in _side_streams.values():
+        if st.device == cur.device:
+            st.wait_event(slot[2])
+    _fold_keep.clear()
 
 
 def _queue_lane_join():
@@ -322,18 +372,38 @@ def _cached(weight, key, build, deps=()):
     return val
 
 
-def _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed):
-    """dW / db on the CURRENT stream; `collapsed` selects the low-resolution form for 3x3-over-upsampled layers."""
+def _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed, defer_fold=False):
+    """dW / db on the CURRENT stream; `collapsed` selects the low-resolution form for 3x3-over-upsampled layers.
+    defer_fold: the slab folds are only recorded (the caller has queued the end-of-pass lane join, which runs them)."""
     C0 = x0.shape[1]
     C1 = 0 if x1 is None else x1.shape[1]
-    if collapsed and L.vqw_conv3x3_up2_wgrad_supported(C0, Cout, N, H // 2, W // 2):
-        ws = _ws(L.vqw_conv3x3_up2_wgrad_ws_bytes(C0, Cout, N, H // 2, W // 2), gy)
-        _lib.check(L.vqw_conv3x3_up2_wgrad(_p(x0), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), N, H // 2, W // 2, C0, Cout,
-                                           int(acc), _st()), "vqw_conv3x3_up2_wgrad")
-        return
-    ws = _ws(L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks), gy)
-    _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
-                                  N, H, W, Cout, ks, dilation, int(acc), _st()), "vqw_conv2d_wgrad")
+    lib = _lib.load()
+    defer_fold = defer_fold and _fold_active()
+    for attempt in (0, 1):
+        old = lib.vqw_fold_defer(1) if defer_fold else 0
+        try:
+            if collapsed and L.vqw_conv3x3_up2_wgrad_supported(C0, Cout, N, H // 2, W // 2):
+                ws = _ws(L.vqw_conv3x3_up2_wgrad_ws_bytes(C0, Cout, N, H // 2, W // 2), gy)
+                _lib.check(L.vqw_conv3x3_up2_wgrad(_p(x0), _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(), N, H // 2, W // 2, C0, Cout,
+                                                   int(acc), _st()), "vqw_conv3x3_up2_wgrad")
+            else:
+                ws = _ws(L.vqw_conv2d_wgrad_ws_bytes(C0, C1, N, H, W, Cout, ks), gy)
+                _lib.check(L.vqw_conv2d_wgrad(_p(x0), C0, int(up0), _p(x1), C1, _p(gy), _p(gw), _p(gb), _p(ws), ws.numel(),
+                                              N, H, W, Cout, ks, dilation, int(acc), _st()), "vqw_conv2d_wgrad")
+        except RuntimeError as e:
+            if defer_fold and attempt == 0 and "flush first" in str(e):
+                # a third use of one weight inside a pass: fold what is recorded (on this lane, after the other lanes), retry
+                lib.vqw_fold_defer(old)
+                sync_wgrad_lanes()
+                _fold_flush()
+                continue
+            raise
+        finally:
+            if defer_fold:
+                lib.vqw_fold_defer(old)
+        break
+    if defer_fold:
+        _fold_keep.append(ws)
 
 
 def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, collapsed=False):
@@ -357,7 +427,7 @@ def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, 
         gw, gb = weight.grad, (bias.grad if bias is not None else None)
         if gw.stride() != weight.stride():
             raise RuntimeError("conv2d: existing weight.grad layout does not match the parameter layout")
-        _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed)
+        _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed, defer_fold=True)
         weight._vqw_pending = getattr(weight, "_vqw_pending", 1) - 1
         if weight._vqw_pending <= 0:
             weight._vqw_pending = 0
@@ -584,6 +654,9 @@ def begin_step():
     _IN_BWD_PARTS.clear()
     if _join_queued_for is not None:
         _join_side_stream()
+    elif _fold_keep or _lib.load().vqw_fold_pending():      # a pass that never reached its lane join: its slabs are still alive
+        sync_wgrad_lanes()
+        _fold_flush()
 
 
 in_bwd_fused_calls = 0         # InstanceNorm backward calls that took their sums from a convolution's epilogue (tests)
@@ -807,9 +880,9 @@ def _deferred_wgrad_cat(wa, ba, wb, bb, x0, gy, ks, N, H, W):
             gb_ = torch.empty(Ct, dtype=torch.float32, device=gy.device)
             wa.grad, wb.grad, ba.grad, bb.grad = gw[:Ca], gw[Ca:], gb_[:Ca], gb_[Ca:]
             wa._vqw_gcat, ba._vqw_gcat = gw, gb_
-            _run_wgrad(L, x0, None, gy, gw, gb_, False, ks, 1, N, H, W, Ct, False, False)
+            _run_wgrad(L, x0, None, gy, gw, gb_, False, ks, 1, N, H, W, Ct, False, False, defer_fold=True)
         elif _grad_halves_adjacent(wa, wb, wa.grad, wb.grad) and _grad_halves_adjacent(ba, bb, ba.grad, bb.grad):
-            _run_wgrad(L, x0, None, gy, wa._vqw_gcat, ba._vqw_gcat, False, ks, 1, N, H, W, Ct, True, False)
+            _run_wgrad(L, x0, None, gy, wa._vqw_gcat, ba._vqw_gcat, False, ks, 1, N, H, W, Ct, True, False, defer_fold=True)
         else:    # gradients someone else allocated: compute once, then accumulate the halves
             gw = torch.empty((Ct, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
             gb_ = torch.empty(Ct, dtype=torch.float32, device=gy.device)

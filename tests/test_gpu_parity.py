@@ -658,6 +658,47 @@ def test_instance_norm_backward_sums_from_the_consumer_convolution(monkeypatch, 
         assert_close(got[k], ref[k], 2e-5, "gradient %s, norm-backward sums from the convolution's epilogue" % k)
 
 
+def test_deferred_slab_folds_match_immediate_folds(monkeypatch):
+    """The weight-gradient kernels' split-K slabs are folded by ONE launch at the end of the backward pass (ops._fold_flush,
+    vqw_fold_flush_host) instead of by two short launches behind every weight-gradient kernel.  Same sums in another fixed
+    order: every parameter gradient within 2e-6 of the run with immediate folds, over a block mix that covers the Winograd,
+    tile, up-sampled, two-source, 1x1, concatenated gamma|beta and dilated weight-gradient kernels, with both views of a step
+    (overwrite, then accumulate into the same gradient) and with a second backward pass accumulating on top."""
+    from networks import blocks as B
+    from networks.aspp import ASPP
+    from hipops import ops, _lib
+
+    def run(defer):
+        monkeypatch.setattr(ops, "FOLD_DEFER", defer)
+        torch.manual_seed(9)
+        cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+        mods = [B.ResBlock(32, 64), B.StyledResUpBlock(64, 32, 32), B.UpBlock(96, 32), ASPP(32, 32, [2, 6]), B.DoubleConv(16, 16)]
+        for m in mods:
+            m.to(DEV).train()
+        xa = [cl(torch.randn(2, 32, 64, 64, device=DEV, requires_grad=True)) for _ in range(2)]      # two "views"
+        f0 = ops.fold_flushes
+        for rep in range(2):               # the second pass accumulates into the gradients of the first
+            loss = 0
+            for x in xa:
+                pooled, out = mods[0](x)                                   # (2, 64, 32, 32), (2, 64, 64, 64)
+                up = mods[1](pooled, x)                                    # (2, 32, 64, 64), style = x
+                u2 = mods[2](pooled, up)                                   # [up2x(64) | 32] -> 32
+                a = mods[3](u2)                                            # (2, 96, 64, 64)
+                d = mods[4](a[:, :16].contiguous(memory_format=torch.channels_last))
+                loss = loss + (a * a).mean() + (d * d).mean() + (out * out).mean()
+            loss.backward()
+            assert _lib.load().vqw_fold_pending() == 0 and not ops._fold_keep, "folds left behind after the backward pass"
+        torch.cuda.synchronize()
+        grads = {"%d.%s" % (i, k): p.grad.clone() for i, m in enumerate(mods) for k, p in m.named_parameters()}
+        return grads, ops.fold_flushes - f0
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 0 and n_got == 2, (n_ref, n_got)
+    gmax = max(float(v.abs().max()) for v in ref.values())
+    for k in ref:
+        assert_close(got[k], ref[k], 2e-6, "gradient %s: one batched fold vs immediate folds" % k, atol=1e-7 * gmax)
+
+
 @pytest.mark.parametrize("second_first", [False, True])
 def test_fusion_notes_are_not_honoured_when_the_activation_has_a_second_consumer(monkeypatch, second_first):
     """The two epilogue fusions pass a note from the consumer's backward to the producer's, keyed by the gradient tensor
