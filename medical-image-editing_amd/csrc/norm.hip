@@ -4,7 +4,6 @@
 // part[n][split][c][2] (fixed pixel ranges per block, fixed tree inside the block), stage 2 sums the
 // partials in index order.  No float atomics -> bitwise reproducible run to run.
 #include "common.h"
-#include <stdlib.h>
 #include "prof.h"
 #include "../../include/vqwnet_hip.h"
 
@@ -407,47 +406,6 @@ __global__ void __launch_bounds__(256) k_plane_sum_finalize(const double* __rest
     out[2 * i + 1] = (float)(b * scale);
 }
 
-// the same for any number of splits (image-chunked launches use up to 256): lanes take the splits round-robin
-__global__ void __launch_bounds__(256) k_plane_sum_finalize_n(const double* __restrict__ part, float* __restrict__ out, int NC, int C,
-                                                              int splits, double scale) {
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;
-    if (i >= NC) return;
-    int n = i / C, c = i % C;
-    double a = 0.0, b = 0.0;
-    for (int t = s; t < splits; t += 64) {
-        const double* o = part + (((long)n * splits + t) * C + c) * 2;
-        a += o[0];
-        b += o[1];
-    }
-    a = wave_sum_d(a);
-    b = wave_sum_d(b);
-    if (s != 0) return;
-    out[2 * i] = (float)(a * scale);
-    out[2 * i + 1] = (float)(b * scale);
-}
-
-// Image-chunked backward passes.  A backward normalisation is a reduction pass over (x, gy) followed by an apply pass over
-// the same two tensors; on the full-resolution layers a tensor of the whole batch (268 MB at 32 channels, 256 x 256, B = 32)
-// is larger than the 256 MiB Infinity Cache, so the apply pass fetches everything from HBM again.  InstanceNorm statistics
-// are per image: running reduce -> finalise -> apply over groups of images whose (x, gy) fit the cache lets the apply pass
-// read what the reduce pass has just brought in - 3 HBM passes (read x, read gy, write gx) instead of 5.  Same sums in the
-// same per-image order for a given chunking (bit-reproducible); VQW_NORM_CHUNK_MB=0 restores whole-batch launches.
-static const long g_norm_chunk_bytes = []{ const char* e = getenv("VQW_NORM_CHUNK_MB"); long mb = e ? atol(e) : 96; return mb << 20; }();
-static inline int norm_chunk_images(int N, double bytes_read_per_image) {
-    if (g_norm_chunk_bytes <= 0 || (double)N * bytes_read_per_image <= (double)g_norm_chunk_bytes) return N;
-    int c = (int)((double)g_norm_chunk_bytes / bytes_read_per_image);
-    return c < 1 ? 1 : (c > N ? N : c);
-}
-// splits of a chunk of nn images: enough workgroups for the whole chip, >= 64 pixels each, within the workspace of the
-// whole-batch launch (N x PLANE_MAX_SPLITS rows)
-static inline int chunk_splits(int N, int nn, int HW) {
-    int s = ceil_div(2048, nn);
-    s = imin(s, imax(1, HW / 64));
-    s = imin(s, 256);
-    s = imin(s, (int)(((long)N * PLANE_MAX_SPLITS) / nn));
-    return imax(s, 1);
-}
-
 template <int RELU>
 __global__ void k_inorm_bwd_apply(const float* __restrict__ x, const float* __restrict__ mr, const float* __restrict__ gy,
                                   const float* __restrict__ means, float* __restrict__ gx, long total, int HW, int C,
@@ -479,31 +437,6 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
     float* means = (float*)((char*)ws + plane_part_bytes(N, C));
     long total = (long)N * HW * C;
     const bool vec = (C & 3) == 0 && (gy_cstride & 3) == 0 && (gy_coff & 3) == 0 && al16(x) && al16(gy) && al16(mean_rstd);
-    const int chunk = norm_chunk_images(N, 8.0 * HW * C);
-    if (vec && chunk < N && al16(gx) && al16(means)) {
-        for (int n0 = 0; n0 < N; n0 += chunk) {
-            const int nn = imin(chunk, N - n0);
-            const int sp = chunk_splits(N, nn, HW);
-            const float* xc = x + (long)n0 * HW * C;
-            const float* gc = gy + (long)n0 * HW * gy_cstride;
-            const float* mc = mean_rstd + (long)n0 * C * 2;
-            float* ec = means + (long)n0 * C * 2;
-            float* oc = gx + (long)n0 * HW * C;
-            if (relu) {
-                FInBwd4<1> f{(const float4*)xc, mc, (const float4*)gc, C, gy_cstride / 4, gy_coff / 4};
-                k_plane_reduce4<<<dim3(sp, nn), 256, 0, st>>>(f, part, HW, C, sp);
-            } else {
-                FInBwd4<0> f{(const float4*)xc, mc, (const float4*)gc, C, gy_cstride / 4, gy_coff / 4};
-                k_plane_reduce4<<<dim3(sp, nn), 256, 0, st>>>(f, part, HW, C, sp);
-            }
-            k_plane_sum_finalize_n<<<ceil_div((long)nn * C, 4), 256, 0, st>>>(part, ec, nn * C, C, sp, 1.0 / (double)HW);
-            const long t4 = (long)nn * HW * C / 4;
-            if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)xc, mc, (const float4*)gc, ec, (float4*)oc, t4, HW, C / 4, gy_cstride / 4, gy_coff / 4);
-            else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)xc, mc, (const float4*)gc, ec, (float4*)oc, t4, HW, C / 4, gy_cstride / 4, gy_coff / 4);
-        }
-        VQW_LAUNCH_CHECK("vqw_inorm_bwd(chunked)");
-        return VQW_OK;
-    }
     if (vec && relu) {
         FInBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gy, C, gy_cstride / 4, gy_coff / 4};
         k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
@@ -682,24 +615,6 @@ extern "C" int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float
     float* ea = (float*)((char*)ws + plane_part_bytes(N, C));
     double* partb = (double*)((char*)ws + one);
     float* eb = (float*)((char*)ws + one + plane_part_bytes(N, C));
-    const int chunk = norm_chunk_images(N, 12.0 * HW * C);
-    if (chunk < N) {       // image-chunked: the apply pass reads xa, xb, gy out of the Infinity Cache (see vqw_inorm_bwd)
-        for (int n0 = 0; n0 < N; n0 += chunk) {
-            const int nn = imin(chunk, N - n0);
-            const int sp = chunk_splits(N, nn, HW);
-            const long po = (long)n0 * HW * C, mo = (long)n0 * C * 2;
-            k_inorm_bwd_pair_reduce4<<<dim3(sp, nn), 256, 0, st>>>((const float4*)(xa + po), mra + mo, (const float4*)(xb + po), mrb + mo,
-                                                                    (const float4*)(gy + po), parta, partb, HW, C, sp);
-            k_plane_sum_finalize_n<<<ceil_div((long)nn * C, 4), 256, 0, st>>>(parta, ea + mo, nn * C, C, sp, 1.0 / (double)HW);
-            k_plane_sum_finalize_n<<<ceil_div((long)nn * C, 4), 256, 0, st>>>(partb, eb + mo, nn * C, C, sp, 1.0 / (double)HW);
-            const long t4 = (long)nn * HW * C / 4;
-            k_inorm_bwd_pair_apply4<<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)(xa + po), mra + mo, ea + mo, (const float4*)(xb + po),
-                                                                          mrb + mo, eb + mo, (const float4*)(gy + po), (float4*)(gxa + po),
-                                                                          (float4*)(gxb + po), t4, HW, C / 4);
-        }
-        VQW_LAUNCH_CHECK("vqw_inorm_bwd_pair(chunked)");
-        return VQW_OK;
-    }
     k_inorm_bwd_pair_reduce4<<<dim3(splits, N), 256, 0, st>>>((const float4*)xa, mra, (const float4*)xb, mrb, (const float4*)gy, parta,
                                                                partb, HW, C, splits);
     k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(parta, ea, N * C, C, splits, 1.0 / (double)HW);
