@@ -86,10 +86,11 @@ __global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict_
             int p = p0 + tr;
             for (; p + 3 * rows < p1; p += 4 * rows) {  // four independent element loads in flight per lane
                 float va[4], vb[4], wa[4], wb[4], xa[4], xb[4], ya[4], yb[4];
-                f(((long)n * HW + p) * C4 + c4, n, c4 * 4, va, vb);
-                f(((long)n * HW + p + rows) * C4 + c4, n, c4 * 4, wa, wb);
-                f(((long)n * HW + p + 2 * rows) * C4 + c4, n, c4 * 4, xa, xb);
-                f(((long)n * HW + p + 3 * rows) * C4 + c4, n, c4 * 4, ya, yb);
+                const long q = (long)n * HW + p;
+                f(q * C4 + c4, q, n, c4 * 4, va, vb);
+                f((q + rows) * C4 + c4, q + rows, n, c4 * 4, wa, wb);
+                f((q + 2 * rows) * C4 + c4, q + 2 * rows, n, c4 * 4, xa, xb);
+                f((q + 3 * rows) * C4 + c4, q + 3 * rows, n, c4 * 4, ya, yb);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     a[k] += ((double)va[k] + (double)wa[k]) + ((double)xa[k] + (double)ya[k]);
@@ -98,14 +99,16 @@ __global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict_
             }
             for (; p + rows < p1; p += 2 * rows) {
                 float va[4], vb[4], wa[4], wb[4];
-                f(((long)n * HW + p) * C4 + c4, n, c4 * 4, va, vb);
-                f(((long)n * HW + p + rows) * C4 + c4, n, c4 * 4, wa, wb);
+                const long q = (long)n * HW + p;
+                f(q * C4 + c4, q, n, c4 * 4, va, vb);
+                f((q + rows) * C4 + c4, q + rows, n, c4 * 4, wa, wb);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { a[k] += (double)va[k] + (double)wa[k]; b[k] += (double)vb[k] + (double)wb[k]; }
             }
             for (; p < p1; p += rows) {
                 float va[4], vb[4];
-                f(((long)n * HW + p) * C4 + c4, n, c4 * 4, va, vb);
+                const long q = (long)n * HW + p;
+                f(q * C4 + c4, q, n, c4 * 4, va, vb);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { a[k] += (double)va[k]; b[k] += (double)vb[k]; }
             }
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict_
 // InstanceNorm
 struct FStats4 {
     const float4* x;
-    __device__ void operator()(long i4, int, int, float* a, float* b) const {
+    __device__ void operator()(long i4, long, int, int, float* a, float* b) const {
         float4 v = x[i4];
         a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
         b[0] = v.x * v.x; b[1] = v.y * v.y; b[2] = v.z * v.z; b[3] = v.w * v.w;
@@ -143,10 +146,10 @@ struct FInBwd4 {
     const float* mr;
     const float4* gy;
     int C, gcs4, gco4;
-    __device__ void operator()(long i4, int n, int c, float* a, float* b) const {
+    // i4 = (pix * C4 + c4) with pix = n * HW + p the pixel of the batch, c = 4 * c4 (no integer division per element)
+    __device__ void operator()(long i4, long pix, int n, int c, float* a, float* b) const {
         const float4* m = (const float4*)(mr + 2 * ((long)n * C + c));
-        const int C4 = C >> 2;
-        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[(i4 / C4) * gcs4 + gco4 + (i4 % C4)];
+        float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[pix * gcs4 + gco4 + (c >> 2)];
         float xh[4] = {(v.x - m0.x) * m0.y, (v.y - m0.z) * m0.w, (v.z - m1.x) * m1.y, (v.w - m1.z) * m1.w};
         float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -167,9 +170,9 @@ struct FSpadeBwd4 {
     float4* dgamma;
     float4* dbeta;
     int C4, gbs4;     // channels / 4, gamma-beta pixel stride / 4
-    __device__ void operator()(long i4, int, int c, float* a, float* b) const {
+    __device__ void operator()(long i4, long pix, int, int c, float* a, float* b) const {
         const float4* m = (const float4*)(mr + 2 * c);
-        const long j4 = (i4 / C4) * gbs4 + (i4 % C4);
+        const long j4 = pix * gbs4 + (c >> 2);
         float4 m0 = m[0], m1 = m[1], v = x[i4], g = gy[i4], ga = gamma[j4], be = beta[j4];
         float xh[4] = {(v.x - m0.x) * m0.y, (v.y - m0.z) * m0.w, (v.z - m1.x) * m1.y, (v.w - m1.z) * m1.w};
         float gg[4] = {g.x, g.y, g.z, g.w}, gm[4] = {1.f + ga.x, 1.f + ga.y, 1.f + ga.z, 1.f + ga.w};
@@ -277,6 +280,226 @@ __global__ void k_inorm_bwd_apply4(const float4* __restrict__ x, const float* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Division-free walks (round 4).  The flat-index kernels above spend ~220 vector instructions per float4 on 64-bit integer
+// divisions (i / plane4, i % C4, (i / C4) * stride with run-time divisors) and re-load the per-(n, c) constants for every
+// element.  When C4 = C / 4 is a power of two <= 256 a 256-thread workgroup covers 256 consecutive float4 = R = 256 / C4 whole
+// pixels: thread t keeps its channel quad c4 = t & (C4 - 1) for the whole walk (its constants stay in registers), its pixel is
+// p = base + (t >> log2 C4) and advances by R per step; grid.y = image for the per-image constants.  Four independent
+// 16-byte loads per tensor in flight per thread.
+static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+static inline bool walk_ok(int C4) { return C4 >= 1 && C4 <= 256 && ilog2_exact(C4) >= 0; }
+static inline int walk_blocks(int N, int HW, int C4) {       // workgroups per image: ~2048 in all, each >= one 4 R-pixel step
+    const int R = 256 / C4;
+    int per = ceil_div(2048, N);
+    int cap = ceil_div(HW, 4 * R);
+    return imax(1, imin(per, cap));
+}
+#define WALK4_SETUP                                                        \
+    const int t = threadIdx.x, c4 = t & (C4 - 1), r = t >> lgC4, R = 256 >> lgC4
+
+template <int RELU>
+__global__ void __launch_bounds__(256) k_inorm_apply4w(const float4* __restrict__ x, const float* __restrict__ mr, float4* __restrict__ y,
+                                                       int HW, int C4, int lgC4, int ycs4, int yco4) {
+    WALK4_SETUP;
+    const int n = blockIdx.y;
+    const float4* m = (const float4*)(mr + 8 * ((long)n * C4 + c4));
+    const float4 m0 = m[0], m1 = m[1];
+    const float4* xn = x + (long)n * HW * C4 + c4;
+    float4* yn = y + (long)n * HW * ycs4 + yco4 + c4;
+    for (int p0 = blockIdx.x * 4 * R + r; p0 < HW; p0 += gridDim.x * 4 * R) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (p0 + u * R < HW) v[u] = xn[(long)(p0 + u * R) * C4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * R >= HW) break;
+            float4 o;
+            o.x = (v[u].x - m0.x) * m0.y; o.y = (v[u].y - m0.z) * m0.w; o.z = (v[u].z - m1.x) * m1.y; o.w = (v[u].w - m1.z) * m1.w;
+            if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            yn[(long)(p0 + u * R) * ycs4] = o;
+        }
+    }
+}
+
+__device__ __forceinline__ float4 inorm_bwd_elem(const float4 v, const float4 g, const float4 m0, const float4 m1, const float4 e0,
+                                                 const float4 e1, const bool relu) {
+    float4 o;
+    float xh, gg;
+    xh = (v.x - m0.x) * m0.y; gg = (relu && !(xh > 0.f)) ? 0.f : g.x; o.x = m0.y * (gg - e0.x - xh * e0.y);
+    xh = (v.y - m0.z) * m0.w; gg = (relu && !(xh > 0.f)) ? 0.f : g.y; o.y = m0.w * (gg - e0.z - xh * e0.w);
+    xh = (v.z - m1.x) * m1.y; gg = (relu && !(xh > 0.f)) ? 0.f : g.z; o.z = m1.y * (gg - e1.x - xh * e1.y);
+    xh = (v.w - m1.z) * m1.w; gg = (relu && !(xh > 0.f)) ? 0.f : g.w; o.w = m1.w * (gg - e1.z - xh * e1.w);
+    return o;
+}
+
+template <int RELU>
+__global__ void __launch_bounds__(256) k_inorm_bwd_apply4w(const float4* __restrict__ x, const float* __restrict__ mr,
+                                                           const float4* __restrict__ gy, const float* __restrict__ means,
+                                                           float4* __restrict__ gx, int HW, int C4, int lgC4, int gcs4, int gco4) {
+    WALK4_SETUP;
+    const int n = blockIdx.y;
+    const long k = 8 * ((long)n * C4 + c4);
+    const float4 m0 = ((const float4*)(mr + k))[0], m1 = ((const float4*)(mr + k))[1];
+    const float4 e0 = ((const float4*)(means + k))[0], e1 = ((const float4*)(means + k))[1];
+    const float4* xn = x + (long)n * HW * C4 + c4;
+    const float4* gn = gy + (long)n * HW * gcs4 + gco4 + c4;
+    float4* on = gx + (long)n * HW * C4 + c4;
+    for (int p0 = blockIdx.x * 4 * R + r; p0 < HW; p0 += gridDim.x * 4 * R) {
+        float4 v[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p0 + u * R < HW) { v[u] = xn[(long)(p0 + u * R) * C4]; g[u] = gn[(long)(p0 + u * R) * gcs4]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * R >= HW) break;
+            on[(long)(p0 + u * R) * C4] = inorm_bwd_elem(v[u], g[u], m0, m1, e0, e1, RELU);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_inorm_bwd_pair_apply4w(const float4* __restrict__ xa, const float* __restrict__ mra,
+                                                                const float* __restrict__ ea, const float4* __restrict__ xb,
+                                                                const float* __restrict__ mrb, const float* __restrict__ eb,
+                                                                const float4* __restrict__ gy, float4* __restrict__ gxa,
+                                                                float4* __restrict__ gxb, int HW, int C4, int lgC4) {
+    WALK4_SETUP;
+    const int n = blockIdx.y;
+    const long k = 8 * ((long)n * C4 + c4);
+    const float4 a0 = ((const float4*)(mra + k))[0], a1 = ((const float4*)(mra + k))[1];
+    const float4 f0 = ((const float4*)(ea + k))[0], f1 = ((const float4*)(ea + k))[1];
+    const float4 b0 = ((const float4*)(mrb + k))[0], b1 = ((const float4*)(mrb + k))[1];
+    const float4 h0 = ((const float4*)(eb + k))[0], h1 = ((const float4*)(eb + k))[1];
+    const long base = (long)n * HW * C4 + c4;
+    for (int p0 = blockIdx.x * 2 * R + r; p0 < HW; p0 += gridDim.x * 2 * R) {
+        float4 va[2], vb[2], g[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (p0 + u * R < HW) {
+                const long i = base + (long)(p0 + u * R) * C4;
+                va[u] = xa[i]; vb[u] = xb[i]; g[u] = gy[i];
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (p0 + u * R >= HW) break;
+            const long i = base + (long)(p0 + u * R) * C4;
+            gxa[i] = inorm_bwd_elem(va[u], g[u], a0, a1, f0, f1, true);
+            gxb[i] = inorm_bwd_elem(vb[u], g[u], b0, b1, h0, h1, false);
+        }
+    }
+}
+
+// SPADE: constants per channel only; the walk runs over the P = N * HW pixels of the batch (grid.x only)
+template <int RELU, int RES>
+__global__ void __launch_bounds__(256) k_spade_fwd4w(const float4* __restrict__ x, const float* __restrict__ mr,
+                                                     const float4* __restrict__ gamma, const float4* __restrict__ beta,
+                                                     float4* __restrict__ y, long P, int C4, int lgC4, int gbs4,
+                                                     const float4* __restrict__ res) {
+    WALK4_SETUP;
+    const float4 m0 = ((const float4*)(mr + 8 * c4))[0], m1 = ((const float4*)(mr + 8 * c4))[1];
+    for (long p0 = (long)blockIdx.x * 4 * R + r; p0 < P; p0 += (long)gridDim.x * 4 * R) {
+        float4 v[4], ga[4], be[4], rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p0 + u * R < P) {
+                const long p = p0 + u * R;
+                v[u] = x[p * C4 + c4]; ga[u] = gamma[p * gbs4 + c4]; be[u] = beta[p * gbs4 + c4];
+                if (RES) rr[u] = res[p * C4 + c4];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * R >= P) break;
+            float4 o;
+            o.x = (v[u].x - m0.x) * m0.y * (1.f + ga[u].x) + be[u].x;
+            o.y = (v[u].y - m0.z) * m0.w * (1.f + ga[u].y) + be[u].y;
+            o.z = (v[u].z - m1.x) * m1.y * (1.f + ga[u].z) + be[u].z;
+            o.w = (v[u].w - m1.z) * m1.w * (1.f + ga[u].w) + be[u].w;
+            if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (RES) { o.x += rr[u].x; o.y += rr[u].y; o.z += rr[u].z; o.w += rr[u].w; }
+            y[(p0 + u * R) * C4 + c4] = o;
+        }
+    }
+}
+
+template <int RELU, int TRAIN>
+__global__ void __launch_bounds__(256) k_spade_bwd_apply4w(const float4* __restrict__ x, const float* __restrict__ mr,
+                                                           const float4* __restrict__ gamma, const float4* __restrict__ beta,
+                                                           const float4* __restrict__ gy, const double* __restrict__ sums,
+                                                           double inv_count, float4* __restrict__ gx, long P, int C4, int lgC4, int gbs4) {
+    WALK4_SETUP;
+    const float4 m0 = ((const float4*)(mr + 8 * c4))[0], m1 = ((const float4*)(mr + 8 * c4))[1];
+    const float mean[4] = {m0.x, m0.z, m1.x, m1.z}, rs[4] = {m0.y, m0.w, m1.y, m1.w};
+    float s1[4], s2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        s1[k] = TRAIN ? (float)(sums[2 * (4 * c4 + k)] * inv_count) : 0.f;
+        s2[k] = TRAIN ? (float)(sums[2 * (4 * c4 + k) + 1] * inv_count) : 0.f;
+    }
+    for (long p0 = (long)blockIdx.x * 2 * R + r; p0 < P; p0 += (long)gridDim.x * 2 * R) {
+        float4 v[2], ga4[2], g4[2], be4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (p0 + u * R < P) {
+                const long p = p0 + u * R;
+                v[u] = x[p * C4 + c4]; ga4[u] = gamma[p * gbs4 + c4]; g4[u] = gy[p * C4 + c4];
+                be4[u] = RELU ? beta[p * gbs4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (p0 + u * R >= P) break;
+            const float xv[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, gav[4] = {ga4[u].x, ga4[u].y, ga4[u].z, ga4[u].w};
+            const float gv[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w}, bev[4] = {be4[u].x, be4[u].y, be4[u].z, be4[u].w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float rk = rs[k];
+                const float xh = (xv[k] - mean[k]) * rk;
+                const float ga = 1.f + gav[k];
+                float g = gv[k];
+                if (RELU) {
+                    const float out = xh * ga + bev[k];
+                    if (!(out > 0.f)) g = 0.f;
+                }
+                const float dxh = g * ga;
+                o[k] = TRAIN ? rk * (dxh - s1[k] - xh * s2[k]) : rk * dxh;
+            }
+            gx[(p0 + u * R) * C4 + c4] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+static inline int walk_blocks_flat(long P, int C4, int per_step) {
+    const int R = 256 / C4;
+    long g = (P + (long)per_step * R - 1) / ((long)per_step * R);
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+// launchers: the walk form where C4 allows, else the flat-index form
+static void launch_inorm_apply4(const float* x, const float* mr, float* y, int N, int HW, int C, int ycs, int yco, int relu, hipStream_t st) {
+    const int C4 = C / 4;
+    if (walk_ok(C4)) {
+        const dim3 g(walk_blocks(N, HW, C4), N);
+        if (relu) k_inorm_apply4w<1><<<g, 256, 0, st>>>((const float4*)x, mr, (float4*)y, HW, C4, ilog2_exact(C4), ycs / 4, yco / 4);
+        else k_inorm_apply4w<0><<<g, 256, 0, st>>>((const float4*)x, mr, (float4*)y, HW, C4, ilog2_exact(C4), ycs / 4, yco / 4);
+        return;
+    }
+    const long t4 = (long)N * HW * C4;
+    if (relu) k_inorm_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mr, (float4*)y, t4, HW, C4, ycs / 4, yco / 4);
+    else k_inorm_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mr, (float4*)y, t4, HW, C4, ycs / 4, yco / 4);
+}
+static void launch_inorm_bwd_apply4(const float* x, const float* mr, const float* gy, const float* means, float* gx, int N, int HW, int C,
+                                    int gcs, int gco, int relu, hipStream_t st) {
+    const int C4 = C / 4;
+    if (walk_ok(C4)) {
+        const dim3 g(walk_blocks(N, HW, C4), N);
+        if (relu) k_inorm_bwd_apply4w<1><<<g, 256, 0, st>>>((const float4*)x, mr, (const float4*)gy, means, (float4*)gx, HW, C4, ilog2_exact(C4), gcs / 4, gco / 4);
+        else k_inorm_bwd_apply4w<0><<<g, 256, 0, st>>>((const float4*)x, mr, (const float4*)gy, means, (float4*)gx, HW, C4, ilog2_exact(C4), gcs / 4, gco / 4);
+        return;
+    }
+    const long t4 = (long)N * HW * C4;
+    if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mr, (const float4*)gy, means, (float4*)gx, t4, HW, C4, gcs / 4, gco / 4);
+    else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mr, (const float4*)gy, means, (float4*)gx, t4, HW, C4, gcs / 4, gco / 4);
+}
+
 // statistics from per-tile float partials part[n][nparts][C][2] (written by the conv that produced x): one wave per
 // (n, c), lanes take the tiles round-robin and sum in double, fixed butterfly
 __global__ void __launch_bounds__(256) k_inorm_finalize_parts(const float* __restrict__ part, float* __restrict__ mr, int NC, int C,
@@ -309,9 +532,7 @@ extern "C" int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int 
     k_inorm_finalize_parts<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, mean_rstd, N * C, C, nparts, 1.0 / (double)HW, eps, (double)nparts / (double)HW);
     long total = (long)N * HW * C;
     if ((C & 3) == 0 && (y_cstride & 3) == 0 && (y_coff & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
-        long t4 = total / 4;
-        if (relu) k_inorm_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
-        else k_inorm_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
+        launch_inorm_apply4(x, mean_rstd, y, N, HW, C, y_cstride, y_coff, relu, st);
     } else if (relu) k_inorm_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     else k_inorm_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     VQW_LAUNCH_CHECK("vqw_inorm_fwd_parts");
@@ -362,9 +583,7 @@ extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff
                                                                  1.0 / (double)HW, eps);
     long total = (long)N * HW * C;
     if ((C & 3) == 0 && (y_cstride & 3) == 0 && (y_coff & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)mean_rstd) & 15) == 0)) {
-        long t4 = total / 4;
-        if (relu) k_inorm_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
-        else k_inorm_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (float4*)y, t4, HW, C / 4, y_cstride / 4, y_coff / 4);
+        launch_inorm_apply4(x, mean_rstd, y, N, HW, C, y_cstride, y_coff, relu, st);
     } else if (relu) k_inorm_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     else k_inorm_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, y, total, HW, C, y_cstride, y_coff);
     VQW_LAUNCH_CHECK("vqw_inorm_fwd");
@@ -453,9 +672,7 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
     k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, means, N * C, C, splits, 1.0 / (double)HW);
     if ((C & 3) == 0 && (gy_cstride & 3) == 0 && (gy_coff & 3) == 0 &&
         ((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)mean_rstd | (uintptr_t)means) & 15) == 0)) {
-        long t4 = total / 4;
-        if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4, gy_cstride / 4, gy_coff / 4);
-        else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means, (float4*)gx, t4, HW, C / 4, gy_cstride / 4, gy_coff / 4);
+        launch_inorm_bwd_apply4(x, mean_rstd, gy, means, gx, N, HW, C, gy_cstride, gy_coff, relu, st);
     } else if (relu) k_inorm_bwd_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
     else k_inorm_bwd_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means, gx, total, HW, C, gy_cstride, gy_coff);
     VQW_LAUNCH_CHECK("vqw_inorm_bwd");
@@ -491,9 +708,7 @@ extern "C" int vqw_inorm_bwd_parts(const float* x, const float* mean_rstd, const
     k_plane_sum_finalize_f<<<ceil_div((long)N * C, 4), 256, 0, st>>>(part, means_ws, N * C, C, nparts, 1.0 / (double)HW);
     const long total = (long)N * HW * C;
     if ((C & 3) == 0 && ((((uintptr_t)x | (uintptr_t)gy | (uintptr_t)gx | (uintptr_t)mean_rstd | (uintptr_t)means_ws) & 15) == 0)) {
-        const long t4 = total / 4;
-        if (relu) k_inorm_bwd_apply4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means_ws, (float4*)gx, t4, HW, C / 4, C / 4, 0);
-        else k_inorm_bwd_apply4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gy, means_ws, (float4*)gx, t4, HW, C / 4, C / 4, 0);
+        launch_inorm_bwd_apply4(x, mean_rstd, gy, means_ws, gx, N, HW, C, C, 0, relu, st);
     } else if (relu) k_inorm_bwd_apply<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means_ws, gx, total, HW, C, C, 0);
     else k_inorm_bwd_apply<0><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gy, means_ws, gx, total, HW, C, C, 0);
     VQW_LAUNCH_CHECK("vqw_inorm_bwd_parts");
@@ -620,6 +835,12 @@ extern "C" int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float
     k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(parta, ea, N * C, C, splits, 1.0 / (double)HW);
     k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(partb, eb, N * C, C, splits, 1.0 / (double)HW);
     const long t4 = (long)N * HW * C / 4;
+    if (walk_ok(C / 4)) {
+        const int R = 256 / (C / 4);
+        const dim3 g(imax(1, imin(ceil_div(2048, N), ceil_div(HW, 2 * R))), N);
+        k_inorm_bwd_pair_apply4w<<<g, 256, 0, st>>>((const float4*)xa, mra, ea, (const float4*)xb, mrb, eb, (const float4*)gy, (float4*)gxa,
+                                                     (float4*)gxb, HW, C / 4, ilog2_exact(C / 4));
+    } else
     k_inorm_bwd_pair_apply4<<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)xa, mra, ea, (const float4*)xb, mrb, eb,
                                                                   (const float4*)gy, (float4*)gxa, (float4*)gxb, t4, HW, C / 4);
     VQW_LAUNCH_CHECK("vqw_inorm_bwd_pair");
@@ -784,6 +1005,11 @@ extern "C" int vqw_spade_fwd_res(const float* x, const float* mean_rstd, const f
               "vqw_spade_fwd_res: needs C %% 4 == 0 and 16-byte aligned tensors");
     const long t4 = P * C / 4;
     hipStream_t st = (hipStream_t)stream;
+    if (walk_ok(C / 4)) {
+        const int C4 = C / 4, gr = walk_blocks_flat(P, C4, 4);
+        if (relu) k_spade_fwd4w<1, 1><<<gr, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, P, C4, ilog2_exact(C4), gb_stride / 4, (const float4*)res);
+        else k_spade_fwd4w<0, 1><<<gr, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, P, C4, ilog2_exact(C4), gb_stride / 4, (const float4*)res);
+    } else
     if (relu) k_spade_fwd4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4, (const float4*)res);
     else k_spade_fwd4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4, (const float4*)res);
     VQW_LAUNCH_CHECK("vqw_spade_fwd_res");
@@ -797,6 +1023,11 @@ extern "C" int vqw_spade_fwd(const float* x, const float* mean_rstd, const float
     hipStream_t st = (hipStream_t)stream;
     if ((C & 3) == 0 && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(y) && al16(mean_rstd)) {
         long t4 = total / 4;
+        if (walk_ok(C / 4)) {
+            const int C4 = C / 4, gr = walk_blocks_flat(P, C4, 4);
+            if (relu) k_spade_fwd4w<1, 0><<<gr, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, P, C4, ilog2_exact(C4), gb_stride / 4, nullptr);
+            else k_spade_fwd4w<0, 0><<<gr, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, P, C4, ilog2_exact(C4), gb_stride / 4, nullptr);
+        } else
         if (relu) k_spade_fwd4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4);
         else k_spade_fwd4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4);
     } else if (relu) k_spade_fwd<1><<<stream_grid(total, 256), 256, 0, st>>>(x, mean_rstd, gamma, beta, y, total, C, gb_stride);
@@ -938,6 +1169,13 @@ extern "C" int vqw_spade_bwd_apply(const float* x, const float* mean_rstd, const
         long t4 = total / 4;
         int g = stream_grid(t4, 256), C4 = C / 4, s4 = gb_stride / 4;
         const float4 *x4 = (const float4*)x, *ga4 = (const float4*)gamma, *be4 = (const float4*)beta, *gy4 = (const float4*)gy;
+        if (walk_ok(C4)) {
+            const int gw = walk_blocks_flat(P, C4, 2), lg = ilog2_exact(C4);
+            if (relu && training) k_spade_bwd_apply4w<1, 1><<<gw, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, P, C4, lg, s4);
+            else if (relu) k_spade_bwd_apply4w<1, 0><<<gw, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, P, C4, lg, s4);
+            else if (training) k_spade_bwd_apply4w<0, 1><<<gw, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, P, C4, lg, s4);
+            else k_spade_bwd_apply4w<0, 0><<<gw, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, P, C4, lg, s4);
+        } else
         if (relu && training) k_spade_bwd_apply4<1, 1><<<g, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, t4, C4, s4);
         else if (relu) k_spade_bwd_apply4<1, 0><<<g, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, t4, C4, s4);
         else if (training) k_spade_bwd_apply4<0, 1><<<g, 256, 0, st>>>(x4, mean_rstd, ga4, be4, gy4, sums, ic, (float4*)gx, t4, C4, s4);
