@@ -66,8 +66,12 @@ __global__ void __launch_bounds__(256) k_plane_reduce(F f, double* __restrict__ 
 
 // float4 variant for C % 4 == 0: a lane owns 4 consecutive channels, C/4 lanes span a pixel, 256/(C/4) pixel rows per
 // pass (1 KiB contiguous per wave-instruction).  Functor F4: (float4 index i4, n, channel c) -> a[4], b[4].
+// (round 4: at least four waves per SIMD - the compiler's 214-register schedule left two, ~64 KB of loads in flight per CU,
+// and the pure-read passes ran at 3.6-4.1 TB/s; a group of four elements is summed in fp32 before it joins the double
+// accumulators unless the functor asks for doubles throughout (F4::kDoubleTree: the forward statistics, where E[x^2] - mean^2
+// cancels))
 template <class F4>
-__global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict__ part, int HW, int C, int splits) {
+__global__ void __launch_bounds__(256, F4::kMinWaves) k_plane_reduce4(F4 f, double* __restrict__ part, int HW, int C, int splits) {
     __shared__ double sa[4][256], sb[4][256];
     const int n = blockIdx.y, s = blockIdx.x;
     const int C4 = C >> 2;
@@ -93,8 +97,13 @@ __global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict_
                 f((q + 3 * rows) * C4 + c4, q + 3 * rows, n, c4 * 4, ya, yb);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    a[k] += ((double)va[k] + (double)wa[k]) + ((double)xa[k] + (double)ya[k]);
-                    b[k] += ((double)vb[k] + (double)wb[k]) + ((double)xb[k] + (double)yb[k]);
+                    if (F4::kDoubleTree) {
+                        a[k] += ((double)va[k] + (double)wa[k]) + ((double)xa[k] + (double)ya[k]);
+                        b[k] += ((double)vb[k] + (double)wb[k]) + ((double)xb[k] + (double)yb[k]);
+                    } else {
+                        a[k] += (double)((va[k] + wa[k]) + (xa[k] + ya[k]));
+                        b[k] += (double)((vb[k] + wb[k]) + (xb[k] + yb[k]));
+                    }
                 }
             }
             for (; p + rows < p1; p += 2 * rows) {
@@ -133,6 +142,8 @@ __global__ void __launch_bounds__(256) k_plane_reduce4(F4 f, double* __restrict_
 // ---------------------------------------------------------------------------------------------
 // InstanceNorm
 struct FStats4 {
+    static constexpr bool kDoubleTree = true;
+    static constexpr int kMinWaves = 4;
     const float4* x;
     __device__ void operator()(long i4, long, int, int, float* a, float* b) const {
         float4 v = x[i4];
@@ -142,6 +153,8 @@ struct FStats4 {
 };
 template <int RELU>
 struct FInBwd4 {
+    static constexpr bool kDoubleTree = false;
+    static constexpr int kMinWaves = 4;
     const float4* x;
     const float* mr;
     const float4* gy;
@@ -162,6 +175,8 @@ struct FInBwd4 {
 };
 template <int RELU>
 struct FSpadeBwd4 {
+    static constexpr bool kDoubleTree = false;
+    static constexpr int kMinWaves = 3;           // four tensors read and two written per element: 128 registers would spill
     const float4* x;
     const float* mr;
     const float4* gamma;
@@ -719,7 +734,7 @@ extern "C" int vqw_inorm_bwd_parts(const float* x, const float* mean_rstd, const
 // Backward of TWO InstanceNorms that receive the SAME gradient (the two branches in front of a ResBlock tail: a with
 // its ReLU, b without): one reduction and one apply kernel read the common gradient once instead of twice each.
 // Arithmetic per element is that of vqw_inorm_bwd.
-__global__ void __launch_bounds__(256) k_inorm_bwd_pair_reduce4(const float4* __restrict__ xa, const float* __restrict__ mra,
+__global__ void __launch_bounds__(256, 4) k_inorm_bwd_pair_reduce4(const float4* __restrict__ xa, const float* __restrict__ mra,
                                                                 const float4* __restrict__ xb, const float* __restrict__ mrb,
                                                                 const float4* __restrict__ gy, double* __restrict__ parta,
                                                                 double* __restrict__ partb, int HW, int C, int splits) {

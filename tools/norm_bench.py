@@ -12,7 +12,18 @@ import torch  # noqa: E402
 from hipops import ops  # noqa: E402
 
 dev = "cuda"
-for C, S in ((32, 256), (16, 256), (64, 128), (128, 64), (256, 32)):
+SHAPES = ((32, 256), (16, 256), (64, 128), (128, 64), (256, 32))
+if len(sys.argv) > 2:          # one shape: norm_bench.py C S   (under rocprofv3 --stats: per-kernel durations of that shape,
+    SHAPES = ((int(sys.argv[1]), int(sys.argv[2])),)      # with a plain copy and a plain add of the same tensors beside them)
+    C, S = SHAPES[0]
+    a = torch.randn(32, C, S, S, device=dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn_like(a)
+    c = torch.empty_like(a)
+    for _ in range(20):
+        c.copy_(a)
+        torch.add(a, b, out=c)
+        ops.add(a, b)
+for C, S in SHAPES:
     x = torch.randn(32, C, S, S, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     g = torch.randn_like(x)
     for _ in range(3):
