@@ -139,12 +139,120 @@ __global__ void __launch_bounds__(256, F4::kMinWaves) k_plane_reduce4(F4 f, doub
     }
 }
 
+// Pipelined form of k_plane_reduce4 for C4 = C / 4 a power of two <= 256 (round 4).  The form above lives too short: a
+// workgroup streams 8 elements per thread in two dependent load-wait-add rounds, then pays two barriers and a serial LDS fold
+// by C4 of its 256 threads - loads are in flight ~60 % of a wave's life and the pure-read passes ran at 3.6-4.4 TB/s beside
+// 5.8-6.5 for the apply passes.  Here a workgroup walks a longer pixel range (splits sized for ~4 workgroups per CU), the
+// NEXT group of four pixels is loaded before the current one is evaluated (two register sets), four elements are summed in
+// fp32 before they join the double accumulators (functors that need doubles throughout keep them), and the fold over the
+// pixel rows of a workgroup runs through wave shuffles, then one small LDS stage over the four waves.
+// Thread t: channel quad c4 = t & (C4 - 1), pixel row r = t >> lgC4 of R = 256 / C4; lanes of a wave that share c4 differ
+// in the bits >= lgC4 of the lane number.
+template <class F4>
+__global__ void __launch_bounds__(256, F4::kMinWaves) k_plane_reduce4p(F4 f, double* __restrict__ part, int HW, int C4, int lgC4,
+                                                                       int splits) {
+    __shared__ double sm[4][8][64];            // [wave][a0..a3, b0..b3][lane]
+    const int n = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
+    const int c4 = t & (C4 - 1), r = t >> lgC4, R = 256 >> lgC4;
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = s * per;
+    const int p1 = (p0 + per < HW) ? p0 + per : HW;
+    float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f), m1 = m0;
+    f.consts(n, c4, m0, m1);
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    const long nb = (long)n * HW;
+    typename F4::Raw cur[4], nxt[4];
+    int p = p0 + r;
+    bool have = p + 3 * R < p1;
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.load((nb + p + u * R) * C4 + c4, nb + p + u * R, c4, cur[u]);
+    }
+    while (have) {
+        const int pn = p + 4 * R;
+        const bool more = pn + 3 * R < p1;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) f.load((nb + pn + u * R) * C4 + c4, nb + pn + u * R, c4, nxt[u]);
+        }
+        float ea[4][4], eb[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f.eval(cur[u], nb + p + u * R, c4, m0, m1, ea[u], eb[u]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (F4::kDoubleTree) {
+                a[k] += ((double)ea[0][k] + (double)ea[1][k]) + ((double)ea[2][k] + (double)ea[3][k]);
+                b[k] += ((double)eb[0][k] + (double)eb[1][k]) + ((double)eb[2][k] + (double)eb[3][k]);
+            } else {
+                a[k] += (double)((ea[0][k] + ea[1][k]) + (ea[2][k] + ea[3][k]));
+                b[k] += (double)((eb[0][k] + eb[1][k]) + (eb[2][k] + eb[3][k]));
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = nxt[u];
+        }
+        p = pn;
+        have = more;
+    }
+    for (; p < p1; p += R) {                    // remainder: fewer than four pixel rows left
+        typename F4::Raw one;
+        float ea[4], eb[4];
+        f.load((nb + p) * C4 + c4, nb + p, c4, one);
+        f.eval(one, nb + p, c4, m0, m1, ea, eb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] += (double)ea[k]; b[k] += (double)eb[k]; }
+    }
+    // fold over the pixel rows: lanes that share c4 inside a wave (xor offsets C4, 2 C4, ... < 64), then the four waves
+    const int lane = t & 63, w = t >> 6;
+    for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] += __shfl_xor(a[k], off, 64); b[k] += __shfl_xor(b[k], off, 64); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sm[w][k][lane] = a[k]; sm[w][4 + k][lane] = b[k]; }
+    __syncthreads();
+    // C4 <= 64: every wave holds every channel quad in its lanes 0..C4-1; C4 = 128 / 256: quad c4 lives in lane c4 & 63 of
+    // the waves w with (w * 64 + lane) & (C4 - 1) == c4
+    if (t < C4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double ta = 0.0, tb = 0.0;
+            if (C4 <= 64) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { ta += sm[v][k][t]; tb += sm[v][4 + k][t]; }
+            } else {
+                for (int v = t >> 6; v < 4; v += C4 >> 6) { ta += sm[v][k][t & 63]; tb += sm[v][4 + k][t & 63]; }
+            }
+            double* o = part + (((long)n * splits + s) * (4 * C4) + 4 * t + k) * 2;
+            o[0] = ta;
+            o[1] = tb;
+        }
+    }
+}
+// splits of the pipelined form: ~1024 workgroups in all, at least 8 pixel-row groups (32 R pixels) each, at most one lane
+// per split in the finalise kernels
+static inline int plane_splits_p(int N, int HW, int C4) {
+    const int R = 256 / C4;
+    int s = ceil_div(1024, N);
+    s = imin(s, imax(1, HW / (32 * R)));
+    s = imin(s, PLANE_MAX_SPLITS);
+    return imax(s, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // InstanceNorm
 struct FStats4 {
     static constexpr bool kDoubleTree = true;
     static constexpr int kMinWaves = 4;
     const float4* x;
+    struct Raw { float4 v; };
+    __device__ void consts(int, int, float4&, float4&) const {}
+    __device__ void load(long i4, long, int, Raw& r) const { r.v = x[i4]; }
+    __device__ void eval(const Raw& r, long, int, const float4&, const float4&, float* a, float* b) const {
+        a[0] = r.v.x; a[1] = r.v.y; a[2] = r.v.z; a[3] = r.v.w;
+        b[0] = r.v.x * r.v.x; b[1] = r.v.y * r.v.y; b[2] = r.v.z * r.v.z; b[3] = r.v.w * r.v.w;
+    }
     __device__ void operator()(long i4, long, int, int, float* a, float* b) const {
         float4 v = x[i4];
         a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
@@ -159,6 +267,22 @@ struct FInBwd4 {
     const float* mr;
     const float4* gy;
     int C, gcs4, gco4;
+    struct Raw { float4 v, g; };
+    __device__ void consts(int n, int c4, float4& m0, float4& m1) const {
+        const float4* m = (const float4*)(mr + 2 * ((long)n * C + 4 * c4));
+        m0 = m[0]; m1 = m[1];
+    }
+    __device__ void load(long i4, long pix, int c4, Raw& r) const { r.v = x[i4]; r.g = gy[pix * gcs4 + gco4 + c4]; }
+    __device__ void eval(const Raw& r, long, int, const float4& m0, const float4& m1, float* a, float* b) const {
+        const float xh[4] = {(r.v.x - m0.x) * m0.y, (r.v.y - m0.z) * m0.w, (r.v.z - m1.x) * m1.y, (r.v.w - m1.z) * m1.w};
+        const float gg[4] = {r.g.x, r.g.y, r.g.z, r.g.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float q = (RELU && !(xh[k] > 0.f)) ? 0.f : gg[k];
+            a[k] = q;
+            b[k] = q * xh[k];
+        }
+    }
     // i4 = (pix * C4 + c4) with pix = n * HW + p the pixel of the batch, c = 4 * c4 (no integer division per element)
     __device__ void operator()(long i4, long pix, int n, int c, float* a, float* b) const {
         const float4* m = (const float4*)(mr + 2 * ((long)n * C + c));
@@ -176,7 +300,7 @@ struct FInBwd4 {
 template <int RELU>
 struct FSpadeBwd4 {
     static constexpr bool kDoubleTree = false;
-    static constexpr int kMinWaves = 3;           // four tensors read and two written per element: 128 registers would spill
+    static constexpr int kMinWaves = 2;           // four tensors read per element, two register sets of four elements: 128 float4 registers in flight
     const float4* x;
     const float* mr;
     const float4* gamma;
@@ -185,6 +309,34 @@ struct FSpadeBwd4 {
     float4* dgamma;
     float4* dbeta;
     int C4, gbs4;     // channels / 4, gamma-beta pixel stride / 4
+    struct Raw { float4 v, g, ga, be; };
+    __device__ void consts(int, int c4, float4& m0, float4& m1) const {
+        const float4* m = (const float4*)(mr + 8 * c4);
+        m0 = m[0]; m1 = m[1];
+    }
+    __device__ void load(long i4, long pix, int c4, Raw& r) const {
+        r.v = x[i4]; r.g = gy[i4]; r.ga = gamma[pix * gbs4 + c4];
+        r.be = RELU ? beta[pix * gbs4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ void eval(const Raw& r, long pix, int c4, const float4& m0, const float4& m1, float* a, float* b) const {
+        const float xh[4] = {(r.v.x - m0.x) * m0.y, (r.v.y - m0.z) * m0.w, (r.v.z - m1.x) * m1.y, (r.v.w - m1.z) * m1.w};
+        const float gg[4] = {r.g.x, r.g.y, r.g.z, r.g.w}, gm[4] = {1.f + r.ga.x, 1.f + r.ga.y, 1.f + r.ga.z, 1.f + r.ga.w};
+        const float bb[4] = {r.be.x, r.be.y, r.be.z, r.be.w};
+        float dg[4], db[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float q = gg[k];
+            if (RELU && !(xh[k] * gm[k] + bb[k] > 0.f)) q = 0.f;
+            dg[k] = q * xh[k];
+            db[k] = q;
+            const float dxh = q * gm[k];
+            a[k] = dxh;
+            b[k] = dxh * xh[k];
+        }
+        const long j4 = pix * gbs4 + c4;
+        dgamma[j4] = make_float4(dg[0], dg[1], dg[2], dg[3]);
+        dbeta[j4] = make_float4(db[0], db[1], db[2], db[3]);
+    }
     __device__ void operator()(long i4, long pix, int, int c, float* a, float* b) const {
         const float4* m = (const float4*)(mr + 2 * c);
         const long j4 = pix * gbs4 + (c >> 2);
@@ -304,6 +456,19 @@ __global__ void k_inorm_bwd_apply4(const float4* __restrict__ x, const float* __
 // 16-byte loads per tensor in flight per thread.
 static inline int ilog2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
 static inline bool walk_ok(int C4) { return C4 >= 1 && C4 <= 256 && ilog2_exact(C4) >= 0; }
+// the float4 plane reduction in its pipelined form where C4 allows; returns the number of splits it wrote
+template <class F4>
+static int launch_plane_reduce4(F4 f, double* part, int N, int HW, int C, hipStream_t st) {
+    const int C4 = C / 4;
+    if (walk_ok(C4)) {
+        const int sp = plane_splits_p(N, HW, C4);
+        k_plane_reduce4p<<<dim3(sp, N), 256, 0, st>>>(f, part, HW, C4, ilog2_exact(C4), sp);
+        return sp;
+    }
+    const int sp = plane_splits(N, HW);
+    k_plane_reduce4<<<dim3(sp, N), 256, 0, st>>>(f, part, HW, C, sp);
+    return sp;
+}
 static inline int walk_blocks(int N, int HW, int C4) {       // workgroups per image: ~2048 in all, each >= one 4 R-pixel step
     const int R = 256 / C4;
     int per = ceil_div(2048, N);
@@ -563,7 +728,7 @@ extern "C" int vqw_inorm_stats(const float* x, float* mean_rstd, void* ws, size_
     int splits = plane_splits(N, HW);
     if ((C & 3) == 0 && al16(x)) {
         FStats4 f{(const float4*)x};
-        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+        splits = launch_plane_reduce4(f, (double*)ws, N, HW, C, st);
     } else {
         FStats f{x};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
@@ -589,7 +754,7 @@ extern "C" int vqw_inorm_fwd(const float* x, float* y, int y_cstride, int y_coff
     int splits = plane_splits(N, HW);
     if ((C & 3) == 0 && al16(x)) {
         FStats4 f{(const float4*)x};
-        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+        splits = launch_plane_reduce4(f, (double*)ws, N, HW, C, st);
     } else {
         FStats f{x};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
@@ -673,10 +838,10 @@ extern "C" int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float
     const bool vec = (C & 3) == 0 && (gy_cstride & 3) == 0 && (gy_coff & 3) == 0 && al16(x) && al16(gy) && al16(mean_rstd);
     if (vec && relu) {
         FInBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gy, C, gy_cstride / 4, gy_coff / 4};
-        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
+        splits = launch_plane_reduce4(f, part, N, HW, C, st);
     } else if (vec) {
         FInBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gy, C, gy_cstride / 4, gy_coff / 4};
-        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
+        splits = launch_plane_reduce4(f, part, N, HW, C, st);
     } else if (relu) {
         FInBwd<1> f{x, mean_rstd, gy, C, gy_cstride, gy_coff};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, part, HW, C, splits);
@@ -928,7 +1093,7 @@ extern "C" int vqw_bn_partial_stats(const float* x, double* sums, void* ws, size
     int splits = plane_splits(N, HW);
     if ((C & 3) == 0 && al16(x)) {
         FStats4 f{(const float4*)x};
-        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+        splits = launch_plane_reduce4(f, (double*)ws, N, HW, C, st);
     } else {
         FStats f{x};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
@@ -1091,10 +1256,10 @@ extern "C" int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, cons
     const bool vec = (C & 3) == 0 && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(gy) && al16(dgamma) && al16(dbeta) && al16(mean_rstd);
     if (vec && relu) {
         FSpadeBwd4<1> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta, C / 4, gb_stride / 4};
-        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+        splits = launch_plane_reduce4(f, (double*)ws, N, HW, C, st);
     } else if (vec) {
         FSpadeBwd4<0> f{(const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (const float4*)gy, (float4*)dgamma, (float4*)dbeta, C / 4, gb_stride / 4};
-        k_plane_reduce4<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
+        splits = launch_plane_reduce4(f, (double*)ws, N, HW, C, st);
     } else if (relu) {
         FSpadeBwd<1> f{x, mean_rstd, gamma, beta, gy, dgamma, dbeta, C, gb_stride};
         k_plane_reduce<<<dim3(splits, N), 256, 0, st>>>(f, (double*)ws, HW, C, splits);
