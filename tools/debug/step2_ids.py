@@ -34,6 +34,17 @@ for s in range(3):
         top = sc.topk(2, dim=1)
         gap_hip = (top.values[:, 0] - top.values[:, 1]).reshape(B, H, W).cpu().numpy()
         arg_hip = top.indices[:, 0].reshape(B, H, W).cpu().numpy()
+    f_tr = tr.encoder.feature_extraction(x2).detach()          # grad mode: the training forward's kernels
+    from hipops import ops
+    q, _, ids_k = ops.vq_quantize(f_tr, e, tr.encoder.vq.cluster_size, tr.encoder.vq.embed_avg, False, 0.999, 1e-5, id_base=1)
+    ids_k = ids_k.cpu().numpy()
+    flat_tr = f_tr.permute(0, 2, 3, 1).reshape(-1, D)
+    sc_tr = 2 * flat_tr @ e.t() - (e * e).sum(1)[None] - (flat_tr * flat_tr).sum(1)[:, None]
+    arg_tr = sc_tr.argmax(1).reshape(B, H, W).cpu().numpy() + 1
+    print("step", s, "max |f_nograd - f_train| %.3e; VQ kernel vs torch argmax on train features: %d differ; torch(train) vs torch(nograd): %d differ"
+          % (float((f - f_tr).abs().max()), int((ids_k != arg_tr).sum()), int((arg_tr != arg_hip + 1).sum())))
+    for b in np.argwhere(ids_k != arg_tr)[:5]:
+        b = tuple(b); print("   kernel/torch mismatch at", b, ids_k[b], arg_tr[b], "scores", sc_tr.reshape(B, H, W, -1)[b].cpu().numpy().round(4))
     out = tr.training_step({"image": img}, noise=noi)
     torch.cuda.synchronize()
     for v in ("1", "2"):
