@@ -345,7 +345,16 @@ def gen_step(name, enc_filters, dec_filters, K, size, batch, n_steps, seed, mome
         # the views of ref_first_step, before the step moves the codebook (every step: later steps of a warm fixture are
         # held to bit-equal ids where the reference's own gap is clear, like step 0)
         d["step%d/gap_1" % s] = npy(ref_vq_gaps(enc, image))
-        d["step%d/gap_2" % s] = npy(ref_vq_gaps(enc, torch.flip(image, dims=[3]) + noise))
+        # view 2 is quantised AFTER view 1's call has moved the codebook (enc(n1) then enc(n2) in ref_first_step, as in
+        # single_window_trainer.py:84-85): its decision gaps are those under that intermediate codebook - a copy of the encoder
+        # takes view 1's call.  (Round 3 took them under the codebook before the step: off by the EMA update, enough to call a
+        # near-tie of the real decision "clear" - found in round 4 when one such pixel of step 2 flipped.)
+        import copy
+        enc_mid = copy.deepcopy(enc)
+        with torch.no_grad():
+            enc_mid(image, rank=0)
+        d["step%d/gap_2" % s] = npy(ref_vq_gaps(enc_mid, torch.flip(image, dims=[3]) + noise))
+        d["step%d/gap_2_before_view1" % s] = npy(ref_vq_gaps(enc, torch.flip(image, dims=[3]) + noise))
         out, grads = ref_first_step(enc, dec, eopt, dopt, image, noise, cfg)
         if s == 0:
             # principled gradient gate (tests/helpers.py::check_grads_vs_fp64): 256 sampled entries of the fp64 gradient and

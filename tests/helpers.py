@@ -20,16 +20,19 @@ def assert_close(a, b, rtol, what="", atol=0.0):
     assert d <= bound, "%s: |diff| %.3e > bound %.3e (rel %.3e)" % (what, d, bound, d / (float(b.norm()) + 1e-30))
 
 
-def assert_ids_equal_where_clear(ids, ref_ids, gap, what=""):
+def assert_ids_equal_where_clear(ids, ref_ids, gap, what="", rel=1e-4):
     """Codebook indices must be BIT-EXACT wherever the reference's top-1 / top-2 score gap is clear of fp32 rounding
     (gap > 1e-4 * (1 + |gap|), the bar of DESIGN.md section 2); the remaining pixels - score ties to rounding in the
     reference itself - must still agree almost everywhere.  `gap` comes from the reference (fixture key `.../gap*`) or,
-    where the reference cannot travel, from the oracle."""
+    where the reference cannot travel, from the oracle.  `rel`: 1e-4 while both sides hold bit-identical weights (step 0, eval);
+    later training steps pass 2e-3 - after s optimiser steps the two sides' features differ by ~1e-4 (measured: reconstructions
+    6e-5 ... 9e-5 apart), which moves a score gap by up to ~1e-3.  For view 2 the gap is the one under the codebook AFTER view
+    1's EMA update of the same step (make_golden.py), the codebook its decision is really taken with."""
     ids = np.asarray(ids.detach().cpu() if torch.is_tensor(ids) else ids)
     ref_ids = np.asarray(ref_ids.detach().cpu() if torch.is_tensor(ref_ids) else ref_ids)
     gap = np.asarray(gap.detach().cpu() if torch.is_tensor(gap) else gap, dtype=np.float64)
     assert ids.shape == ref_ids.shape == gap.shape, "%s: shapes %s %s %s" % (what, ids.shape, ref_ids.shape, gap.shape)
-    clear = gap > 1e-4 * (1.0 + np.abs(gap))
+    clear = gap > rel * (1.0 + np.abs(gap))
     bad = clear & (ids != ref_ids)
     assert not bad.any(), "%s: %d ids differ on tie-free pixels (smallest gap among them %.3e)" % (what, int(bad.sum()), float(gap[bad].min()))
     assert np.mean(ids == ref_ids) > 0.999, "%s: agreement %.5f" % (what, np.mean(ids == ref_ids))

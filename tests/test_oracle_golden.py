@@ -253,7 +253,7 @@ def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, s
         ref = g["step%d/ids_%s" % (s, v)]
         if ids_spread == 0.0:       # the reference reproduces its ids: bit-equal wherever its top-1 / top-2 gap is clear
             rep["ids_" + v] = float(np.mean(ids != ref))
-            assert_ids_equal_where_clear(ids, ref, g["step%d/gap_%s" % (s, v)], "%s ids_%s step %d" % (what, v, s))
+            assert_ids_equal_where_clear(ids, ref, g["step%d/gap_%s" % (s, v)], "%s ids_%s step %d" % (what, v, s), rel=2e-3)
         else:                       # (one flipped Adam sign in the encoder moves a handful of pixels across a code boundary)
             hold("ids_" + v, float(np.mean(ids != ref)), F * ids_spread + 5e-3, "(fraction of differing ids, reference spread %.4f)" % ids_spread)
     for v in ("1", "2"):
