@@ -256,6 +256,15 @@ def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, s
             assert_ids_equal_where_clear(ids, ref, g["step%d/gap_%s" % (s, v)], "%s ids_%s step %d" % (what, v, s), rel=2e-3)
         else:                       # (one flipped Adam sign in the encoder moves a handful of pixels across a code boundary)
             hold("ids_" + v, float(np.mean(ids != ref)), F * ids_spread + 5e-3, "(fraction of differing ids, reference spread %.4f)" % ids_spread)
+    # A code that differs on a pixel whose gap is NOT clear (allowed above) is a different decoder input: the quantised map is
+    # piecewise constant and the decoder's low-resolution InstanceNorm planes have almost no variance, so ONE flipped pixel of
+    # 8 192 moves that view's reconstruction by 16 % (measured, round 4) and with it this step's decoder gradients, parameter
+    # update and BatchNorm statistics.  Those are then held to the bounds of the reference's non-reproducible regime; with
+    # identical ids - the usual case - they are held tightly.
+    flipped = stable and any(rep["ids_" + v] > 0.0 for v in ("1", "2"))
+    rep["ids_flipped_on_near_ties"] = float(flipped)
+    if flipped:
+        recon_floor, state_floor_bn = 0.5, 5e-3
     for v in ("1", "2"):
         hold("recon_" + v, rel_err(out["recon_" + v], g["step%d/recon_%s" % (s, v)]), max(F * rsp, recon_floor))
     for key in ("vq.embed", "vq.cluster_size", "vq.embed_avg"):
@@ -266,8 +275,8 @@ def check_later_step(g, s, out, PE, PD, lr, loss_floor=5e-4, recon_floor=5e-3, s
              max(F * sp(key), state_floor))
     bn = torch.cat([v.detach().reshape(-1).float().cpu() for k, v in PD.items() if "running_" in k])
     # (chaotic regime: the running statistics follow the decoder's activations, which differ by tens of per cent: floor 5e-3)
-    hold("bn", rel_err(bn, g["step%d/bn_running" % s]), max(F * sp("bn"), state_floor if stable else 5e-3), "(BatchNorm running statistics, spread %.3e)" % sp("bn"))
-    if stable:
+    hold("bn", rel_err(bn, g["step%d/bn_running" % s]), max(F * sp("bn"), state_floor if (stable and not flipped) else 5e-3), "(BatchNorm running statistics, spread %.3e)" % sp("bn"))
+    if stable and not flipped:
         # the reference's trajectory is reproducible: parameters after Adam's step t = s + 1, elementwise on the sampled entries.
         # An update is ~lr whatever |g|; elements whose gradient is rounding noise move at random, so the statistic is the
         # fraction of sampled entries within 0.1 lr, over parameters with a real gradient
