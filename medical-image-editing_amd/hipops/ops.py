@@ -411,8 +411,6 @@ def refresh_weight_caches(params):
                 side = _prefetch_streams[p.device.index] = torch.cuda.Stream(device=p.device)
                 _prefetch_ids.add(side.cuda_stream)
             _prefetch_joined.clear()
-            if os.environ.get("VQW_WEIGHT_PREFETCH", "1") == "2":      # measurement aid: rebuild on the calling stream
-                side = main
             side.wait_stream(main)             # behind the optimiser's update kernels
             ctx = torch.cuda.stream(side)
             ctx.__enter__()
