@@ -366,15 +366,8 @@ def _cached(weight, key, build, deps=()):
     cur = torch.cuda.current_stream()
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
-        if hit[3] != cur:            # built on another stream: order this stream after the build
-            if hit[3].cuda_stream in _prefetch_ids:
-                # ... the prefetch stream: ONE wait per consumer stream and step covers every layout rebuilt there (a wait per
-                # layout - ~280 stream barriers a step - cost 7 % of the step)
-                if cur.cuda_stream not in _prefetch_joined:
-                    cur.wait_stream(hit[3])
-                    _prefetch_joined.add(cur.cuda_stream)
-            else:
-                cur.wait_event(hit[2])
+        if hit[3] != cur:            # built on another stream (the other view, the prefetch stream): order this stream after the build
+            cur.wait_event(hit[2])
         return hit[1]
     val = build()
     cache[key] = (tag, val, cur.record_event(), cur, build, deps)
@@ -387,8 +380,6 @@ def _cached(weight, key, build, deps=()):
 # VQW_WEIGHT_PREFETCH=0: lazy rebuilds only.
 WEIGHT_PREFETCH = os.environ.get("VQW_WEIGHT_PREFETCH", "1") != "0"
 _prefetch_streams = {}
-_prefetch_ids = set()           # raw handles of the prefetch streams
-_prefetch_joined = set()        # consumer streams that have waited for the prefetch stream since the last refresh
 _PREFETCH_ORDER = ("cat", "dgrad", "wino", "up2", "cat_dgrad", "cat_wino", "wino_dgrad", "cat_wino_dgrad")
 weight_prefetch_builds = 0      # layouts rebuilt ahead of their use (tests)
 
@@ -409,8 +400,6 @@ def refresh_weight_caches(params):
             side = _prefetch_streams.get(p.device.index)
             if side is None:
                 side = _prefetch_streams[p.device.index] = torch.cuda.Stream(device=p.device)
-                _prefetch_ids.add(side.cuda_stream)
-            _prefetch_joined.clear()
             side.wait_stream(main)             # behind the optimiser's update kernels
             ctx = torch.cuda.stream(side)
             ctx.__enter__()
