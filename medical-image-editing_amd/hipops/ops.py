@@ -356,9 +356,7 @@ _CACHE_ON = os.environ.get("VQW_WEIGHT_CACHE", "1") != "0"
 
 
 def _cached(weight, key, build, deps=()):
-    """`deps`: further tensors the derived value is built from (concatenated convs).  `build` must derive the value from the
-    parameters themselves (a derived layout it needs comes from its own _cached call inside): refresh_weight_caches() calls it
-    again after the parameters have moved."""
+    """`deps`: further tensors the derived value is built from (concatenated convs)."""
     if not _CACHE_ON:
         return build()
     cache = weight.__dict__.setdefault("_vqw_cache", {})
@@ -366,51 +364,12 @@ def _cached(weight, key, build, deps=()):
     cur = torch.cuda.current_stream()
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
-        if hit[3] != cur:            # built on another stream (the other view, the prefetch stream): order this stream after the build
+        if hit[3] != cur:            # built on another stream (the other view): order this stream after the build
             cur.wait_event(hit[2])
         return hit[1]
     val = build()
-    cache[key] = (tag, val, cur.record_event(), cur, build, deps)
+    cache[key] = (tag, val, cur.record_event(), cur)
     return val
-
-
-# Derived weight layouts (dgrad-packed, Winograd U, collapsed up-sampled forms, the gamma | beta concatenation: ~140 short
-# launches per step) are rebuilt right after the optimiser step on a side stream, beside the first kernels of the next step,
-# instead of lazily at their first use - which sits on the dependency chain of the first view's forward / backward pass.
-# VQW_WEIGHT_PREFETCH=0: lazy rebuilds only.
-WEIGHT_PREFETCH = os.environ.get("VQW_WEIGHT_PREFETCH", "1") != "0"
-_prefetch_streams = {}
-_PREFETCH_ORDER = ("cat", "dgrad", "wino", "up2", "cat_dgrad", "cat_wino", "wino_dgrad", "cat_wino_dgrad")
-weight_prefetch_builds = 0      # layouts rebuilt ahead of their use (tests)
-
-
-def refresh_weight_caches(params):
-    """Rebuild every derived layout the given parameters have cached (call after the optimiser steps, on the stream that
-    ran them).  A layout nobody has used yet is not invented; one whose parameter has not changed is kept."""
-    global weight_prefetch_builds
-    if not (WEIGHT_PREFETCH and _CACHE_ON):
-        return
-    main = None
-    for p in params:
-        cache = p.__dict__.get("_vqw_cache")
-        if not cache or not p.is_cuda:
-            continue
-        if main is None:
-            main = torch.cuda.current_stream(p.device)
-            side = _prefetch_streams.get(p.device.index)
-            if side is None:
-                side = _prefetch_streams[p.device.index] = torch.cuda.Stream(device=p.device)
-            side.wait_stream(main)             # behind the optimiser's update kernels
-            ctx = torch.cuda.stream(side)
-            ctx.__enter__()
-        for key in _PREFETCH_ORDER:
-            ent = cache.get(key)
-            if ent is not None and len(ent) >= 6:
-                before = cache[key][1]
-                _cached(p, key, ent[4], ent[5])
-                weight_prefetch_builds += cache[key][1] is not before
-    if main is not None:
-        ctx.__exit__(None, None, None)
 
 
 def _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, acc, collapsed, defer_fold=False):
@@ -566,8 +525,8 @@ class _Conv2d(torch.autograd.Function):
                 _L().vqw_conv3x3_up2_supported(Cin, Cout, N, H // 2, W // 2):
             L = _L()
 
-            def _collapse():     # (captures the parameter only: the entry outlives this forward pass)
-                buf = _ws(L.vqw_conv3x3_up2_ws_bytes(Cin, Cout), w)
+            def _collapse():
+                buf = _ws(L.vqw_conv3x3_up2_ws_bytes(Cin, Cout), x0)
                 _lib.check(L.vqw_conv3x3_up2_prepare(_p(w), _p(buf), buf.numel(), Cin, Cout, _st()), "vqw_conv3x3_up2_prepare")
                 return buf
             up_ws = _cached(weight, "up2", _collapse)
@@ -740,8 +699,8 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             if group is not None:
                 g0 = group.member_done(g0)
     elif need0 or (need1 and x1 is not None):
-        def _pack():             # (captures the parameter only: the entry outlives this backward pass)
-            buf = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=w.device)
+        def _pack():
+            buf = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
             _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
             return buf
         wt = _cached(w, "dgrad", _pack)
@@ -750,7 +709,7 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             if ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W) \
                     and L.vqw_conv3x3_wino_masked_supported(Cout, Cin, N, H, W):
                 # Winograd form, the shared buffer read and added in the kernel's epilogue
-                ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, _cached(w, "dgrad", _pack), Cout, Cin))
+                ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
                 _lib.check(L.vqw_conv3x3_wino_fwd_acc(_p(gy), _p(ut), _p(group.buf), N, H, W, Cout, Cin, _st()),
                            "vqw_conv3x3_wino_fwd_acc(dgrad)")
                 group_acc_calls += 1
@@ -770,14 +729,14 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             # x0 is the output of an InstanceNorm (+ReLU) and feeds this layer only: the norm's backward sums ride in this launch
             global in_bwd_fused_calls
             nparts = L.vqw_conv3x3_wino_fwd_inbwd_parts(Cout, Cin, N, H, W)
-            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, _cached(w, "dgrad", _pack), Cout, Cin))
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
             bpart = torch.empty(N * nparts * Cin * 2, dtype=torch.float32, device=gy.device)
             xraw, mr, nrelu = in_src
             _lib.check(L.vqw_conv3x3_wino_fwd_inbwd(_p(gy), _p(ut), _p(xraw), _p(mr), int(nrelu), _p(g_full), _p(bpart),
                                                     N, H, W, Cout, Cin, _st()), "vqw_conv3x3_wino_fwd_inbwd(dgrad)")
             _IN_BWD_PARTS.put(g_full, (bpart, nparts, xraw.data_ptr()))
         elif ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W):
-            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, _cached(w, "dgrad", _pack), Cout, Cin))
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
             _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(g_full), N, H, W, Cout, Cin, 0, _st()),
                        "vqw_conv3x3_wino_fwd(dgrad)")
         else:
@@ -956,7 +915,7 @@ class _ConvCat(torch.autograd.Function):
         w, b = _cat_weights(wa, ba, wb, bb)
         if wino_fwd and ks == 3 and _L().vqw_conv3x3_wino_supported(Cin, Ca + Cb, N, H, W):
             L = _L()
-            u = _cached(wa, "cat_wino", lambda: _wino_weights(L, _cat_weights(wa, ba, wb, bb)[0], Cin, Ca + Cb), deps=(wb,))
+            u = _cached(wa, "cat_wino", lambda: _wino_weights(L, w, Cin, Ca + Cb), deps=(wb,))
             y = empty_nhwc(N, Ca + Cb, H, W, x)
             _lib.check(L.vqw_conv3x3_wino_fwd(_p(x), _p(u), _p(b), _p(y), N, H, W, Cin, Ca + Cb, 0, _st()), "vqw_conv3x3_wino_fwd")
         else:
@@ -981,14 +940,13 @@ class _ConvCat(torch.autograd.Function):
         gx = gwa = gba = gwb = gbb = None
         if ctx.needs_input_grad[0]:
             def _pack():
-                wc = _cat_weights(wa, ba, wb, bb)[0]
-                buf = torch.empty(Cin * ks * ks * Ct, dtype=torch.float32, device=wc.device)
-                _lib.check(L.vqw_pack_dgrad_weights(_p(wc), _p(buf), Ct, Cin, ks, _st()), "vqw_pack_dgrad_weights")
+                buf = torch.empty(Cin * ks * ks * Ct, dtype=torch.float32, device=gy.device)
+                _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Ct, Cin, ks, _st()), "vqw_pack_dgrad_weights")
                 return buf
             wt = _cached(wa, "cat_dgrad", _pack, deps=(wb,))
             gx = empty_nhwc(N, Cin, H, W, gy)
             if ks == 3 and L.vqw_conv3x3_wino_supported(Ct, Cin, N, H, W):
-                ut = _cached(wa, "cat_wino_dgrad", lambda: _wino_weights(L, _cached(wa, "cat_dgrad", _pack, deps=(wb,)), Ct, Cin), deps=(wb,))
+                ut = _cached(wa, "cat_wino_dgrad", lambda: _wino_weights(L, wt, Ct, Cin), deps=(wb,))
                 if ctx.relu_in and FUSE_RELU_MASK and L.vqw_conv3x3_wino_masked_supported(Ct, Cin, N, H, W):
                     # the gradient in FRONT of the producer's ReLU: its mask (x > 0) applied in this kernel's epilogue
                     _lib.check(L.vqw_conv3x3_wino_fwd_masked(_p(gy), _p(ut), _p(x), _p(gx), N, H, W, Ct, Cin, _st()),

@@ -239,7 +239,6 @@ class FirstStepTrainer:
             self.reducer.finish()
         self.enc_optim.step()
         self.dec_optim.step()
-        ops.refresh_weight_caches(self._params)      # derived weight layouts of the next step, off its dependency chain
         self.throttle.end()
         return out
 
