@@ -79,7 +79,8 @@ int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const float* src1, 
                          int N, int H, int W, int Cout, int ksize, int dil, void* stream);
 /* y += conv(src0) ('same' conv, no bias): the input gradient of one of several convolutions of the same tensor summed in
  * place (aspp.py:44-47: five branches of one input; autograd would add their gradients pairwise, three passes each).
- * Served for the shapes of the row-chain kernel (dilated 3x3, 32 channels, rows <= 256 pixels): query ..._supported. */
+ * Served for the shapes of the row-chain kernel (dilated 3x3, 32 channels, rows <= 256 pixels) and (ABI 8) for 1x1 layers on
+ * the implicit-GEMM kernel, whose epilogue then adds to y: query ..._supported. */
 int vqw_conv2d_fwd_acc_supported(int C0, int N, int H, int W, int Cout, int ksize, int dil);
 int vqw_conv2d_fwd_acc(const float* src0, int C0, const float* w_ohwi, float* y, int N, int H, int W, int Cout, int ksize,
                        int dil, void* stream);

@@ -146,9 +146,16 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
 // y += conv(src0): the input gradient of one of several convolutions of the same tensor, summed in place (autograd would
 // write each to a tensor of its own and add them pairwise: three more passes over the tensor per extra consumer).
 // Served by the row-chain kernel (dilated 3x3, 32 channels: the atrous pyramid's branches); query ..._supported first.
+// 1 x 1 layers on the implicit-GEMM kernel (its epilogue adds to y when asked): not the stem / head shapes, tensors within
+// the 32-bit descriptor range
+static bool conv_pw_acc_ok(const ConvIn& in, int N, int H, int W, int Cout, int ksize) {
+    return ksize == 1 && !conv_stem_ok(in, Cout, ksize) && !conv_head_ok(in, Cout, ksize) && conv_mfma_fwd_ok(in, Cout, ksize) &&
+           (long)N * H * W * (long)imax(Cout, in.C0) * 4 <= 0xFFFFFFE0L;
+}
 extern "C" int vqw_conv2d_fwd_acc_supported(int C0, int N, int H, int W, int Cout, int ksize, int dil) {
     ConvIn in{nullptr, nullptr, C0, 0, 0};
-    return g_conv_backend == 0 && N > 0 && conv_batch_group(N, H, W, C0, Cout) >= N && conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil) ? 1 : 0;
+    if (g_conv_backend != 0 || N <= 0 || conv_batch_group(N, H, W, C0, Cout) < N) return 0;
+    return (conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil) || conv_pw_acc_ok(in, N, H, W, Cout, ksize)) ? 1 : 0;
 }
 extern "C" int vqw_conv2d_fwd_acc(const float* src0, int C0, const float* w_ohwi, float* y, int N, int H, int W, int Cout,
                                   int ksize, int dil, void* stream) {
@@ -156,6 +163,10 @@ extern "C" int vqw_conv2d_fwd_acc(const float* src0, int C0, const float* w_ohwi
     VQW_CHECK(vqw_conv2d_fwd_acc_supported(C0, N, H, W, Cout, ksize, dil), "vqw_conv2d_fwd_acc: shape not served (query vqw_conv2d_fwd_acc_supported)");
     ConvIn in{src0, nullptr, C0, 0, 0};
     const double px = (double)N * H * W;
+    if (ksize == 1) {
+        ProfScope ps(0, 2.0 * px * Cout * C0, (hipStream_t)stream, 4.0 * (px * C0 + 2.0 * px * Cout + (double)Cout * C0));
+        return conv_mfma_fwd(in, w_ohwi, nullptr, y, N, H, W, Cout, 1, 1, 2, (hipStream_t)stream);      // relu = 2: y += result
+    }
     ProfScope ps(0, 2.0 * px * Cout * 9.0 * C0, (hipStream_t)stream, 4.0 * (px * C0 + 2.0 * px * Cout + 9.0 * Cout * C0));
     return conv_dil_fwd(in, w_ohwi, nullptr, y, N, H, W, Cout, dil, 0, (hipStream_t)stream, nullptr, 1);
 }

@@ -291,7 +291,8 @@ k_conv_mfma_fwd(ConvIn in, const float* __restrict__ w, const float* __restrict_
                         unsigned n = q / (unsigned)H, yh = q - n * H;
                         op = ((size_t)n * 2 * H + 2 * yh + par_y) * (2 * W) + 2 * xw + par_x;
                     }
-                    y[op * Cout + co] = relu ? fmaxf(v, 0.f) : v;
+                    // relu: 0 plain, 1 ReLU, 2 accumulate (y += result: a later member of a gradient group, conv.hip)
+                    y[op * Cout + co] = relu == 1 ? fmaxf(v, 0.f) : (relu == 2 ? y[op * Cout + co] + v : v);
                 }
             }
         }

@@ -715,8 +715,11 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
                 group_acc_calls += 1
                 g_full = None
             elif L.vqw_conv2d_fwd_acc_supported(Cout, N, H, W, Cin, ks, dilation):
+                # row-chain kernel (dilated 3x3) or the implicit-GEMM kernel (1x1): y += conv in the epilogue
                 _lib.check(L.vqw_conv2d_fwd_acc(_p(gy), Cout, _p(wt), _p(group.buf), N, H, W, Cin, ks, dilation, _st()),
                            "vqw_conv2d_fwd_acc")
+                if ks == 1:
+                    group_acc_calls += 1
                 g_full = None
             else:
                 g_full = empty_nhwc(N, Cin, H, W, gy)
@@ -1221,7 +1224,7 @@ def spade_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1
 # ----------------------------------------------------------------------------------------------
 class _Add(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, relu):
+    def forward(ctx, a, b, relu, a_group=None):
         _dev(a, b)
         a, b = nhwc(a), nhwc(b)
         if a.shape != b.shape:
@@ -1229,23 +1232,31 @@ class _Add(torch.autograd.Function):
         y = torch.empty_like(a, memory_format=CL)
         _lib.check(_L().vqw_add(_p(a), _p(b), _p(y), a.numel(), int(relu), _st()), "vqw_add")
         ctx.relu = relu
+        ctx.a_group = a_group
         if relu:
             ctx.save_for_backward(y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        if not ctx.relu:
-            return gy, gy, None
-        (y,) = ctx.saved_tensors
-        gy = nhwc(gy)
-        gx = torch.empty_like(y, memory_format=CL)
-        _lib.check(_L().vqw_relu_bwd(_p(y), _p(gy), _p(gx), y.numel(), _st()), "vqw_relu_bwd")
-        return gx, gx, None
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            gy = nhwc(gy)
+            gx = torch.empty_like(y, memory_format=CL)
+            _lib.check(_L().vqw_relu_bwd(_p(y), _p(gy), _p(gx), y.numel(), _st()), "vqw_relu_bwd")
+            gy = gx
+        if ctx.a_group is not None:
+            # `a` has further consumers that form a gradient group (their backward runs AFTER everything upstream of `b`, which
+            # reads this gradient, has run): this gradient is the group's member - as the first to arrive it becomes the buffer
+            # the others add to in their kernels' epilogues; the last member hands the sum to autograd
+            return ctx.a_group.member_done(nhwc(gy)), gy, None, None
+        return gy, gy, None, None
 
 
-def add(a, b, relu=False):
-    return _Add.apply(a, b, bool(relu))
+def add(a, b, relu=False, a_group=None):
+    """a + b (+ReLU).  a_group: an ops.GradGroup that the OTHER consumers of `a` belong to, sized for them plus this op; `b`
+    must be computed from `a` through those consumers (x + f(x)), so that their backward runs after b's whole chain."""
+    return _Add.apply(a, b, bool(relu), a_group)
 
 
 class _MaxPool2(torch.autograd.Function):

@@ -26,11 +26,22 @@ class ASPP(nn.Module):
         for i, rate in enumerate(rates):
             self.stages.add_module("c{}".format(i + 1), _ConvBnReLU(in_ch, out_ch, 3, 1, padding=rate, dilation=rate))
 
-    def forward(self, x):
+    def forward(self, x, grad_group=None):
+        """grad_group: an ops.GradGroup the caller has sized for this module's five convolutions PLUS its own further
+        consumers of x (the decoder's `x + conv_last(x)`: the residual's gradient seeds the group's buffer)."""
         # every branch normalises straight into its channel slice of the concatenated output
         # (each conv's epilogue leaves the statistics of its branch's norm)
         # the five branches read one tensor: their input gradients are summed in place (ops.GradGroup), not by autograd
         stages = list(self.stages.children())
-        grp = ops.GradGroup(len(stages)) if (torch.is_grad_enabled() and x.requires_grad) else None
-        raw, parts = zip(*[stage.conv(x, want_stats=True, grad_group=grp) for stage in stages])
+        grp = grad_group
+        if grp is None and torch.is_grad_enabled() and x.requires_grad:
+            grp = ops.GradGroup(len(stages))
+        # Autograd runs the branches' backward in reverse order of their creation and only the dilated branches have an
+        # accumulating input-gradient kernel: the 1 x 1 branch is created LAST, so it runs first and its gradient becomes the
+        # group's buffer (created first it ran last and was added by a separate three-pass add kernel).  Output order unchanged.
+        order = list(range(1, len(stages))) + [0]
+        res = {}
+        for i in order:
+            res[i] = stages[i].conv(x, want_stats=True, grad_group=grp)
+        raw, parts = zip(*[res[i] for i in range(len(stages))])
         return ops.instance_norm_cat(list(raw), relu=True, eps=1e-5, parts=parts)

@@ -81,9 +81,12 @@ class ResBlock(nn.Module):
         # x feeds the 1x1 branch and the first 3x3 convolution: their input gradients are summed in the second one's
         # epilogue (ops.GradGroup) instead of by an add pass
         grp = ops.GradGroup(2) if (GRAD_GROUP_BLOCKS and x.requires_grad) else None
+        # (the 1 x 1 branch is created FIRST: autograd then runs it LAST in backward, where its input-gradient kernel adds to the
+        # 3 x 3 convolution's gradient in its epilogue - every shape has that route, while a 16-channel 3 x 3 layer has no
+        # accumulating kernel and its gradient used to be added by a separate three-pass kernel)
         if RES_TAIL_NORM and dc.ends_in_norm_relu() and ds[1].eps == dc.double_conv[4].eps and not ds[1].relu:
-            x2, part2 = dc(x, raw_tail=True, grad_group=grp)
             xid, partid = ds[0](x, want_stats=True, grad_group=grp)
+            x2, part2 = dc(x, raw_tail=True, grad_group=grp)
             got = ops.res_tail_norm(x2, xid, eps=ds[1].eps, part2=part2, partid=partid)
             if got is not None:
                 return got

@@ -65,6 +65,10 @@ class UNetDecoder(nn.Module):
             x = self.double_conv2(x)
             for u, d_skip, m in zip(self.up_convs, d_skips, maps):
                 x = u(x, d_skip, maps=m)
-            out = ops.add(x, self.conv_last(x))
+            # x feeds the residual and the pyramid's five convolutions: ONE gradient group - the residual's gradient is the
+            # buffer the branches' input-gradient kernels add to (no add pass by autograd: ops.add(..., a_group=))
+            aspp, dc = self.conv_last[0], self.conv_last[1]
+            grp = ops.GradGroup(len(list(aspp.stages.children())) + 1) if (ops.GRAD_GROUPS and torch.is_grad_enabled() and x.requires_grad) else None
+            out = ops.add(x, dc(aspp(x, grad_group=grp)), a_group=grp)
             out = self.conv1x1(out)
             return ops.tanh(out)
