@@ -1784,6 +1784,7 @@ def test_full_size_epilogue_fusions_agree_with_the_separate_passes(monkeypatch):
         monkeypatch.setattr(ops, "FUSE_RELU_MASK", fused)
         monkeypatch.setattr(ops, "FUSE_IN_BWD", fused)
         monkeypatch.setattr(B_, "GRAD_GROUP_BLOCKS", fused)
+        monkeypatch.setattr(ops, "GRAD_GROUPS", fused)       # (the pyramid's group and its residual seed, round 4)
         torch.manual_seed(0)
         tr = FirstStepTrainer(device=DEV)
         img, noise = bench.synthetic_batch(8, 256, 77, torch.device(DEV))
