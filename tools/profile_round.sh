@@ -1,17 +1,17 @@
 # Round profile: bench (default + 20 steps), rocprofv3 kernel summaries of the default and the serialised schedule, the two
 # PMC passes for HBM traffic; config 4 (training step + VQ alone) and config 5 (run_recon) with their kernel summaries.
-#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r03'   ->   gpurun_out/<tag>/...
+#   gpurun --timeout 1200 -- 'bash tools/profile_round.sh r04'   ->   gpurun_out/<tag>/...
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-# HBM traffic first: the bench lines below read profiles/r03_hbm_traffic.json (tied to the sources by digest)
+# HBM traffic first: the bench lines below read profiles/r04_hbm_traffic.json (tied to the sources by digest)
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 echo "fetch done"
 timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_write.json 2> $O/pmc_write.err
 echo "write done"
-python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $R/profiles/r03_hbm_traffic.json > $O/hbm_traffic.txt
-cp $R/profiles/r03_hbm_traffic.json $O/hbm_traffic.json
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $R/profiles/r04_hbm_traffic.json > $O/hbm_traffic.txt
+cp $R/profiles/r04_hbm_traffic.json $O/hbm_traffic.json
 echo "traffic done"
 timeout -k 10 500 python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 echo "bench default done"
@@ -19,6 +19,9 @@ timeout -k 10 500 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > 
 echo "bench20 done"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/conc.err
 echo "conc done"
+# per-stream timeline of the last CONCURRENT step of that trace (the run ends with the serialised roofline pass: one warm step + --serial-steps 5 -> steps_back 7)
+F=$(ls $O/conc/*/t_kernel_trace.csv 2>/dev/null | head -1); [ -z "$F" ] && F=$O/conc/t_kernel_trace.csv
+python3 $R/tools/stream_timeline.py $F 5 7 --json $O/stream_timeline.json > $O/stream_timeline.txt || echo "timeline failed"
 export VQW_WGRAD_STREAM=0 VQW_CONCURRENT_VIEWS=0
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ser -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof_serialised.json 2> $O/ser.err
 unset VQW_WGRAD_STREAM VQW_CONCURRENT_VIEWS
