@@ -75,7 +75,10 @@ def test_rccl_world_size_one_equals_plain_step(tmp_path, overlap):
     ProcessGroupNCCL's stream, finish() and the optimiser step.  With one rank every all-reduce is the identity and the mean
     divides by 1, so losses, ids, VQ buffers, BN running statistics, averaged gradients and updated parameters must equal the
     non-distributed step BIT FOR BIT; a missing stream dependency shows up as a difference."""
-    plain = _run(1, tmp_path, "plain1", 29631)[0]
+    # (the overlapped schedule needs a parameter's gradient final when it is announced, so its weight-gradient slabs are folded
+    # call by call; the plain step folds them in one batched launch at the end of the pass - another fixed summation order.
+    # Its reference therefore runs with the batched fold off: VQW_FOLD_DEFER=0)
+    plain = _run(1, tmp_path, "plain1", 29631, extra_env={"VQW_FOLD_DEFER": "0"} if overlap == "1" else None)[0]
     # overlap "0": the gradient buckets are exchanged in finish() (default); "1": launched from inside the backward pass
     rccl = _run(1, tmp_path, "rccl1", 29632, extra_env={"VQW_DP_FORCE": "1", "VQW_TEST_BACKEND": "nccl", "VQW_DP_OVERLAP": overlap})[0]
     assert rccl["backend"] == "nccl" and plain["backend"] == ""
