@@ -228,14 +228,16 @@ extern "C" int vqw_conv2d_wgrad(const float* src0, int C0, int up0, const float*
     {   // > 4 GiB tensors: image groups, the later ones accumulating into dW / dbias (see vqw_conv2d_fwd)
         const int g = conv_batch_group(N, H, W, C0 + C1, Cout);
         if (g < N) {
-            for (int n0 = 0; n0 < N; n0 += g) {
+            // (the groups share ONE workspace: their slab folds must run between them, not be deferred to the end of the pass)
+            const int was = vqw_fold_defer(0);
+            for (int n0 = 0; n0 < N && rc == 0; n0 += g) {
                 const int nn = N - n0 < g ? N - n0 : g;
                 const size_t px = (size_t)n0 * H * W;
                 rc = vqw_conv2d_wgrad(src0 + (up0 ? px / 4 : px) * C0, C0, up0, src1 ? src1 + px * C1 : nullptr, C1, dy + px * Cout,
                                       dw_ohwi, dbias, ws, ws_bytes, nn, H, W, Cout, ksize, dil, (accumulate || n0 > 0) ? 1 : 0, stream);
-                if (rc) return rc;
             }
-            return VQW_OK;
+            vqw_fold_defer(was);
+            return rc;
         }
     }
     ConvIn in{src0, src1, C0, C1, up0};
