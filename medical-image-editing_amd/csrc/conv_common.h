@@ -70,6 +70,10 @@ int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, i
 bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W);
 int conv_wino_wgrad_blocks(const ConvIn& in, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
 bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);
+bool conv_wino32_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);       // (32 co x 32 ci) blocks: Cout % 64 == 32
+int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
+int conv_wino32_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+                      hipStream_t st);
 int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
 int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
                       hipStream_t st);

@@ -811,6 +811,7 @@ bool conv_wino_wgrad_ok(int Cin, int Cout, int N, int H, int W) {
 int conv_wino_wgrad_blocks(const ConvIn& in, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
     const int Cin = in.C0 + in.C1;
     if (conv_wino64_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino64_wgrad_blocks(Cin, Cout, N, H, W, max_slabs, kt_out);
+    if (conv_wino32_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino32_wgrad_blocks(Cin, Cout, N, H, W, max_slabs, kt_out);
     const int nblk = (Cout / 32) * (Cin / 16);
     const int rw = W % 32 == 0 ? 32 : 16;
     const int nsp = N * ceil_div(H, 256 / rw) * (W / rw);
@@ -826,6 +827,7 @@ int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, 
                     hipStream_t st) {
     const int Cin = in.C0 + in.C1;
     if (conv_wino64_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino64_wgrad(in.src0, dy, ws, bpart, N, H, W, Cin, Cout, nsb, kt, st);
+    if (conv_wino32_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino32_wgrad(in.src0, dy, ws, bpart, N, H, W, Cin, Cout, nsb, kt, st);
     constexpr size_t lds = (size_t)(2 * (WW_D + WW_X) + 512 * 4) * sizeof(float);
     static_assert(lds <= 160 * 1024 && lds >= 8 * 512 * sizeof(float), "Winograd wgrad tiles do not fit the LDS");
     static bool attr_set = false;

@@ -1001,6 +1001,304 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad64(W64WgArgs a) {
     }
 }
 
+
+// =====================================================================================================================
+// The same weight-gradient structure for layers whose Cout is a multiple of 32 but not of 64 (round 4): a workgroup owns a
+// (32 co x 32 ci) block of dU.  Wave (r, kh) as above; a k-step is 16 MFMAs (4 xi columns x 2 co blocks x 2 ci blocks, 64
+// accumulators) and its operand build 2 x 4 + 2 x 8 = 24 VALU = 1.5 per MFMA (the 64 x 32 block: 1.0; k_conv_wino_wgrad of
+// conv_wino.hip, which these layers ran on: ~3 with its in-loop address arithmetic).  Two VALU operations and two LDS reads per
+// MFMA position instead of one; everything else - region walk, descriptors that move with the region, edge bits, fold - is
+// the 64-cout kernel's.  32-pixel-wide regions only (the layers concerned live on the 128- and 256-pixel levels).
+constexpr int WH_DP = 40, WH_XP = 40;      // floats per dY pixel (32 co + 8) / X pixel (32 ci + 8): adjacent tiles 16 banks apart
+struct WhGeo {
+    static constexpr int RW = 32, TRP = 4;
+    static constexpr int XW = RW + 2, XR = TRP + 2, XPIX = XR * XW;
+    static constexpr int DBUF = 128 * WH_DP, XBUF = XPIX * WH_XP;
+};
+
+__global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
+    using G = WhGeo;
+    constexpr int RW = 32, NT = 512, DBUF = G::DBUF, XBUF = G::XBUF, XW = G::XW;
+    constexpr int XF = G::XPIX * 8;                        // float4 per X halo: 1632
+    constexpr int LX = (XF + NT - 1) / NT;                 // 4 slots
+    constexpr int LD = 2;                                  // dY: 128 pixels x 8 float4 = 1024 = 2 slots
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // layout: dY tiles [2][DBUF], then X halos [2][XBUF]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = wv & 3, kh = wv >> 2;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk = lb % a.nblk, sblk = lb / a.nblk;
+    const int co_base = (blk / a.n_ci_b) * 32, ci_base = (blk % a.n_ci_b) * 32;
+    const int sp0 = sblk * a.kt;
+    const int my_tiles = min(a.kt, a.nsp - sp0);
+    const int per_img = a.tilesY * a.tilesX;
+    const bool do_bias = a.bias_part != nullptr && ci_base == 0;
+
+    // ---- loader slots ----
+    // dY float4 f = tid + 512 j -> pixel f / 8 = (tid >> 3) + 64 j (two pixel rows per slot), co quad tid & 7
+    const int d_px = tid >> 3;
+    const unsigned d_fix = ((unsigned)((d_px >> 5) * W + (d_px & 31)) * Cout + co_base + (tid & 7) * 4) * 4u;
+    const unsigned d_jstride = (unsigned)(2 * W) * Cout * 4u;
+    const int d_lds = d_px * WH_DP + (tid & 7) * 4;                       // + j * 64 * WH_DP
+    unsigned x_fix[LX];
+    int x_lds[LX];
+    unsigned x_bits = 0;
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+        int f = tid + j * NT;
+        if (f >= XF) f -= XF;
+        const int hp = f >> 3, hy = hp / XW, hx = hp - hy * XW;
+        x_fix[j] = ((unsigned)(hy * W + hx) * Cin + ci_base + (tid & 7) * 4) * 4u;
+        x_lds[j] = 2 * DBUF + hp * WH_XP + (tid & 7) * 4;
+        x_bits |= (unsigned)((hy == 0 ? 1 : 0) | (hy == G::XR - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == XW - 1 ? 8 : 0)) << (4 * j);
+    }
+    float4 rd[LD], rx[LX];
+    float4 bsum;
+    bsum.x = bsum.y = bsum.z = bsum.w = 0.f;
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+        float4 f;
+        unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+        f.x = __uint_as_float(a0); f.y = __uint_as_float(a1); f.z = __uint_as_float(a2); f.w = __uint_as_float(a3);
+        return f;
+    };
+    __amdgpu_buffer_rsrc_t rsd, rsx;
+    unsigned x_edges = 0;
+    auto region_setup = [&](int n, int tx, int ty) {
+        const int y0 = ty * G::TRP, x0 = tx * RW;
+        const long dpix = ((long)n * H + y0) * W + x0;
+        const long doff = dpix * Cout * 4;
+        rsd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + doff), 0, (int)(unsigned)((long)a.nbd - doff), 0x00020000);
+        const long xoff = (dpix - W - 1) * Cin * 4;
+        const long xleft = (long)a.nbx - xoff;
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
+        x_edges = ((y0 == 0 ? 1u : 0u) | (y0 + G::TRP == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + RW == W ? 8u : 0u)) * 0x1111u;
+    };
+    auto issue_d = [&](int j) { rd[j] = ld4(rsd, d_fix, j * d_jstride); };
+    auto issue_x = [&](int j) {
+        const unsigned vo = (x_bits & x_edges & (0xFu << (4 * j))) ? 0xFFFFFFFFu : x_fix[j];
+        rx[j] = ld4(rsx, vo, 0);
+    };
+    float once_v = 1.f;
+    auto commit_d = [&](int j, int buf) {
+        *(float4*)&smem[d_lds + buf * DBUF + j * 64 * WH_DP] = rd[j];
+        if (do_bias) {
+            bsum.x = __builtin_fmaf(once_v, rd[j].x, bsum.x); bsum.y = __builtin_fmaf(once_v, rd[j].y, bsum.y);
+            bsum.z = __builtin_fmaf(once_v, rd[j].z, bsum.z); bsum.w = __builtin_fmaf(once_v, rd[j].w, bsum.w);
+        }
+    };
+    auto commit_x = [&](int j, int buf) { *(float4*)&smem[x_lds[j] + buf * XBUF] = rx[j]; };
+
+    // ---- fragment addressing: lane (channel idx = lane & 15, tile k = lane >> 4 of the k-step) ----
+    const int idx = lane & 15, k = lane >> 4;
+    const int aF = r == 3 ? 1 : 0, aS = r == 0 ? 0 : 1;
+    const int trow0 = kh;
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    const int a_F = opaque(((2 * trow0 + aF) * RW + 2 * k) * WH_DP + idx);
+    const int a_S = opaque(((2 * trow0 + aS) * RW + 2 * k) * WH_DP + idx);
+    const int iA = r == 0 ? 0 : r == 2 ? 2 : 1, iB = r == 0 ? 2 : r == 1 ? 2 : r == 2 ? 1 : 3;
+    const int x_A = opaque(2 * DBUF + ((2 * trow0 + iA) * XW + 2 * k) * WH_XP + idx);
+    const int x_B = opaque(2 * DBUF + ((2 * trow0 + iB) * XW + 2 * k) * WH_XP + idx);
+    float sA, sB;
+    { float s = (r == 1) ? 1.f : (r == 2) ? -1.f : 0.f; asm volatile("v_mov_b32 %0, %1" : "=v"(sA) : "v"(s)); }
+    { float s = (r == 1) ? 1.f : -1.f; asm volatile("v_mov_b32 %0, %1" : "=v"(sB) : "v"(s)); }
+
+    f32x4 acc[4][2][2];                // [xi column][co block][ci block]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[c][mb][nb][q] = 0.f;
+    float dm[2][2][4];                 // [operand set][co block][xi column]
+    float vv[2][2][4];                 // [operand set][ci block][xi column]
+    float ra[2][4], rb[2][8];          // raw LDS values: ra[co group], rb[ci group]
+
+    // groups of a k-step: g = 0, 1 co block g (4 reads, 4 VALU), g = 2, 3 ci block g - 2 (8 reads, 8 VALU)
+    auto rd_grp = [&](int nbuf, int s, int g, int i) {
+        if (g < 2) {
+            const int o = nbuf * DBUF + 8 * s * WH_DP + g * 16 + (i & 1) * WH_DP;
+            ra[g][i] = i < 2 ? smem[a_F + o] : smem[a_S + o];
+        } else {
+            const int o = nbuf * XBUF + 8 * s * WH_XP + (g - 2) * 16 + (i & 3) * WH_XP;
+            rb[g - 2][i] = i < 4 ? smem[x_A + o] : smem[x_B + o];
+        }
+    };
+    auto op_grp = [&](int set, int g, int i) {
+        if (g < 2) {
+            float* d = dm[set][g];
+            const float* q = ra[g];
+            if (i == 0) d[0] = __builtin_fmaf(sA, q[2], q[0]);
+            if (i == 1) d[3] = __builtin_fmaf(sA, q[3], q[1]);
+            if (i == 2) d[1] = d[0] + d[3];
+            if (i == 3) d[2] = d[0] - d[3];
+        } else {
+            float* o = vv[set][g - 2];
+            float* q = rb[g - 2];
+            if (i < 4) q[i] = __builtin_fmaf(sB, q[4 + i], q[i]);
+            if (i == 4) o[0] = q[0] - q[2];
+            if (i == 5) o[1] = q[1] + q[2];
+            if (i == 6) o[2] = q[2] - q[1];
+            if (i == 7) o[3] = q[1] - q[3];
+        }
+    };
+    // position p = 0..15 of a phase -> what is built beside MFMA p (reads land two positions before their first use):
+    //   p 0-1 reads A0 | 2 reads A1 | 3 reads A1, ops A0 | 4 ops A0, reads B0 | 5-6 ops A1, reads B0 | 7 reads B0 |
+    //   8-11 ops B0, reads B1 | 12-15 ops B1            (two reads / two operations per position)
+    auto build_slot = [&](int nbuf, int s, int set, int p) {
+        auto rd2 = [&](int g, int i0) { rd_grp(nbuf, s, g, i0); rd_grp(nbuf, s, g, i0 + 1); };
+        auto op2 = [&](int g, int i0) { op_grp(set, g, i0); op_grp(set, g, i0 + 1); };
+        if (p == 0) rd2(0, 0);
+        else if (p == 1) rd2(0, 2);
+        else if (p == 2) rd2(1, 0);
+        else if (p == 3) { op2(0, 0); rd2(1, 2); }
+        else if (p == 4) { op2(0, 2); rd2(2, 0); }
+        else if (p == 5) { op2(1, 0); rd2(2, 2); }
+        else if (p == 6) { op2(1, 2); rd2(2, 4); }
+        else if (p == 7) rd2(2, 6);
+        else if (p < 12) { op2(2, 2 * (p - 8)); rd2(3, 2 * (p - 8)); }
+        else op2(3, 2 * (p - 12));
+    };
+
+    int cn = sp0 / per_img, ctx, cty;
+    {
+        const int rem = sp0 - cn * per_img;
+        ctx = rem / a.tilesY;
+        cty = rem - ctx * a.tilesY;
+    }
+    auto next_region = [&](int& n, int& tx, int& ty) {
+        const int ty1 = ty + 1, wy = ty1 == a.tilesY ? 1 : 0;
+        ty = wy ? 0 : ty1;
+        const int tx1 = tx + wy, wx = tx1 == a.tilesX ? 1 : 0;
+        tx = wx ? 0 : tx1;
+        n += wx;
+    };
+    if (my_tiles > 0) {
+        region_setup(cn, ctx, cty);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) issue_d(j);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) issue_x(j);
+#pragma unroll
+        for (int j = 0; j < LD; ++j) commit_d(j, 0);
+#pragma unroll
+        for (int j = 0; j < LX; ++j) commit_x(j, 0);
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 16; ++p) build_slot(0, 0, 0, p);
+    }
+    int ln = cn, ltx = ctx, lty = cty, lcount = 0;
+    auto load_advance = [&]() {
+        if (lcount + 1 < my_tiles) { next_region(ln, ltx, lty); ++lcount; once_v = 1.f; } else once_v = 0.f;
+        region_setup(ln, ltx, lty);
+    };
+    if (my_tiles > 0) {
+        load_advance();
+#pragma unroll
+        for (int j = 0; j < LD; ++j) issue_d(j);
+    }
+
+    // One phase = the 16 MFMAs of k-step s (operand set SET) + the build of the next k-step's operands (set SET ^ 1) from
+    // buffer NB + what LOADS says: 0 commit dY, 1 issue X, 2 commit X (all of the next region), 3 issue dY of the one after it
+    auto phase = [&](auto SET, auto SNEXT, auto NBUF, auto DBUFW, auto LOADS) {
+        constexpr int set = decltype(SET)::value, sn = decltype(SNEXT)::value, nbuf = decltype(NBUF)::value;
+        constexpr int wbuf = decltype(DBUFW)::value, loads = decltype(LOADS)::value;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int p = c * 4 + mb * 2 + nb;
+                    acc[c][mb][nb] = MFMA16(dm[set][mb][c], vv[set][nb][c], acc[c][mb][nb]);
+                    build_slot(nbuf, sn, set ^ 1, p);
+                    if (loads == 0 && p >= 8 && p < 8 + LD) commit_d(p - 8, wbuf);
+                    if (loads == 1 && p >= 2 && p < 2 + 2 * LX && (p - 2) % 2 == 0) issue_x((p - 2) / 2);
+                    if (loads == 2 && p >= 8 && p < 8 + LX) commit_x(p - 8, wbuf);
+                    if (loads == 3 && p >= 2 && p < 2 + 2 * LD && (p - 2) % 2 == 0) issue_d((p - 2) / 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    auto region = [&](auto BUF) {
+        constexpr int b = decltype(BUF)::value;
+        using B = std::integral_constant<int, b>;
+        using NB = std::integral_constant<int, b ^ 1>;
+        phase(I0{}, I1{}, B{}, NB{}, I0{});
+        phase(I1{}, I2{}, B{}, NB{}, I1{});
+        phase(I0{}, I3{}, B{}, NB{}, I2{});
+        __syncthreads();
+        load_advance();
+        phase(I1{}, I0{}, NB{}, B{}, I3{});
+    };
+    for (int g = 0; g < my_tiles; g += 2) {
+        region(I0{});
+        if (g + 1 < my_tiles) region(I1{});
+    }
+
+    // ---- fold: the two K halves and the four xi rows meet in LDS, one co block (16 couts) per round ----
+    __syncthreads();
+    float* red = smem;                     // [kh][r][c][16 co][32 ci] = 64 KB
+    if (do_bias) {                         // threads with equal (tid & 7) hold the same 4 couts
+        *(float4*)&red[tid * 4] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            const int cq = tid >> 2, comp = tid & 3;
+            float sum = 0.f;
+            for (int i = 0; i < 64; ++i) sum += red[(i * 8 + cq) * 4 + comp];
+            a.bias_part[(size_t)sblk * Cout + co_base + tid] = sum;
+        }
+        __syncthreads();
+    }
+    int fold_w = ((kh * 4 + r) * 4 * 16 + 4 * (lane >> 4)) * 32 + idx, fold_r = tid;
+    asm volatile("" : "+v"(fold_w), "+v"(fold_r));
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    red[fold_w + c * 512 + q * 32 + nb * 16] = acc[c][mb][nb][q];
+        __syncthreads();
+        {
+            const int e = fold_r;          // (co16, ci32) = (tid >> 5, tid & 31)
+            float tcol[3][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float u[4];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float t = red[((0 * 4 + rr) * 4 + c) * 512 + e] + red[((1 * 4 + rr) * 4 + c) * 512 + e];
+                    u[rr] = ((rr == 3) != (c == 3)) ? -t : t;
+                }
+                tcol[0][c] = u[0] + 0.5f * (u[1] + u[2]);
+                tcol[1][c] = 0.5f * (u[1] - u[2]);
+                tcol[2][c] = u[3] + 0.5f * (u[1] + u[2]);
+            }
+            const int co = co_base + mb * 16 + (tid >> 5), ci = ci_base + (tid & 31);
+            float* o = a.part + (size_t)sblk * Cout * 9 * Cin + ((size_t)co * 9) * Cin + ci;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float t0 = tcol[ky][0], t1 = tcol[ky][1], t2 = tcol[ky][2], t3 = tcol[ky][3];
+                o[(ky * 3 + 0) * Cin] = t0 + 0.5f * (t1 + t2);
+                o[(ky * 3 + 1) * Cin] = 0.5f * (t1 - t2);
+                o[(ky * 3 + 2) * Cin] = t3 + 0.5f * (t1 + t2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 // one full-resolution source, whole regions (4 x 32 or 8 x 16 pixels)
@@ -1046,5 +1344,48 @@ int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, 
     if (rw == 32) k_conv_wino_wgrad64<32><<<a.nblk * nsb, 512, lds, st>>>(a);
     else k_conv_wino_wgrad64<16><<<a.nblk * nsb, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino64_wgrad");
+    return VQW_OK;
+}
+
+// (32 co x 32 ci) blocks: Cout a multiple of 32 but not of 64 (those take the 64-cout kernel), one full-resolution source,
+// 32-pixel-wide whole regions (4 x 32 pixels).  VQW_WINOGRAD32W=0: these layers on k_conv_wino_wgrad (A/B timing).
+static const int g_w32w_env = env_int64("VQW_WINOGRAD32W", 1);
+bool conv_wino32_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W) {
+    if (!g_w64_env || !g_w32w_env || C1 != 0 || up0 || C0 % 32 != 0 || Cout % 32 != 0 || Cout % 64 == 0 || W % 32 != 0) return false;
+    return H % 4 == 0;
+}
+int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
+    const int nblk = (Cout / 32) * (Cin / 32);
+    const int nsp = N * (H / 4) * (W / 32);
+    int nsb = g_w64_max_blocks / nblk;
+    if (nsb > max_slabs) nsb = max_slabs;
+    if (nsb > nsp) nsb = nsp;
+    if (nsb < 1) nsb = 1;
+    const int kt = ceil_div(nsp, nsb);
+    if (kt_out) *kt_out = kt;
+    return ceil_div(nsp, kt);
+}
+int conv_wino32_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+                      hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (WhGeo::DBUF + WhGeo::XBUF) * sizeof(float);
+    static_assert(lds <= 160 * 1024 && lds >= 64 * 1024, "the fold needs 64 KB");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino_wgrad32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            vqw_set_error("conv_wino32_wgrad: cannot raise the dynamic LDS limit");
+            return VQW_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const long P = (long)N * H * W;
+    W64WgArgs a;
+    a.x = x; a.dy = dy; a.part = ws; a.bias_part = bpart;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.tilesY = H / 4; a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
+    a.n_ci_b = Cin / 32; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
+    a.nbx = (unsigned)(P * Cin * 4);
+    a.nbd = (unsigned)(P * Cout * 4);
+    k_conv_wino_wgrad32<<<a.nblk * nsb, 512, lds, st>>>(a);
+    VQW_LAUNCH_CHECK("conv_wino32_wgrad");
     return VQW_OK;
 }

@@ -78,6 +78,10 @@ CONV_CASES = [
     (1, 20, 16, 128, 0, False, 64, 3, 1, True, False),
     (1, 256, 320, 16, 0, False, 64, 3, 1, True, False),
     (2, 22, 32, 64, 0, False, 16, 3, 1, False, False),     # its input gradient: 16 -> 64
+    # (32 co x 32 ci)-block Winograd weight gradient (round 4: Cout % 64 == 32, Cin % 32 == 0, W % 32 == 0, H % 4 == 0): three co
+    # blocks, several regions per workgroup and images, an odd number of regions, no bias
+    (3, 64, 64, 32, 0, False, 96, 3, 1, True, False),
+    (2, 12, 96, 64, 0, False, 32, 3, 1, False, False),
     # up-sampled 3x3 in Winograd form with nine products (conv_wino_up.hip): ragged H, the shortest channel walk (two chunks),
     # several regions per strip and image, both N-tile widths (64 / 128 input channels)
     (1, 40, 32, 64, 0, True, 16, 3, 1, True, False),
