@@ -692,8 +692,13 @@ template <int RW> struct WgGeo {
     static constexpr int DBUF = 128 * WG_DP, XBUF = XPIX * WG_XP;
 };
 
+#ifdef W6_WG_VGPR                            // experiment: cap the weight-gradient kernel's registers (room for other streams' waves)
+#define W6_WG_ATTR __attribute__((amdgpu_num_vgpr(W6_WG_VGPR)))
+#else
+#define W6_WG_ATTR
+#endif
 template <int RW>
-__global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad64(W64WgArgs a) {
+__global__ void __launch_bounds__(512, 1) W6_WG_ATTR k_conv_wino_wgrad64(W64WgArgs a) {
     using G = WgGeo<RW>;
     constexpr int NT = 512, DBUF = G::DBUF, XBUF = G::XBUF, XW = G::XW;
     constexpr int XF = G::XPIX * 8;                        // float4 per X halo: 1632 / 1440
@@ -1302,7 +1307,10 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
 }  // namespace
 
 // one full-resolution source, whole regions (4 x 32 or 8 x 16 pixels)
+// VQW_WGRAD64=0 (experiment): the (64 co x 32 ci)-block kernel off; its 32-pixel-wide layers then take the (32 x 32)-block kernel
+static const int g_wg64_env = env_int64("VQW_WGRAD64", 1);
 bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W) {
+    if (!g_wg64_env && W % 32 == 0 && H % 4 == 0) return false;
     if (!g_w64_env || C1 != 0 || up0 || C0 % 32 != 0 || Cout % 64 != 0 || W % 16 != 0) return false;
     return H % (W % 32 == 0 ? 4 : 8) == 0;
 }
@@ -1351,7 +1359,7 @@ int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, 
 // 32-pixel-wide whole regions (4 x 32 pixels).  VQW_WINOGRAD32W=0: these layers on k_conv_wino_wgrad (A/B timing).
 static const int g_w32w_env = env_int64("VQW_WINOGRAD32W", 1);
 bool conv_wino32_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W) {
-    if (!g_w64_env || !g_w32w_env || C1 != 0 || up0 || C0 % 32 != 0 || Cout % 32 != 0 || Cout % 64 == 0 || W % 32 != 0) return false;
+    if (!g_w64_env || !g_w32w_env || C1 != 0 || up0 || C0 % 32 != 0 || Cout % 32 != 0 || (Cout % 64 == 0 && g_wg64_env) || W % 32 != 0) return false;
     return H % 4 == 0;
 }
 int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
