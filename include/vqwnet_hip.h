@@ -103,6 +103,13 @@ int vqw_conv3x3_up2_fwd(const float* x_low, const void* ws, const float* bias, f
 int vqw_conv3x3_up2_fwd_stats_parts(int Cin, int Cout, int N, int h, int w);
 int vqw_conv3x3_up2_fwd_stats(const float* x_low, const void* ws, const float* bias, float* y, float* part, int N, int h, int w,
                               int Cin, int Cout, void* stream);
+/* (ABI 8) TWO 32-cout layers of the same up-sampled input - StyledResUpBlock's shortcut `conv` and `conv1`, blocks.py:100-112 - as ONE
+ * 64-cout launch of the nine-product kernel.  ws = vqw_conv3x3_up2_prepare() of the concatenated weights [w_a | w_b] (Cout = 64),
+ * bias_cat = [b_a | b_b] or NULL; y_a / y_b (N, 2h, 2w, 32) and their InstanceNorm / BatchNorm statistics partials part_a / part_b
+ * ([N][parts][32][2], parts = the value ..._supported returns; 0 = not served) come out as separate tensors. */
+int vqw_conv3x3_up2_fwd_pair_supported(int Cin, int Cout_each, int N, int h, int w);
+int vqw_conv3x3_up2_fwd_pair(const float* x_low, const void* ws, const float* bias_cat, float* y_a, float* y_b, float* part_a,
+                             float* part_b, int N, int h, int w, int Cin, int Cout_each, void* stream);
 int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
                           void* stream);
 /* ABI 7.  dx_low += the same input gradient: the second of the two up-sampled convolutions that read one tensor (a

@@ -318,6 +318,23 @@ extern "C" int vqw_conv3x3_up2_fwd_stats(const float* x_low, const void* ws, con
     ProfScope ps(wino ? 4 : 0, flops, (hipStream_t)stream, bytes);
     return conv_up2_fwd(x_low, (const float*)ws, bias, y, N, h, w, Cin, Cout, 0, (hipStream_t)stream, part);
 }
+// Two 32-cout layers of the SAME up-sampled input (StyledResUpBlock's shortcut `conv` and `conv1`, blocks.py:100-112) as ONE
+// 64-cout launch of the nine-product kernel: ws = vqw_conv3x3_up2_prepare of the concatenated weights [w_a | w_b] (Cout = 64),
+// bias_cat = [b_a | b_b] or NULL; y_a / y_b and their statistics partials come out as two 32-channel tensors.  Returns the
+// partials per image from ..._supported (0: not served - run the layers one by one).
+extern "C" int vqw_conv3x3_up2_fwd_pair_supported(int Cin, int Cout_each, int N, int h, int w) {
+    if (g_conv_backend != 0 || Cout_each != 32 || !conv_up2_ok(Cin, 64, (long)N * h * w) || !conv_wino_up_fwd_ok(Cin, 64, N, h, w)) return 0;
+    return conv_wino_up_stat_tiles(h, w);
+}
+extern "C" int vqw_conv3x3_up2_fwd_pair(const float* x_low, const void* ws, const float* bias_cat, float* y_a, float* y_b, float* part_a,
+                                        float* part_b, int N, int h, int w, int Cin, int Cout_each, void* stream) {
+    VQW_CHECK(x_low && ws && y_a && y_b && part_a && part_b && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_fwd_pair: bad arguments");
+    VQW_CHECK(vqw_conv3x3_up2_fwd_pair_supported(Cin, Cout_each, N, h, w) > 0, "vqw_conv3x3_up2_fwd_pair: shape not served");
+    const double flops = 2.0 * N * h * w * 9.0 * 64.0 * Cin;
+    const double bytes = 4.0 * ((double)N * h * w * Cin + 4.0 * N * h * w * 64.0 + 16.0 * 64.0 * Cin);
+    ProfScope ps(4, flops, (hipStream_t)stream, bytes);
+    return conv_wino_up_fwd(x_low, (const float*)ws + 32L * 64 * Cin, bias_cat, y_a, N, h, w, Cin, 64, 0, (hipStream_t)stream, part_a, y_b, part_b);
+}
 extern "C" int vqw_conv3x3_up2_dgrad(const float* dy, const void* ws, float* dx_low, int N, int h, int w, int Cin, int Cout,
                                      void* stream) {
     VQW_CHECK(dy && ws && dx_low && N > 0 && h > 0 && w > 0, "vqw_conv3x3_up2_dgrad: bad arguments");

@@ -95,7 +95,7 @@ int conv_wino_up_wgrad(const float* x_low, const float* dy, float* dw, float* db
 bool conv_wino_up_fwd_ok(int Cin, int Cout, int N, int h, int w);
 int conv_wino_up_stat_tiles(int h, int w);
 int conv_wino_up_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
-                     hipStream_t st, float* stats = nullptr);
+                     hipStream_t st, float* stats = nullptr, float* y2 = nullptr, float* stats2 = nullptr);
 // collapsed 3x3-over-upsampled forward / dgrad (conv_mfma.hip)
 bool conv_up2_ok(int Cin, int Cout, long Plow);
 size_t conv_up2_ws_floats(int Cin, int Cout);

@@ -377,6 +377,10 @@ struct WUpFwArgs {
     int relu;
     unsigned nbx, nbu, nby;
     float* stats;              // optional [N][tilesY * tilesX][Cout][2]
+    // pair mode (round 4): Cout = 64 = TWO 32-cout layers of the same input (StyledResUpBlock's `conv` and `conv1`, blocks.py:100-112)
+    // run as one 64-cout launch; couts 32..63 go to y2 / stats2, each output tensor (and statistics array) has 32 channels
+    float* y2;
+    float* stats2;
 };
 
 constexpr int WF_KPH = 12;                 // floats per low-resolution halo pixel: adjacent tiles are ONE pixel apart (12 m: conflict-free)
@@ -400,6 +404,9 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_fwd(WUpFwArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = a.h, w = a.w, Cin = a.Cin, Cout = a.Cout;
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
+    const bool split = a.y2 != nullptr;                    // uniform: two 32-channel outputs
+    const __amdgpu_buffer_rsrc_t rsy2 = make_rsrc(split ? a.y2 : a.y, a.nby);
+    const int Cst = split ? 32 : a.Cout;                   // channels per output pixel as stored
 
     const int ntn = a.ntn, nch = a.nch;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -590,17 +597,19 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_fwd(WUpFwArgs a) {
                 yv[r * 4 + 2] = fmaxf((t1[0] + t1[1]) + bvv[nb], lo);
                 yv[r * 4 + 3] = fmaxf((t1[1] - t1[2]) + bvv[nb], lo);
             }
-            const unsigned co = (unsigned)(co_base + nb * 16 + m);
+            const bool second = split && nb >= 2;          // pair mode: N blocks 2, 3 are the second layer's couts 0..31
+            const unsigned co = second ? (unsigned)((nb - 2) * 16 + m) : (unsigned)(co_base + nb * 16 + m);
+            const __amdgpu_buffer_rsrc_t rso = second ? rsy2 : rsy;
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
                 const int yy = yrow0 + aa;
-                const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cout + co;
+                const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cst + co;
                 const int voff = (int)sel_u32(yy < H, base * 4u, 0xFFFFFFFFu);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int b = 0; b < 2; ++b)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rso, voff, (2 * r + b) * Cst * 4, 0);
             }
             if (a.stats) {     // uniform: h % 8 == 0 whenever statistics are requested
                 float s1, s2;
@@ -622,7 +631,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_up_fwd(WUpFwArgs a) {
 #pragma unroll
                 for (int r = 1; r < 8; ++r) stat_merge(s1, s2, 64.f * r, R[r * NCO * 2], R[r * NCO * 2 + 1], 64.f);
                 const int t = (cn * a.tilesX + ctx) * a.tilesY + cty;
-                float* o = a.stats + ((size_t)t * Cout + co_base + tid) * 2;
+                float* o = split ? (tid < 32 ? a.stats : a.stats2) + ((size_t)t * 32 + (tid & 31)) * 2
+                                 : a.stats + ((size_t)t * Cout + co_base + tid) * 2;
                 o[0] = s1;
                 o[1] = s2;
             }
@@ -1033,10 +1043,11 @@ bool conv_wino_up_fwd_ok(int Cin, int Cout, int N, int h, int w) {
 }
 int conv_wino_up_stat_tiles(int h, int w) { return (h % 8 == 0 && w % 16 == 0) ? (h / 8) * (w / 16) : 0; }
 int conv_wino_up_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,
-                     hipStream_t st, float* stats) {
+                     hipStream_t st, float* stats, float* y2, float* stats2) {
     constexpr size_t lds = (size_t)(2 * 10 * 18 * WF_KPH + 2 * 9 * 64 * 8 + 2 * 8 * 64 * 2) * sizeof(float);
+    if (y2 && Cout != 64) { vqw_set_error("conv_wino_up_fwd: pair mode needs two 32-cout layers (Cout = 64)"); return VQW_ERR_ARG; }
     WUpFwArgs a;
-    a.x = x_low; a.u = ws; a.bias = bias; a.y = y;
+    a.x = x_low; a.u = ws; a.bias = bias; a.y = y; a.y2 = y2; a.stats2 = stats2;
     a.N = N; a.h = h; a.w = w; a.Cin = Cin; a.Cout = Cout;
     a.tilesY = ceil_div(h, 8); a.tilesX = w / 16; a.nsp = N * a.tilesY * a.tilesX;
     a.ntn = Cout / 64; a.nch = Cin / 8;
@@ -1045,7 +1056,7 @@ int conv_wino_up_fwd(const float* x_low, const float* ws, const float* bias, flo
     const long Pl = (long)N * h * w;
     a.nbx = (unsigned)(Pl * Cin * 4);
     a.nbu = (unsigned)(9L * Cout * Cin * 4);
-    a.nby = (unsigned)(4 * Pl * Cout * 4);
+    a.nby = (unsigned)(4 * Pl * (y2 ? 32 : Cout) * 4);
     int groups = g_wup_max_blocks / a.ntn;
     if (groups < 1) groups = 1;
     const int even = ceil_div(a.nsp, groups);

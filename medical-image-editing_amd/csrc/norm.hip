@@ -460,7 +460,9 @@ static inline bool walk_ok(int C4) { return C4 >= 1 && C4 <= 256 && ilog2_exact(
 template <class F4>
 static int launch_plane_reduce4(F4 f, double* part, int N, int HW, int C, hipStream_t st) {
     const int C4 = C / 4;
-    if (walk_ok(C4)) {
+    static const int pipe_env = []{ const char* e = getenv("VQW_PLANE_PIPE"); return e ? atoi(e) : 3; }();      // bit 0: InstanceNorm functors, bit 1: SPADE
+    const int bit = F4::kMinWaves == 2 ? 2 : 1;
+    if (walk_ok(C4) && (pipe_env & bit)) {
         const int sp = plane_splits_p(N, HW, C4);
         k_plane_reduce4p<<<dim3(sp, N), 256, 0, st>>>(f, part, HW, C4, ilog2_exact(C4), sp);
         return sp;

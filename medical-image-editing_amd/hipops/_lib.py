@@ -38,6 +38,8 @@ SIGNATURES = {
     "vqw_conv3x3_up2_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_fwd_stats_parts": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_up2_fwd_stats": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "vqw_conv3x3_up2_fwd_pair_supported": (c_i, [c_i] * 5),
+    "vqw_conv3x3_up2_fwd_pair": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_dgrad": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_up2_dgrad_acc_supported": (c_i, [c_i] * 5),
     "vqw_conv3x3_up2_dgrad_acc": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -636,6 +636,117 @@ class _GradNotes:
         return len(self.notes)
 
 
+# ----------------------------------------------------------------------------------------------
+# two 32-cout 3x3 layers of one up-sampled input as ONE 64-cout launch (StyledResUpBlock's shortcut `conv` and `conv1`)
+# ----------------------------------------------------------------------------------------------
+UP_PAIR = os.environ.get("VQW_UP_PAIR", "1") != "0"      # 0: the two layers run one by one (A/B timing)
+up_pair_calls = 0
+
+
+class _ConvUpPair(torch.autograd.Function):
+    """(y_a, part_a, y_b, part_b) = the forward of conv2d(x, w_a, b_a, up2x=True, want_stats=True) and of the same with (w_b, b_b),
+    computed by one launch of the nine-product kernel on the concatenated weights (a 32-cout layer alone falls back to the
+    collapsed 4-tap form at a third of that kernel's rate).  The backward is the two layers' own: each input gradient through
+    its layer's own collapsed / nine-product weights (the second added to the first in its kernel's epilogue when `group` is
+    given), each weight gradient on the side lanes."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, group):
+        global up_pair_calls
+        _dev(x, wa, ba, wb, bb)
+        x = nhwc(x)
+        Ca, Cin, ks, _ = wa.shape
+        N, _, h, w = x.shape
+        L = _L()
+        nparts = L.vqw_conv3x3_up2_fwd_pair_supported(Cin, Ca, N, h, w)
+        if nparts <= 0 or tuple(wb.shape) != tuple(wa.shape) or ks != 3:
+            raise RuntimeError("conv2d_up_pair: shape not served (query vqw_conv3x3_up2_fwd_pair_supported)")
+
+        def _prep():
+            wc = torch.empty((2 * Ca, Cin, 3, 3), dtype=torch.float32, device=wa.device, memory_format=CL)
+            wc[:Ca].copy_(wa.detach())
+            wc[Ca:].copy_(wb.detach())
+            buf = _ws(L.vqw_conv3x3_up2_ws_bytes(Cin, 2 * Ca), wa)
+            _lib.check(L.vqw_conv3x3_up2_prepare(_p(wc), _p(buf), buf.numel(), Cin, 2 * Ca, _st()), "vqw_conv3x3_up2_prepare")
+            bc = None
+            if ba is not None and bb is not None:
+                bc = torch.cat([ba.detach().reshape(-1), bb.detach().reshape(-1)])
+            return buf, bc
+        deps = (wb,) + tuple(t for t in (ba, bb) if t is not None)
+        up_ws, bias_cat = _cached(wa, "up2pair", _prep, deps=deps)
+        ya = empty_nhwc(N, Ca, 2 * h, 2 * w, x)
+        yb = empty_nhwc(N, Ca, 2 * h, 2 * w, x)
+        pa = torch.empty(N * nparts * Ca * 2, dtype=torch.float32, device=x.device)
+        pb = torch.empty(N * nparts * Ca * 2, dtype=torch.float32, device=x.device)
+        _lib.check(L.vqw_conv3x3_up2_fwd_pair(_p(x), _p(up_ws), _p(bias_cat), _p(ya), _p(yb), _p(pa), _p(pb), N, h, w, Cin, Ca, _st()),
+                   "vqw_conv3x3_up2_fwd_pair")
+        up_pair_calls += 1
+        ctx.save_for_backward(x, nhwc(wa), nhwc(wb))
+        ctx.group = group
+        ctx.cfg = (N, 2 * h, 2 * w, Ca, Cin)
+        ctx.params = ((wa, ba), (wb, bb))
+        ctx.defer = []
+        for i, (wgt, bias) in enumerate(ctx.params):
+            d = (WGRAD_ASYNC and ctx.needs_input_grad[1 + 2 * i] and wgt.is_leaf and nhwc(wgt) is wgt
+                 and not wgrad_through_autograd(wgt, bias) and (bias is None or (bias.is_leaf and bias.is_contiguous())))
+            ctx.defer.append(d)
+            if d:
+                wgt._vqw_pending = getattr(wgt, "_vqw_pending", 0) + 1
+        ctx.mark_non_differentiable(pa, pb)
+        ctx.set_materialize_grads(False)
+        return ya, pa, yb, pb
+
+    @staticmethod
+    def backward(ctx, ga, _gpa, gb, _gpb):
+        x, wa_n, wb_n = ctx.saved_tensors
+        N, H, W, Cout, Cin = ctx.cfg
+        L = _L()
+        out = [None] * 6
+        gx_total = None
+        # (the second layer's input gradient runs first, like the second of two separate nodes would)
+        for i in (1, 0):
+            gy = (ga, gb)[i]
+            if gy is None:
+                if ctx.group is not None:
+                    raise RuntimeError("conv2d_up_pair: both outputs must take part in the backward pass of a gradient group")
+                continue
+            wgt, bias = ctx.params[i]
+            w_n = (wa_n, wb_n)[i]
+
+            def _collapse(w_n=w_n):
+                buf = _ws(L.vqw_conv3x3_up2_ws_bytes(Cin, Cout), w_n)
+                _lib.check(L.vqw_conv3x3_up2_prepare(_p(w_n), _p(buf), buf.numel(), Cin, Cout, _st()), "vqw_conv3x3_up2_prepare")
+                return buf
+            up_ws = _cached(wgt, "up2", _collapse)
+            need0 = ctx.needs_input_grad[0]
+            needw, needb = ctx.needs_input_grad[1 + 2 * i], (bias is not None and ctx.needs_input_grad[2 + 2 * i])
+            defer = ctx.defer[i] and (needw or needb)
+            g0, _, gw, gbias, gy_n = conv2d_backward_impl(gy, x, None, w_n, None, 1, True, bias is not None, up_ws, need0, False,
+                                                          needw and not defer, needb and not defer, group=ctx.group)
+            if defer:
+                _deferred_wgrad(wgt, bias if (bias is not None and bias.requires_grad) else None, x, None, gy_n, True, 3, 1,
+                                N, H, W, Cout, collapsed=True)
+            out[1 + 2 * i], out[2 + 2 * i] = gw, gbias
+            if g0 is not None:
+                gx_total = g0 if gx_total is None else gx_total.add_(g0)
+        out[0] = gx_total
+        return tuple(out)
+
+
+def conv2d_up_pair_supported(x, weight_a, weight_b):
+    """True when conv2d_up_pair serves these two layers (both 3x3, 32 couts, same shape, the nine-product kernel's geometry)."""
+    if not (UP_PAIR and x.is_cuda and weight_a.shape == weight_b.shape and weight_a.shape[2] == 3 and not _in_custom_op):
+        return False
+    N, _, h, w = x.shape
+    return _L().vqw_conv3x3_up2_fwd_pair_supported(weight_a.shape[1], weight_a.shape[0], N, h, w) > 0
+
+
+def conv2d_up_pair(x, weight_a, bias_a, weight_b, bias_b, grad_group=None):
+    """-> ((y_a, part_a), (y_b, part_b)): conv2d(x, w, b, up2x=True, want_stats=True) of two layers of one input, one launch."""
+    ya, pa, yb, pb = _ConvUpPair.apply(x, weight_a, bias_a, weight_b, bias_b, grad_group if GRAD_GROUPS else None)
+    return (ya, pa), (yb, pb)
+
+
 # Gradients that arrive already multiplied by a fused ReLU's mask: payload = data_ptr of the ReLU output the gradient was masked
 # with.  Written by a consumer whose input-gradient kernel applies the mask in its epilogue (vqw_conv3x3_wino_fwd_masked),
 # taken by the producer's backward, which then skips its own mask pass.

@@ -662,6 +662,43 @@ def test_instance_norm_backward_sums_from_the_consumer_convolution(monkeypatch, 
         assert_close(got[k], ref[k], 2e-5, "gradient %s, norm-backward sums from the convolution's epilogue" % k)
 
 
+def test_upsampled_layer_pair_as_one_launch(monkeypatch):
+    """StyledResUpBlock's shortcut `conv` and `conv1` (blocks.py:100-112) read the same up-sampled input; at 32 couts each they
+    run as ONE 64-cout launch of the nine-product kernel (ops.conv2d_up_pair, vqw_conv3x3_up2_fwd_pair) instead of two launches
+    of the collapsed 4-tap form.  Outputs, input / style gradients and every parameter gradient agree with the block run layer
+    by layer (VQW_UP_PAIR=0) to rounding; the paired launch is really taken, also without a gradient group."""
+    from networks import blocks as B
+    from hipops import ops
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+
+    def run(pair, groups=True):
+        monkeypatch.setattr(ops, "UP_PAIR", pair)
+        monkeypatch.setattr(B, "GRAD_GROUP_BLOCKS", groups)
+        torch.manual_seed(13)
+        mod = B.StyledResUpBlock(64, 32, 32).to(DEV).train()
+        down = cl(torch.randn(3, 64, 16, 32, device=DEV)).requires_grad_(True)
+        skip = cl(torch.randn(3, 32, 32, 64, device=DEV)).requires_grad_(True)
+        r = cl(torch.randn(3, 32, 32, 64, device=DEV))
+        n0 = ops.up_pair_calls
+        out = mod(down, skip)
+        (out * r).sum().backward()
+        torch.cuda.synchronize()
+        grads = {"down": down.grad.clone(), "skip": skip.grad.clone()}
+        grads.update({k: p.grad.clone() for k, p in mod.named_parameters()})
+        return out.detach(), grads, ops.up_pair_calls - n0
+    y0, g0, n0 = run(False)
+    y1, g1, n1 = run(True)
+    y2, g2, n2 = run(True, groups=False)
+    assert n0 == 0 and n1 == 1 and n2 == 1, (n0, n1, n2)
+    assert_close(y1, y0, 2e-5, "block output, paired launch vs layer by layer")
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        if float(g0[k].abs().max()) < 1e-4 * gmax:      # a bias in front of a norm: analytically zero
+            continue
+        assert_close(g1[k], g0[k], 1e-4, "gradient %s, paired launch" % k)
+        assert_close(g2[k], g0[k], 1e-4, "gradient %s, paired launch without gradient groups" % k)
+
+
 def test_deferred_slab_folds_match_immediate_folds(monkeypatch):
     """The weight-gradient kernels' split-K slabs are folded by ONE launch at the end of the backward pass (ops._fold_flush,
     vqw_fold_flush_host) instead of by two short launches behind every weight-gradient kernel.  Same sums in another fixed
