@@ -133,6 +133,10 @@ extern "C" int vqw_conv2d_fwd(const float* src0, int C0, int up0, const float* s
         ProfScope ps(2, flops, st, bytes);
         return conv_head_fwd(in, w_ohwi, bias, y, (long)N * H * W, relu, st);
     }
+    if (g_conv_backend == 0 && ksize == 1 && !relu && C1 == 0 && !up0 && conv_pw_stream_ok(C0, Cout, N, H * W)) {
+        ProfScope ps(2, flops, st, bytes);          // streaming 1x1 on the vector lanes (HBM-bound)
+        return conv_pw_stream(src0, w_ohwi, bias, y, nullptr, N, H * W, C0, Cout, 0, st);
+    }
     if (g_conv_backend == 0 && conv_mfma_fwd_ok(in, Cout, ksize)) {
         ProfScope ps(0, flops, st, bytes);
         if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, relu, st);
@@ -164,6 +168,10 @@ extern "C" int vqw_conv2d_fwd_acc(const float* src0, int C0, const float* w_ohwi
     ConvIn in{src0, nullptr, C0, 0, 0};
     const double px = (double)N * H * W;
     if (ksize == 1) {
+        if (conv_pw_stream_ok(C0, Cout, N, H * W)) {
+            ProfScope ps(2, 2.0 * px * Cout * C0, (hipStream_t)stream, 4.0 * (px * C0 + 2.0 * px * Cout + (double)Cout * C0));
+            return conv_pw_stream(src0, w_ohwi, nullptr, y, nullptr, N, H * W, C0, Cout, 1, (hipStream_t)stream);
+        }
         ProfScope ps(0, 2.0 * px * Cout * C0, (hipStream_t)stream, 4.0 * (px * C0 + 2.0 * px * Cout + (double)Cout * C0));
         return conv_mfma_fwd(in, w_ohwi, nullptr, y, N, H, W, Cout, 1, 1, 2, (hipStream_t)stream);      // relu = 2: y += result
     }
@@ -178,6 +186,7 @@ extern "C" int vqw_conv2d_fwd_stats_parts(int C0, int C1, int up0, int N, int H,
     ConvIn in{nullptr, nullptr, C0, C1, up0};
     if (g_conv_backend != 0 || N <= 0 || conv_stem_ok(in, Cout, ksize) || conv_head_ok(in, Cout, ksize) || !conv_mfma_fwd_ok(in, Cout, ksize)) return 0;
     if (conv_batch_group(N, H, W, C0 + C1, Cout) < N) return 0;
+    if (ksize == 1 && C1 == 0 && !up0 && conv_pw_stream_ok(C0, Cout, N, H * W)) return conv_pw_stream_stat_tiles(H * W);
     if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_stat_tiles(in, H, W, Cout);
     if (conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_dil_stat_tiles(H);
     return conv_mfma_stat_tiles(in, N, H, W, Cout, dil);        // implicit-GEMM kernel: 1x1, dilated, ragged widths
@@ -195,6 +204,10 @@ extern "C" int vqw_conv2d_fwd_stats(const float* src0, int C0, int up0, const fl
     const double flops = 2.0 * N * H * W * (double)Cout * ksize * ksize * (C0 + C1);
     const double px = (double)N * H * W;
     const double bytes = 4.0 * (px * C0 / (up0 ? 4 : 1) + px * C1 + px * Cout + (double)Cout * ksize * ksize * (C0 + C1));
+    if (ksize == 1 && C1 == 0 && !up0 && conv_pw_stream_ok(C0, Cout, N, H * W)) {
+        ProfScope ps2(2, flops, st, bytes);
+        return conv_pw_stream(src0, w_ohwi, bias, y, part, N, H * W, C0, Cout, 0, st);
+    }
     ProfScope ps(0, flops, st, bytes);
     if (conv_halo_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_halo_fwd(in, w_ohwi, bias, y, N, H, W, Cout, 0, st, part);
     if (conv_dil_fwd_ok(in, N, H, W, Cout, ksize, dil)) return conv_dil_fwd(in, w_ohwi, bias, y, N, H, W, Cout, dil, 0, st, part);

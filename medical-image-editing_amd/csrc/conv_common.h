@@ -131,6 +131,11 @@ int conv_k4s1_wgrad_grid(const float* x, const float* dy_grid, float* dw, float*
                          hipStream_t st);
 
 // thin-channel streams (conv_thin.hip): 1-channel stem, 1-channel 1x1 head
+// streaming 1x1 channel mixing on the vector lanes (conv_thin.hip): y[p][n] = sum_k x[p][k] B[k][n], B = [K][Nout]
+bool conv_pw_stream_ok(int K, int Nout, int N, int HW);
+int conv_pw_stream_stat_tiles(int HW);
+int conv_pw_stream(const float* x, const float* Bm, const float* bias, float* y, float* part, int N, int HW, int K, int Nout, int mode,
+                   hipStream_t st);
 bool conv_stem_ok(const ConvIn& in, int Cout, int ks);
 bool conv_stem_wgrad_ok(const ConvIn& in, int Cout, int ks);
 int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks, int dil,

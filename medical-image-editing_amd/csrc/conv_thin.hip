@@ -425,3 +425,142 @@ int conv_pw_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, long 
     VQW_LAUNCH_CHECK("conv_pw_wgrad");
     return reduce_rows(ws, dw, (long)Cin * Cout, nb, st, acc);
 }
+
+// =====================================================================================================================
+// Streaming 1 x 1 convolution (round 4): forward and input gradient of the channel-mixing layers on the large maps
+// (ResBlock projections 16->32 @256 / 32->64 @128, the pyramid's 1 x 1 branch 32->32 @256; blocks.py:25, aspp.py:25)
+// =====================================================================================================================
+// These layers are HBM-bound (2-5 FLOP per byte) and ran on the implicit-GEMM kernel at 3.0-4.0 TB/s: a 128-pixel MFMA tile
+// with LDS staging, barriers and dword stores per 24 KB of traffic.  Here: y[p][n] = sum_k x[p][k] B[k][n] on the vector lanes.
+// A 256-thread workgroup covers R = 256 / (NOUT / 4) whole pixels per pass; thread t keeps its output quad q4 = t % (NOUT / 4)
+// for the whole walk (four passes in flight), B (KIN x NOUT, <= 16 KB) sits in LDS and is read as broadcast float4 rows, the
+// pixel's KIN inputs arrive as KIN / 4 float4 loads that the NOUT / 4 threads of the pixel share in the texture cache, the
+// result leaves as one float4 store: 16-byte accesses end to end.  MODE 0: y = result (+ bias); 1: y += result (a later
+// member of a gradient group).  With `part` the workgroup also leaves the (sum, M2 about the tile mean) statistics partials
+// of its TILE pixels per output channel for the InstanceNorm that follows (shifted sums per thread, Chan merges across the
+// threads of a channel in a fixed order).
+template <int KIN, int NOUT, int MODE>
+__global__ void __launch_bounds__(256) k_pw_stream(const float4* __restrict__ x, const float* __restrict__ Bm, const float* __restrict__ bias,
+                                                   float4* __restrict__ y, float* __restrict__ part, long P, int tile_px) {
+    constexpr int Q = NOUT / 4, R = 256 / Q, K4 = KIN / 4;
+    __shared__ float4 sB[KIN * Q];
+    __shared__ float sred[4][2][NOUT];
+    const int t = threadIdx.x, q4 = t % Q, r = t / Q;
+    // Bm arrives as the layer's OHWI weights [NOUT][KIN]; the mixing matrix is its transpose [KIN][NOUT]
+    for (int i = t; i < KIN * NOUT; i += 256) ((float*)sB)[i] = Bm[(i % NOUT) * KIN + i / NOUT];
+    __syncthreads();
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = ((const float4*)bias)[q4];
+    const long p_begin = (long)blockIdx.x * tile_px;
+    const long p_end = p_begin + tile_px < P ? p_begin + tile_px : P;
+    // statistics: shifted sums about the thread's first value per channel (n_thr values per thread, equal for every thread)
+    float sh[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    bool have_shift = false;
+    for (long p0 = p_begin + r; p0 < p_end; p0 += 2 * R) {
+        float4 acc[2];
+        float4 xin[2][K4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long p = p0 + u * R;
+            if (p < p_end) {
+#pragma unroll
+                for (int j = 0; j < K4; ++j) xin[u][j] = x[p * K4 + j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long p = p0 + u * R;
+            if (p >= p_end) break;
+            float4 a = bv;
+            // B's rows at q4 do not change from pixel to pixel: the compiler keeps them in registers (KIN float4: fine up to
+            // KIN = 32, 422 registers at 64) - there an index it cannot see through keeps them in LDS
+            int qo = q4;
+            if (KIN > 32) asm volatile("" : "+v"(qo));
+#pragma unroll
+            for (int j = 0; j < K4; ++j) {
+                const float xv[4] = {xin[u][j].x, xin[u][j].y, xin[u][j].z, xin[u][j].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 b = sB[(4 * j + k) * Q + qo];
+                    a.x = fmaf(xv[k], b.x, a.x); a.y = fmaf(xv[k], b.y, a.y); a.z = fmaf(xv[k], b.z, a.z); a.w = fmaf(xv[k], b.w, a.w);
+                }
+            }
+            if (MODE == 1) {
+                const float4 o = y[p * Q + q4];
+                a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+            }
+            y[p * Q + q4] = a;
+            acc[u] = a;
+            if (part) {
+                const float av[4] = {a.x, a.y, a.z, a.w};
+                if (!have_shift) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sh[k] = av[k];
+                    have_shift = true;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const float d = av[k] - sh[k]; s1[k] += d; s2[k] = fmaf(d, d, s2[k]); }
+            }
+        }
+        (void)acc;
+    }
+    if (part) {        // uniform; every thread has seen n_thr = tile_px / R pixels (the launcher guarantees whole tiles)
+        const float n_thr = (float)(tile_px / R);
+        float sum[4], m2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sum[k] = fmaf(n_thr, sh[k], s1[k]);                    // sum of the thread's values
+            m2[k] = s2[k] - s1[k] * s1[k] / n_thr;                 // about the thread's own mean
+        }
+        // threads that share q4: inside a wave the lanes q4 + Q i (xor offsets Q, 2 Q, ... < 64), then the four waves in order
+        float n = n_thr;
+        for (int off = Q; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) stat_merge_eq(sum[k], m2[k], __shfl_xor(sum[k], off, 64), __shfl_xor(m2[k], off, 64), 0.5f / n);
+            n *= 2.f;
+        }
+        const int lane = t & 63, wv = t >> 6;
+        if (lane < Q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sred[wv][0][4 * lane + k] = sum[k]; sred[wv][1][4 * lane + k] = m2[k]; }
+        }
+        __syncthreads();
+        if (t < NOUT) {
+            // Q >= 64 cannot happen (NOUT <= 64 -> Q <= 16): every wave holds every quad
+            float a = sred[0][0][t], b = sred[0][1][t];
+            stat_merge_eq(a, b, sred[1][0][t], sred[1][1][t], 0.5f / n);
+            float c = sred[2][0][t], d = sred[2][1][t];
+            stat_merge_eq(c, d, sred[3][0][t], sred[3][1][t], 0.5f / n);
+            stat_merge_eq(a, b, c, d, 0.25f / n);
+            float* o = part + ((size_t)blockIdx.x * NOUT + t) * 2;
+            o[0] = a;
+            o[1] = b;
+        }
+    }
+}
+
+static const int g_pw_stream = []{ const char* e = getenv("VQW_PW_STREAM"); return e ? atoi(e) : 1; }();      // 0: implicit-GEMM kernel (A/B)
+static inline int pw_tile_px(int HW) { return HW % 1024 == 0 ? 1024 : (HW % 512 == 0 ? 512 : 0); }
+// K -> Nout channel mixing on a map of at least 128 x 128 pixels per image, both channel counts in {16, 32, 64}
+bool conv_pw_stream_ok(int K, int Nout, int N, int HW) {
+    auto okc = [](int c) { return c == 16 || c == 32 || c == 64; };
+    return g_pw_stream && okc(K) && okc(Nout) && HW >= 16384 && pw_tile_px(HW) > 0 && (long)N * HW * (K > Nout ? K : Nout) * 4 < 0xffffff00L;
+}
+int conv_pw_stream_stat_tiles(int HW) { const int tp = pw_tile_px(HW); return tp ? HW / tp : 0; }
+// Bm: the OHWI weights [Nout][K] of the 1 x 1 layer that maps K -> Nout channels (transposed while they are staged in LDS)
+int conv_pw_stream(const float* x, const float* Bm, const float* bias, float* y, float* part, int N, int HW, int K, int Nout, int mode,
+                   hipStream_t st) {
+    const long P = (long)N * HW;
+    const int tp = pw_tile_px(HW);
+    const int grid = (int)((P + tp - 1) / tp);
+#define PWS(K_, N_)                                                                                                                 \
+    if (K == K_ && Nout == N_) {                                                                                                    \
+        if (mode == 1) k_pw_stream<K_, N_, 1><<<grid, 256, 0, st>>>((const float4*)x, Bm, bias, (float4*)y, part, P, tp);             \
+        else k_pw_stream<K_, N_, 0><<<grid, 256, 0, st>>>((const float4*)x, Bm, bias, (float4*)y, part, P, tp);                       \
+    } else
+    PWS(16, 16) PWS(16, 32) PWS(16, 64) PWS(32, 16) PWS(32, 32) PWS(32, 64) PWS(64, 16) PWS(64, 32) PWS(64, 64)
+    { vqw_set_error("conv_pw_stream: channel counts %d -> %d not served", K, Nout); return VQW_ERR_ARG; }
+#undef PWS
+    VQW_LAUNCH_CHECK("conv_pw_stream");
+    return VQW_OK;
+}

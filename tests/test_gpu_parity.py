@@ -82,6 +82,12 @@ CONV_CASES = [
     # blocks, several regions per workgroup and images, an odd number of regions, no bias
     (3, 64, 64, 32, 0, False, 96, 3, 1, True, False),
     (2, 12, 96, 64, 0, False, 32, 3, 1, False, False),
+    # streaming 1x1 on the vector lanes (round 4: both channel counts in {16, 32, 64}, >= 128 x 128 pixels per image): forward
+    # and - with the roles of the channel counts swapped - input gradient; with and without bias
+    (2, 128, 128, 16, 0, False, 32, 1, 1, False, False),
+    (1, 128, 256, 32, 0, False, 32, 1, 1, True, False),
+    (1, 128, 128, 32, 0, False, 64, 1, 1, False, False),
+    (1, 256, 128, 64, 0, False, 16, 1, 1, True, False),
     # up-sampled 3x3 in Winograd form with nine products (conv_wino_up.hip): ragged H, the shortest channel walk (two chunks),
     # several regions per strip and image, both N-tile widths (64 / 128 input channels)
     (1, 40, 32, 64, 0, True, 16, 3, 1, True, False),
@@ -338,6 +344,9 @@ STATS_CASES_GEMM = [
     (2, 32, 32, 64, 32, 3, 1, True),      # collapsed: four parity launches, each a quarter of every plane
     (1, 32, 64, 128, 64, 3, 1, True),
     (2, 48, 128, 64, 32, 3, 1, True),     # halo kernel's 4-tap form: 4 x 3 x 2 partials per plane
+    (2, 128, 128, 16, 32, 1, 1, False),   # streaming 1x1 kernel: 1024-pixel tiles, shifted sums per thread
+    (1, 128, 256, 32, 32, 1, 1, False),
+    (2, 128, 192, 32, 64, 1, 1, False),   # 512-pixel tiles
 ]
 
 
@@ -442,7 +451,7 @@ def test_conv_epilogue_statistics_need_whole_tiles():
     assert torch.equal(ops.instance_norm(y, relu=True, part=part), ops.instance_norm(y, relu=True))
 
 
-@pytest.mark.parametrize("ks,Cin,Cout,S", [(1, 16, 16, 32), (3, 32, 32, 32), (3, 16, 16, 64), (1, 32, 64, 64)])
+@pytest.mark.parametrize("ks,Cin,Cout,S", [(1, 16, 16, 32), (3, 32, 32, 32), (3, 16, 16, 64), (1, 32, 64, 64), (1, 16, 32, 128)])
 def test_conv_epilogue_statistics_far_from_zero(ks, Cin, Cout, S):
     """Planes whose mean is ~60 standard deviations off zero (conv of a nearly constant positive input, as behind ReLUs on a
     quantised map): the InstanceNorm fed from the conv epilogue must be as exact as the one that reduces the plane in
