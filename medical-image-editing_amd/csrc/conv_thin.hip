@@ -475,7 +475,11 @@ __global__ void __launch_bounds__(256) k_pw_stream(const float4* __restrict__ x,
             // B's rows at q4 do not change from pixel to pixel: the compiler keeps them in registers (KIN float4: fine up to
             // KIN = 32, 422 registers at 64) - there an index it cannot see through keeps them in LDS
             int qo = q4;
+#ifdef PW_NOHOIST32
+            if (KIN >= 32) asm volatile("" : "+v"(qo));
+#else
             if (KIN > 32) asm volatile("" : "+v"(qo));
+#endif
 #pragma unroll
             for (int j = 0; j < K4; ++j) {
                 const float xv[4] = {xin[u][j].x, xin[u][j].y, xin[u][j].z, xin[u][j].w};

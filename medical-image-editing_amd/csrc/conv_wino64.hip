@@ -40,6 +40,8 @@ static int env_int64(const char* name, int dflt) {
 }
 static const int g_w64_env = env_int64("VQW_WINOGRAD64", 1);
 static const int g_w64_max_blocks = []{ int v = env_int64("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
+// weight-gradient kernels (they run on the side lanes beside the chain): VQW_WGRAD_MAX_BLOCKS leaves CUs to the chain's kernels (experiment)
+static const int g_w64_max_blocks_wg = []{ int v = env_int64("VQW_WGRAD_MAX_BLOCKS", g_w64_max_blocks); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -1318,7 +1320,7 @@ int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_sla
     const int nblk = (Cout / 64) * (Cin / 32);
     const int rw = W % 32 == 0 ? 32 : 16;
     const int nsp = N * (H / (128 / rw)) * (W / rw);
-    int nsb = g_w64_max_blocks / nblk;
+    int nsb = g_w64_max_blocks_wg / nblk;
     if (nsb > max_slabs) nsb = max_slabs;
     if (nsb > nsp) nsb = nsp;
     if (nsb < 1) nsb = 1;
@@ -1365,7 +1367,7 @@ bool conv_wino32_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W) {
 int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
     const int nblk = (Cout / 32) * (Cin / 32);
     const int nsp = N * (H / 4) * (W / 32);
-    int nsb = g_w64_max_blocks / nblk;
+    int nsb = g_w64_max_blocks_wg / nblk;
     if (nsb > max_slabs) nsb = max_slabs;
     if (nsb > nsp) nsb = nsp;
     if (nsb < 1) nsb = 1;

@@ -27,6 +27,8 @@ static int env_int_up(const char* name, int dflt) {
 }
 static const int g_wup_env = env_int_up("VQW_WINOGRAD_UP", 1);
 static const int g_wup_max_blocks = []{ int v = env_int_up("VQW_CONV_MAX_BLOCKS", 256); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
+// weight-gradient kernels (they run on the side lanes beside the chain): VQW_WGRAD_MAX_BLOCKS leaves CUs to the chain's kernels (experiment)
+static const int g_wup_max_blocks_wg = []{ int v = env_int_up("VQW_WGRAD_MAX_BLOCKS", g_wup_max_blocks); return v < 8 ? 8 : (v > 256 ? 256 : v); }();
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -1075,7 +1077,7 @@ bool conv_wino_up_wgrad_ok(int Cin, int Cout, int N, int h, int w) {
 static int wup_wgrad_blocks(int Cin, int Cout, int N, int h, int w, int* kt_out) {
     const int nblk = (Cout / 32) * (Cin / 32);
     const int nsp = N * (h / 4) * (w / 16);
-    int nsb = g_wup_max_blocks / nblk;
+    int nsb = g_wup_max_blocks_wg / nblk;
     if (nsb > nsp) nsb = nsp;
     if (nsb < 1) nsb = 1;
     const int kt = ceil_div(nsp, nsb);
