@@ -145,6 +145,16 @@ int vqw_conv3x3_wino_fwd_masked(const float* x, const void* ws, const float* mas
  * blocks.py:100-134) - adds its input gradient to the shared buffer in its epilogue instead of leaving the sum to a separate
  * add pass.  Served where ..._masked_supported says so. */
 int vqw_conv3x3_wino_fwd_acc(const float* x, const void* ws, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
+/* One launch, two output tensors (ABI 8): couts [0, split) -> y0 [N,H,W,split] - or, with pool0, summed over each 2 x 2 output
+ * tile into y0 [N,H/2,W/2,split] - and couts [split, Cout) -> y1 [N,H,W,Cout-split].  Two uses: (i) the input gradient of a 3x3
+ * layer over [nearest-up2x(a) | b] (UpBlock, blocks.py:9-18 with unet_encoder.py's torch.cat): x = dY, ws = the transformed
+ * input-gradient weights, Cout = Ca + Cb, split = Ca, pool0 = 1: the gradients of a and b leave the epilogue, replacing two
+ * vqw_input_grad_gather passes over the concatenated gradient; (ii) two layers of one input on concatenated weights (the two
+ * mlp_shared convolutions of a StyledResUpBlock's StyledDenorms, blocks.py:72-75, 100-134): pool0 = 0, bias / relu as in
+ * vqw_conv3x3_wino_fwd.  split % 16 == 0; served where ..._split_supported says so. */
+int vqw_conv3x3_wino_split_supported(int Cin, int Cout, int split, int pool0, int N, int H, int W);
+int vqw_conv3x3_wino_fwd_split(const float* x, const void* ws, const float* bias, float* y0, float* y1, int N, int H, int W,
+                               int Cin, int Cout, int split, int pool0, int relu, void* stream);
 /* The input gradient of a layer whose forward read the output of an InstanceNorm (+ReLU) (DoubleConv: conv -> norm -> ReLU ->
  * conv, blocks.py:39-61): y = the gradient as usual, and part[N][parts][Cout][2] = that norm's backward sums per region,
  * (sum gm, sum gm * xhat) with xhat = (norm_x - mean) * rstd and gm = the gradient where the norm's ReLU passed - what

@@ -66,6 +66,11 @@ struct W64Args {
                                // (sum gm, sum gm * xhat), gm = g where the norm's ReLU passed (all of g without a ReLU)
     const float* mr;
     int in_relu;
+    // EPI 4: the couts split into two tensors: [0, split) -> y (channel stride split; pool0: summed over each 2 x 2 output tile
+    // and stored at half resolution - the adjoint of a nearest x2 up-sampling that fed those channels), [split, Cout) -> y2
+    float* y2;
+    int split, pool0;
+    unsigned nby2;
 };
 
 constexpr int W6_KPH = 10;                 // floats per halo pixel in LDS (8 channels + 2: conflict-free ds_read_b64 patches)
@@ -77,17 +82,25 @@ constexpr int W6_KPH = 10;                 // floats per halo pixel in LDS (8 ch
 // Region geometry, RW = region width: 8 MBW rows x 32 columns (halo rows x 34), or - for maps whose width is a multiple of
 // 16 only (the 16 x 16 level, MBW = 1) - 16 x 16 (halo 18 x 18, LDS row stride 24 pixels: the two tile rows of an M block
 // then land on complementary banks).
-template <int RW, int MBW> struct W64Geo {
+// NW = waves per workgroup: 8 (one workgroup per CU) or 4 - HALF the region rows, two workgroups per CU (same two waves per
+// SIMD, same registers per wave).  The two workgroups of a CU are in independent phases: while one sits in its region
+// epilogue, at a barrier or behind a prefetch commit, the other one's MFMAs run.  With eight waves in lock step those
+// costs ADD to the MFMA time (timing-only A/B builds, 32->32 @256: MFMAs alone 0.138 ms, + epilogue 0.053, + loads 0.032,
+// + transform 0.018, + barriers 0.006 = the 0.239 measured).
+template <int RW, int MBW, int NW = 8> struct W64Geo {
     static_assert(MBW == 1 || (MBW == 2 && RW == 32), "two M blocks per wave: 32-wide regions only");
+    static_assert(NW == 8 || (NW == 4 && RW == 32), "four-wave workgroups: 32-wide regions only");
+    static constexpr int NMB = NW / 2;                     // waves per xi half = M-block rows of the workgroup
     static constexpr int NBW = 4 / MBW;
     static constexpr int NCO = 16 * NBW;                   // couts per workgroup
-    static constexpr int TR = RW == 32 ? 8 * MBW : 16;
+    static constexpr int TR = RW == 32 ? 2 * MBW * NMB : 16;
     static constexpr int HR = TR + 2, HWV = RW + 2;
     static constexpr int HWS = RW == 32 ? 34 : 24;
     static constexpr int HBUF = HR * HWS * W6_KPH;
     static constexpr int UBUF = 16 * NCO * 8;              // floats per U chunk: [xi][couts][8 channels], float4 halves swizzled by cout bit 3
-    static constexpr int EXF = 16384;                      // exchange area of the region epilogue: 64 KB
-    static constexpr size_t LDS_FLOATS = 2 * HBUF + UBUF + EXF + 2 * 4 * NCO * 2;
+    static constexpr int EXF = 2048 * NW;                  // exchange area of the region epilogue: 8 KB per wave
+    static_assert(EXF >= UBUF, "U buffer 1 lives in the exchange area");
+    static constexpr size_t LDS_FLOATS = 2 * HBUF + UBUF + EXF + 2 * NMB * NCO * 2;
 };
 #ifdef W6_EXP_NO_BARRIER
 #define W6_ITEM_BARRIER() do {} while (0)
@@ -99,33 +112,40 @@ template <int RW, int MBW> struct W64Geo {
                                            // 2 -> 4: 32->64 @256 dgrad 0.447 -> 0.425 ms, 64->128 @128 0.318 -> 0.306, nothing slower)
 #endif
 constexpr int W6_CP = 26;                  // MFMA position of the first LDS commit of the prefetched data
+constexpr int W6_PB = 33, W6_CB = 58;      // second phase of U slots (four-wave workgroups): first issue, first commit
 
-template <int RW, int MBW, int EPI>
-__global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
-    constexpr bool MASK = EPI != 0;        // both forms read 16 values per (M block, N block) at the output positions
-    using G = W64Geo<RW, MBW>;
-    constexpr int NT = 512, NBW = G::NBW, NCO = G::NCO;
+template <int RW, int MBW, int EPI, int NW = 8>
+__global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
+    constexpr bool MASK = EPI >= 1 && EPI <= 3;   // these forms read 16 values per (M block, N block) at the output positions
+    using G = W64Geo<RW, MBW, NW>;
+    constexpr int NT = 64 * NW, NMB = G::NMB, NBW = G::NBW, NCO = G::NCO;
     constexpr int HWS = G::HWS, HWV = G::HWV, HBUF = G::HBUF, UBUF = G::UBUF;
     constexpr int HPIX = G::HR * HWV;          // 340 / 324 / 612 halo pixels
     constexpr int HF = HPIX * 2;               // float4 per halo chunk: 680 / 648 / 1224
     constexpr int LH = (HF + NT - 1) / NT;     // 2 / 2 / 3 halo slots per thread
-    constexpr int LU = NBW;                    // U slots per thread: 512 NBW float4 per chunk
+    constexpr int LU = 512 * NBW / NT;         // U slots per thread: 512 NBW float4 per chunk
     static_assert(HF > (LH - 1) * NT && HF >= NT, "every halo slot but the last is full");
-    static_assert(1 + (LH + LU) * W6_LS <= W6_CP && W6_CP + LH + LU <= 32, "prefetch slots fit the first half of an item");
+    // All slots in the first half of an item where they fit; otherwise the second half of the U slots forms a second phase
+    // (issued from position W6_PB on, committed from W6_CB on) that re-uses the registers of the first.
+    constexpr bool ONE_PHASE = 1 + (LH + LU) * W6_LS <= W6_CP && W6_CP + LH + LU <= 32;
+    constexpr int LUA = ONE_PHASE ? LU : LU / 2;
+    static_assert(1 + (LH + LUA) * W6_LS <= W6_CP && W6_CP + LH + LUA <= 32, "prefetch slots fit the first half of an item");
+    static_assert(ONE_PHASE || (LU == 2 * LUA && W6_PB + LUA * W6_LS <= W6_CB && W6_CB + LUA <= 64), "second U phase fits the second half");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Hs = smem;                      // [2][HBUF]
     float* Us = smem + 2 * HBUF;           // [2][UBUF]
     float* Ex = Us + UBUF;                 // exchange area of the region epilogue (64 KB): U buffer 1 (dead by then) + spare
-    float* Rs = Ex + G::EXF;               // [2][4 waves of a half][NCO couts][2] statistics of the waves' pixels
+    float* Rs = Ex + G::EXF;               // [2][NMB waves of a half][NCO couts][2] statistics of the waves' pixels
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: scalar branches on h
-    const int mb = wv & 3, h = wv >> 2;
+    const int mb = wv & (NMB - 1), h = wv / NMB;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     const __amdgpu_buffer_rsrc_t rsx = make_rsrc(a.x, a.nbx), rsu = make_rsrc(a.u, a.nbu), rsy = make_rsrc(a.y, a.nby);
     const __amdgpu_buffer_rsrc_t rsm = make_rsrc((EPI == 1 || EPI == 3) ? a.mask : a.y, a.nby);  // (instantiations of their own: the plain kernels keep their registers)
     const __amdgpu_buffer_rsrc_t rsr = make_rsrc(EPI == 3 ? a.mr : a.y, EPI == 3 ? (unsigned)((size_t)a.N * a.Cout * 8) : a.nby);
+    const __amdgpu_buffer_rsrc_t rsy2 = make_rsrc(EPI == 4 ? a.y2 : a.y, EPI == 4 ? a.nby2 : a.nby);
 
     const int ntn = a.ntn, nch = a.nch;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -167,15 +187,15 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
             h_voff[j] = sel_u32(ok, pix * (unsigned)Cin * 4u + (unsigned)c4 * 16u, 0xFFFFFFFFu);
         }
     };
-    // U float4 f = tid + 512 j -> row = xi * NCO + n = (tid >> 1) + 256 j, channel quad tid & 1
+    // U float4 f = tid + NT j -> row = xi * NCO + n = (tid >> 1) + NT / 2 j, channel quad tid & 1
     // (a wave's slot = 32 couts x 32 bytes = 1 KB in a row of the chunked layout [Cin / 8][16 xi][Cout][8])
     const int u_n = (tid >> 1) & (NCO - 1);
     const unsigned u_voff = (((unsigned)(tid >> 1) / NCO * Cout + co_base + u_n) * 8u + c4 * 4) * 4u;
-    const unsigned u_jstride = (256u / NCO) * Cout * 32u;                  // 256 rows = 256 / NCO xi further per slot
+    const unsigned u_jstride = (unsigned)(NT / 2 / NCO) * Cout * 32u;      // NT / 2 rows = NT / 2 / NCO xi further per slot
     const unsigned u_cstride = 16u * Cout * 32u;                           // per 8-channel chunk
-    const int u_lds = (tid >> 1) * 8 + ((c4 ^ ((u_n >> 3) & 1)) * 4);      // + j * 2048 floats
+    const int u_lds = (tid >> 1) * 8 + ((c4 ^ ((u_n >> 3) & 1)) * 4);      // + j * NT * 4 floats
 
-    float4 rh[LH], ru[LU];
+    float4 rh[LH], ru[LUA];
     auto issue_h = [&](int j, int chunk) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)h_voff[j], chunk * 32, 0);
         unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
@@ -184,7 +204,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     auto issue_u = [&](int j, int chunk) {
         u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsu, (int)u_voff, (int)(chunk * u_cstride + j * u_jstride), 0);
         unsigned a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
-        ru[j].x = __uint_as_float(a0); ru[j].y = __uint_as_float(a1); ru[j].z = __uint_as_float(a2); ru[j].w = __uint_as_float(a3);
+        float4& r = ru[j % LUA];
+        r.x = __uint_as_float(a0); r.y = __uint_as_float(a1); r.z = __uint_as_float(a2); r.w = __uint_as_float(a3);
     };
     auto commit_h = [&](int j, float* Hb) {    // a halo pixel is 40 bytes: two 8-byte-aligned halves
         float* p = Hb + h_lds[j];
@@ -193,7 +214,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
         *(f32x2*)p = lo;
         *(f32x2*)(p + 2) = hi;
     };
-    auto commit_u = [&](int j, float* Ub) { *(float4*)&Ub[u_lds + j * 2048] = ru[j]; };
+    auto commit_u = [&](int j, float* Ub) { *(float4*)&Ub[u_lds + j * (NT * 4)] = ru[j % LUA]; };
 
     // ---- item cursors: (image, strip, region row, chunk) of items i, i+1, i+2 ----
     int cn, ctx, cty, ch = 0;
@@ -290,11 +311,15 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
 #pragma unroll
     for (int j = 0; j < LH; ++j) issue_h(j, 0);
 #pragma unroll
-    for (int j = 0; j < LU; ++j) issue_u(j, 0);
+    for (int j = 0; j < LUA; ++j) issue_u(j, 0);
 #pragma unroll
     for (int j = 0; j < LH; ++j) commit_h(j, Hs);
 #pragma unroll
-    for (int j = 0; j < LU; ++j) commit_u(j, Us);
+    for (int j = 0; j < LUA; ++j) commit_u(j, Us);
+#pragma unroll
+    for (int j = LUA; j < LU; ++j) issue_u(j, 0);
+#pragma unroll
+    for (int j = LUA; j < LU; ++j) commit_u(j, Us);
     region_offsets(n1, tx1, ty1);
 #pragma unroll
     for (int j = 0; j < LH; ++j) issue_h(j, ch1);
@@ -336,8 +361,12 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
             if (p >= W6_CP && p < W6_CP + LH) commit_h(p - W6_CP, Hw);
 #endif
 #if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_ULOADS)
-            if (p >= 1 + LH * W6_LS && p < 1 + (LH + LU) * W6_LS && (p - 1) % W6_LS == 0) issue_u((p - 1) / W6_LS - LH, ch1);
-            if (p >= W6_CP + LH && p < W6_CP + LH + LU) commit_u(p - W6_CP - LH, Uw);
+            if (p >= 1 + LH * W6_LS && p < 1 + (LH + LUA) * W6_LS && (p - 1) % W6_LS == 0) issue_u((p - 1) / W6_LS - LH, ch1);
+            if (p >= W6_CP + LH && p < W6_CP + LH + LUA) commit_u(p - W6_CP - LH, Uw);
+            if (!ONE_PHASE) {
+                if (p >= W6_PB && p < W6_PB + LUA * W6_LS && (p - W6_PB) % W6_LS == 0) issue_u(LUA + (p - W6_PB) / W6_LS, ch1);
+                if (p >= W6_CB && p < W6_CB + LUA) commit_u(LUA + p - W6_CB, Uw);
+            }
 #endif
 #ifndef W6_EXP_NO_XFORM
             xform_slot(Hn, par ^ 1, p);
@@ -438,12 +467,18 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
 #pragma unroll
             for (int i = 0; i < NBW / 2; ++i) {
                 float yv[16];      // [r][a][b]
-                const unsigned co = (unsigned)(co_base + (hh * (NBW / 2) + i) * 16 + m);
+                const int co0 = co_base + (hh * (NBW / 2) + i) * 16;       // uniform
+                const unsigned co = (unsigned)(co0 + m);
+                // EPI 4: which tensor this N block belongs to (uniform), its channel stride and the lane's channel in it
+                const bool part0 = EPI == 4 && co0 < a.split;
+                const bool pooled = part0 && a.pool0;
+                const unsigned cs = EPI != 4 ? (unsigned)Cout : (unsigned)(part0 ? a.split : Cout - a.split);
+                const unsigned cc = EPI != 4 ? co : (part0 ? co : co - (unsigned)a.split);
                 int voffs[2];
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa) {
                     const int yy = yrow0 + aa;
-                    const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * (unsigned)Cout + co;
+                    const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * cs + cc;
                     voffs[aa] = (int)sel_u32(yy < H, base * 4u, 0xFFFFFFFFu);
                 }
                 float mk[16];
@@ -495,14 +530,25 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
                     if (w == 0) { st1[i] = s1; st2[i] = s2; }
                     else { st1[i] += s1; st2[i] += s2; }
                 }
+                if (EPI == 4 && pooled) {       // one value per tile at half resolution: tile r of the lane = low-res column xcol0 / 2 + r
+                    const unsigned base = (((unsigned)cn * (unsigned)(H >> 1) + (unsigned)(yrow0 >> 1)) * (unsigned)(W >> 1) + (unsigned)(xcol0 >> 1)) * cs + cc;
+                    const int voff = (int)sel_u32(yrow0 < H, base * 4u, 0xFFFFFFFFu);
 #pragma unroll
-                for (int aa = 0; aa < 2; ++aa) {
-                    const int voff = voffs[aa];
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = (yv[r * 4 + 0] + yv[r * 4 + 1]) + (yv[r * 4 + 2] + yv[r * 4 + 3]);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rsy, voff, r * (int)cs * 4, 0);
+                    }
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int aa = 0; aa < 2; ++aa) {
+                        const int voff = voffs[aa];
 #pragma unroll
-                        for (int b = 0; b < 2; ++b)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), rsy, voff, (2 * r + b) * Cout * 4, 0);
+                        for (int r = 0; r < 4; ++r)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), (EPI == 4 && !part0) ? rsy2 : rsy, voff,
+                                                                      (2 * r + b) * (int)cs * 4, 0);
+                    }
                 }
                 if (EPI != 3 && a.stats) {     // uniform: H % TR == 0 whenever statistics are requested
                     float t1, t2;
@@ -517,7 +563,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
         if (a.stats && lane < 16) {
 #pragma unroll
             for (int i = 0; i < NBW / 2; ++i) {
-                float* R = Rs + spar * (4 * NCO * 2) + (mb * NCO + (hh * (NBW / 2) + i) * 16 + lane) * 2;
+                float* R = Rs + spar * (NMB * NCO * 2) + (mb * NCO + (hh * (NBW / 2) + i) * 16 + lane) * 2;
                 R[0] = st1[i];
                 R[1] = st2[i];
             }
@@ -526,15 +572,15 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino64(W64Args a) {
     auto fold_stats = [&]() {          // after the barrier that follows epi_finish
         if (!a.stats) return;          // uniform
         if (tid < NCO) {
-            const float* R = Rs + spar * (4 * NCO * 2) + tid * 2;
-            float s1 = R[0], s2 = R[1];              // the four waves' 64 MBW pixels each, merged in order
+            const float* R = Rs + spar * (NMB * NCO * 2) + tid * 2;
+            float s1 = R[0], s2 = R[1];              // the NMB waves' 64 MBW pixels each, merged in order
             constexpr float PW = 64.f * MBW;
             if (EPI == 3) {
 #pragma unroll
-                for (int r = 1; r < 4; ++r) { s1 += R[r * NCO * 2]; s2 += R[r * NCO * 2 + 1]; }
+                for (int r = 1; r < NMB; ++r) { s1 += R[r * NCO * 2]; s2 += R[r * NCO * 2 + 1]; }
             } else {
 #pragma unroll
-                for (int r = 1; r < 4; ++r) stat_merge(s1, s2, PW * r, R[r * NCO * 2], R[r * NCO * 2 + 1], PW);
+                for (int r = 1; r < NMB; ++r) stat_merge(s1, s2, PW * r, R[r * NCO * 2], R[r * NCO * 2 + 1], PW);
             }
             const int t = (cn * a.tilesX + ctx) * a.tilesY + cty;
             float* o = a.stats + ((size_t)t * Cout + co_base + tid) * 2;
@@ -595,20 +641,25 @@ static int wino64_shape(int Cin, int Cout, int W) {
     if (Cout % 64 == 0) return 1;
     return (Cout % 32 == 0 && W % 32 == 0) ? 2 : 0;
 }
+// Waves per workgroup of a shape: the 32-cout shape (MBW = 2) runs as two four-wave workgroups per CU (VQW_WINO64_NW4=0: one
+// eight-wave workgroup, the round-3 form)
+static const int g_w64_nw4 = env_int64("VQW_WINO64_NW4", 1);
+static int wino64_waves(int shape) { return (shape == 2 && g_w64_nw4) ? 4 : 8; }
 bool conv_wino64_ok(int Cin, int Cout, int W) { return wino64_shape(Cin, Cout, W) != 0; }
 int conv_wino64_stat_tiles(int Cin, int Cout, int H, int W) {
-    const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? 8 * wino64_shape(Cin, Cout, W) : 16;
+    const int shape = wino64_shape(Cin, Cout, W);
+    const int rw = W % 32 == 0 ? 32 : 16, tr = rw == 32 ? shape * wino64_waves(shape) : 16;
     return tr > 0 && H % tr == 0 ? (H / tr) * (W / rw) : 0;
 }
 
-template <int RW, int MBW, int EPI>
+template <int RW, int MBW, int EPI, int NW = 8>
 static int launch_wino64(W64Args& a, hipStream_t st) {
-    using G = W64Geo<RW, MBW>;
+    using G = W64Geo<RW, MBW, NW>;
     constexpr size_t lds = G::LDS_FLOATS * sizeof(float);
-    static_assert(lds <= 160 * 1024, "buffers do not fit the 160 KB LDS");
+    static_assert(lds * (8 / NW) <= 160 * 1024, "buffers do not fit the 160 KB LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_conv_wino64<RW, MBW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)k_conv_wino64<RW, MBW, EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             vqw_set_error("conv_wino64: cannot raise the dynamic LDS limit");
             return VQW_ERR_HIP;
         }
@@ -616,11 +667,11 @@ static int launch_wino64(W64Args& a, hipStream_t st) {
     }
     a.tilesY = ceil_div(a.H, G::TR); a.tilesX = a.W / RW; a.nsp = a.N * a.tilesY * a.tilesX;
     a.ntn = a.Cout / G::NCO;
-    int groups = g_w64_max_blocks / a.ntn;
+    int groups = g_w64_max_blocks * (8 / NW) / a.ntn;
     if (groups < 1) groups = 1;
     const int even = ceil_div(a.nsp, groups);
     a.kt = even < 1 ? 1 : even;
-    k_conv_wino64<RW, MBW, EPI><<<ceil_div(a.nsp, a.kt) * a.ntn, 512, lds, st>>>(a);
+    k_conv_wino64<RW, MBW, EPI, NW><<<ceil_div(a.nsp, a.kt) * a.ntn, 64 * NW, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino64");
     return VQW_OK;
 }
@@ -628,6 +679,7 @@ static int launch_wino64(W64Args& a, hipStream_t st) {
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
                     hipStream_t st, float* stats, const float* mask, int accumulate, const float* in_mr, int in_relu) {
     W64Args a;
+    a.y2 = nullptr; a.split = 0; a.pool0 = 0; a.nby2 = 0;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.mask = mask; a.mr = in_mr; a.in_relu = in_relu;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.nch = Cin / 8;
@@ -638,6 +690,12 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
     a.nbu = (unsigned)(16L * Cout * Cin * 4);
     a.nby = (unsigned)(P * Cout * 4);
     const int shape = wino64_shape(Cin, Cout, W);
+    if (shape == 2 && wino64_waves(shape) == 4) {
+        if (in_mr) return launch_wino64<32, 2, 3, 4>(a, st);
+        if (mask) return launch_wino64<32, 2, 1, 4>(a, st);
+        if (accumulate) return launch_wino64<32, 2, 2, 4>(a, st);
+        return launch_wino64<32, 2, 0, 4>(a, st);
+    }
     if (in_mr) {               // (mask = the norm's raw input, stats = the backward sums)
         if (shape == 2) return launch_wino64<32, 2, 3>(a, st);
         if (W % 32 == 0) return launch_wino64<32, 1, 3>(a, st);
@@ -656,6 +714,35 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
     if (shape == 2) return launch_wino64<32, 2, 0>(a, st);
     if (W % 32 == 0) return launch_wino64<32, 1, 0>(a, st);
     return launch_wino64<16, 1, 0>(a, st);
+}
+
+// Two output tensors from one launch (EPI 4): couts [0, split) -> y0 (pool0: summed over each 2 x 2 tile, at half resolution),
+// [split, Cout) -> y1.  Serves (i) the input gradient of a 3x3 layer over [up2x(a) | b] - the gradients of a and of b come
+// out of the epilogue instead of out of two gather passes over the concatenated gradient - and (ii) two layers of one input
+// as one launch on concatenated weights.  split % 16 == 0 (an N block never straddles the two tensors).
+bool conv_wino64_split_ok(int Cin, int Cout, int split, int pool0, int N, int H, int W) {
+    if (!conv_wino64_ok(Cin, Cout, W) || g_wino_mode != 0 || split <= 0 || split >= Cout || split % 16 != 0) return false;
+    if (pool0 && (H % 2 != 0)) return false;
+    return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
+}
+int conv_wino64_fwd_split(const float* x, const float* u, const float* bias, float* y0, float* y1, int N, int H, int W, int Cin, int Cout,
+                          int split, int pool0, int relu, hipStream_t st) {
+    W64Args a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y0; a.y2 = y1; a.mask = nullptr; a.mr = nullptr; a.in_relu = 0;
+    a.split = split; a.pool0 = pool0;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.nch = Cin / 8;
+    a.relu = relu;
+    a.stats = nullptr;
+    const long P = (long)N * H * W;
+    a.nbx = (unsigned)(P * Cin * 4);
+    a.nbu = (unsigned)(16L * Cout * Cin * 4);
+    a.nby = (unsigned)((pool0 ? P / 4 : P) * split * 4);
+    a.nby2 = (unsigned)(P * (Cout - split) * 4);
+    const int shape = wino64_shape(Cin, Cout, W);
+    if (shape == 2) return wino64_waves(shape) == 4 ? launch_wino64<32, 2, 4, 4>(a, st) : launch_wino64<32, 2, 4>(a, st);
+    if (W % 32 == 0) return launch_wino64<32, 1, 4>(a, st);
+    return launch_wino64<16, 1, 4>(a, st);
 }
 
 // =====================================================================================================================

@@ -747,6 +747,106 @@ def conv2d_up_pair(x, weight_a, bias_a, weight_b, bias_b, grad_group=None):
     return (ya, pa), (yb, pb)
 
 
+# ----------------------------------------------------------------------------------------------
+# two plain 3x3 layers of one input as ONE launch on concatenated weights (StyledResUpBlock: the mlp_shared convolutions of its two
+# StyledDenorms read the same style tensor, blocks.py:72-75 / 100-134)
+# ----------------------------------------------------------------------------------------------
+CONV_PAIR = os.environ.get("VQW_CONV_PAIR", "1") != "0"      # 0: the two layers run one by one (A/B timing)
+conv_pair_calls = 0
+
+
+class _ConvPair(torch.autograd.Function):
+    """(y_a, y_b) = conv2d(x, w_a, b_a, relu=relu), conv2d(x, w_b, b_b, relu=relu) in Winograd form, one launch of the 64-cout
+    kernel with a two-tensor epilogue (vqw_conv3x3_wino_fwd_split): the input is read and transformed once, and two 32-cout
+    layers leave the 128-tile x 32-cout workgroup shape for the 64 x 64 one.  The backward is the two layers' own."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, relu, group):
+        global conv_pair_calls
+        _dev(x, wa, ba, wb, bb)
+        x = nhwc(x)
+        Ca, Cin, ks, _ = wa.shape
+        N, _, H, W = x.shape
+        L = _L()
+        if tuple(wb.shape) != tuple(wa.shape) or ks != 3 or (ba is None) != (bb is None) \
+                or not L.vqw_conv3x3_wino_split_supported(Cin, 2 * Ca, Ca, 0, N, H, W):
+            raise RuntimeError("conv2d_pair: shape not served (query vqw_conv3x3_wino_split_supported)")
+
+        def _prep():
+            wc = torch.empty((2 * Ca, Cin, 3, 3), dtype=torch.float32, device=wa.device, memory_format=CL)
+            wc[:Ca].copy_(wa.detach())
+            wc[Ca:].copy_(wb.detach())
+            u = _wino_weights(L, wc, Cin, 2 * Ca)
+            bc = torch.cat([ba.detach().reshape(-1), bb.detach().reshape(-1)]) if ba is not None else None
+            return u, bc
+        deps = (wb,) + tuple(t for t in (ba, bb) if t is not None)
+        u, bias_cat = _cached(wa, "pair_wino", _prep, deps=deps)
+        ya = empty_nhwc(N, Ca, H, W, x)
+        yb = empty_nhwc(N, Ca, H, W, x)
+        _lib.check(L.vqw_conv3x3_wino_fwd_split(_p(x), _p(u), _p(bias_cat), _p(ya), _p(yb), N, H, W, Cin, 2 * Ca, Ca, 0, int(relu), _st()),
+                   "vqw_conv3x3_wino_fwd_split")
+        conv_pair_calls += 1
+        ctx.save_for_backward(x, nhwc(wa), nhwc(wb), ya if relu else None, yb if relu else None)
+        ctx.group = group
+        ctx.cfg = (N, H, W, Ca, Cin)
+        ctx.params = ((wa, ba), (wb, bb))
+        ctx.defer = []
+        for i, (wgt, bias) in enumerate(ctx.params):
+            d = (WGRAD_ASYNC and ctx.needs_input_grad[1 + 2 * i] and wgt.is_leaf and nhwc(wgt) is wgt
+                 and not wgrad_through_autograd(wgt, bias) and (bias is None or (bias.is_leaf and bias.is_contiguous())))
+            ctx.defer.append(d)
+            if d:
+                wgt._vqw_pending = getattr(wgt, "_vqw_pending", 0) + 1
+        ctx.set_materialize_grads(False)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        x, wa_n, wb_n, ya, yb = ctx.saved_tensors
+        N, H, W, Cout, Cin = ctx.cfg
+        out = [None] * 7
+        gx_total = None
+        # (the second layer's input gradient runs first, like the second of two separate nodes would)
+        for i in (1, 0):
+            gy = (ga, gb)[i]
+            if gy is None:
+                if ctx.group is not None:
+                    raise RuntimeError("conv2d_pair: both outputs must take part in the backward pass of a gradient group")
+                continue
+            wgt, bias = ctx.params[i]
+            w_n = (wa_n, wb_n)[i]
+            need0 = ctx.needs_input_grad[0]
+            needw, needb = ctx.needs_input_grad[1 + 2 * i], (bias is not None and ctx.needs_input_grad[2 + 2 * i])
+            defer = ctx.defer[i] and (needw or needb)
+            g0, _, gw, gbias, gy_n = conv2d_backward_impl(gy, x, None, w_n, (ya, yb)[i], 1, False, bias is not None, None, need0, False,
+                                                          needw and not defer, needb and not defer, group=ctx.group)
+            if defer:
+                _deferred_wgrad(wgt, bias if (bias is not None and bias.requires_grad) else None, x, None, gy_n, False, 3, 1,
+                                N, H, W, Cout)
+            out[1 + 2 * i], out[2 + 2 * i] = gw, gbias
+            if g0 is not None:
+                gx_total = g0 if gx_total is None else gx_total.add_(g0)
+        out[0] = gx_total
+        return tuple(out)
+
+
+def conv2d_pair_supported(x, weight_a, weight_b):
+    """True when conv2d_pair serves these two layers here: both 3x3 of one shape, the Winograd forward admitted at this point of the
+    graph (ops.winograd_forward() / evaluation), the 64-cout kernel's geometry."""
+    if not (CONV_PAIR and x.is_cuda and weight_a.shape == weight_b.shape and weight_a.shape[2] == 3 and not _in_custom_op
+            and _decide_wino_fwd()):
+        return False
+    N, _, H, W = x.shape
+    Ca, Cin = weight_a.shape[0], weight_a.shape[1]
+    L = _L()
+    return bool(L.vqw_conv3x3_wino_supported(Cin, 2 * Ca, N, H, W) and L.vqw_conv3x3_wino_split_supported(Cin, 2 * Ca, Ca, 0, N, H, W))
+
+
+def conv2d_pair(x, weight_a, bias_a, weight_b, bias_b, relu=False, grad_group=None):
+    """-> (y_a, y_b): conv2d(x, w, b, relu=relu) of two 3x3 layers of one input, one launch."""
+    return _ConvPair.apply(x, weight_a, bias_a, weight_b, bias_b, bool(relu), grad_group if GRAD_GROUPS else None)
+
+
 # Gradients that arrive already multiplied by a fused ReLU's mask: payload = data_ptr of the ReLU output the gradient was masked
 # with.  Written by a consumer whose input-gradient kernel applies the mask in its epilogue (vqw_conv3x3_wino_fwd_masked),
 # taken by the producer's backward, which then skips its own mask pass.
@@ -773,6 +873,8 @@ def begin_step():
 in_bwd_fused_calls = 0         # InstanceNorm backward calls that took their sums from a convolution's epilogue (tests)
 masked_dgrad_calls = 0         # input-gradient launches that applied a ReLU mask in their epilogue (tests)
 group_acc_calls = 0            # Winograd input-gradient launches that added to a gradient group's buffer in their epilogue (tests)
+split_dgrad_calls = 0          # two-source input-gradient launches whose epilogue wrote both sources' gradients (tests)
+SPLIT_DGRAD = os.environ.get("VQW_SPLIT_DGRAD", "1") != "0"      # 0: concatenated gradient + two gather passes (A/B)
 
 
 def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, need0, need1, needw, needb, group=None, in_src=None):
@@ -815,6 +917,24 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
             return buf
         wt = _cached(w, "dgrad", _pack)
+        if SPLIT_DGRAD and x1 is not None and need0 and need1 and group is None and ks == 3 and dilation == 1 \
+                and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W) \
+                and L.vqw_conv3x3_wino_split_supported(Cout, Cin, C0, int(up0), N, H, W):
+            # two sources [up2x(x0) | x1]: both gradients leave the input-gradient kernel's epilogue (x0's summed over each 2 x 2
+            # tile when x0 was up-sampled: a Winograd tile IS one low-resolution pixel) instead of two gather passes over the
+            # concatenated gradient
+            global split_dgrad_calls
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+            g0 = torch.empty_like(x0, memory_format=CL)
+            g1 = torch.empty_like(x1, memory_format=CL)
+            _lib.check(L.vqw_conv3x3_wino_fwd_split(_p(gy), _p(ut), None, _p(g0), _p(g1), N, H, W, Cout, Cin, C0, int(up0), 0, _st()),
+                       "vqw_conv3x3_wino_fwd_split(dgrad)")
+            split_dgrad_calls += 1
+            if needw or (needb and has_bias):
+                gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+                gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
+                _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, False, up_ws is not None)
+            return g0, g1, gw, gb, gy
         if group is not None and need0 and group.buf is not None:
             # a later member of a gradient group (single full-resolution source): add into the shared buffer
             if ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W) \

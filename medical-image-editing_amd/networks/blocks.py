@@ -160,11 +160,13 @@ class StyledDenorm(nn.Module):
         self.mlp_gamma = conv3x3(in_channels, in_channels)
         self.mlp_beta = conv3x3(in_channels, in_channels)
 
-    def style_maps(self, style, grad_group=None):
+    def style_maps(self, style, grad_group=None, actv=None):
         """(gamma, beta) of reference blocks.py:85-87: a function of the style input only, so a caller may evaluate
         it ahead of / beside the trunk and hand it to forward().  grad_group: the ops.GradGroup of the convolutions that
-        read this style tensor (the two StyledDenorms of a StyledResUpBlock)."""
-        actv = self.mlp_shared[0](style, relu=True, grad_group=grad_group)
+        read this style tensor (the two StyledDenorms of a StyledResUpBlock).  actv: mlp_shared's output when the caller has
+        computed it already (both StyledDenorms' mlp_shared convolutions in one launch, ops.conv2d_pair)."""
+        if actv is None:
+            actv = self.mlp_shared[0](style, relu=True, grad_group=grad_group)
         if FUSE_GAMMA_BETA:     # one conv with [gamma | beta] output channels
             return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias, relu_input=True), None
         return self.mlp_gamma(actv), self.mlp_beta(actv)
@@ -223,8 +225,15 @@ class StyledResUpBlock(nn.Module):
         # both mlp_shared convolutions read skip_input: one gradient group (their input gradients meet in the second one's epilogue)
         grp = ops.GradGroup(2) if (GRAD_GROUP_BLOCKS and skip_input.requires_grad) else None
         with ops.Branch(skip_input) as br:
-            m1 = self.norm1.style_maps(skip_input, grad_group=grp)
-            m2 = self.norm2.style_maps(skip_input, grad_group=grp)
+            c1, c2 = self.norm1.mlp_shared[0], self.norm2.mlp_shared[0]
+            if ops.conv2d_pair_supported(skip_input, c1.weight, c2.weight):
+                # both mlp_shared convolutions (+ReLU) read skip_input: one launch on the concatenated weights
+                a1, a2 = ops.conv2d_pair(skip_input, c1.weight, c1.bias, c2.weight, c2.bias, relu=True, grad_group=grp)
+                m1 = self.norm1.style_maps(skip_input, actv=a1)
+                m2 = self.norm2.style_maps(skip_input, actv=a2)
+            else:
+                m1 = self.norm1.style_maps(skip_input, grad_group=grp)
+                m2 = self.norm2.style_maps(skip_input, grad_group=grp)
         return br, m1, m2
 
     def forward(self, down_input, skip_input, maps=None):

@@ -127,6 +127,11 @@ CONV_CASES = [
     (1, 16, 64, 32, 16, True, 64, 3, 1, False, True),
     (2, 32, 16, 128, 64, True, 64, 3, 1, True, False),
     (1, 24, 32, 16, 32, False, 32, 3, 1, True, False),
+    # ... whose input gradients leave the epilogue of the 64-cout kernel as two tensors (round 4: vqw_conv3x3_wino_fwd_split):
+    # both workgroup shapes, ragged heights, with and without the up-sampling
+    (2, 20, 32, 128, 64, True, 64, 3, 1, True, False),
+    (1, 22, 64, 64, 32, True, 32, 3, 1, False, True),
+    (1, 24, 64, 64, 32, False, 32, 3, 1, True, False),
     # collapsed up-sampled forward on the halo kernel's 4-tap form (low-resolution width a multiple of 32): two cout tile
     # widths, ragged low-res height, ReLU epilogue
     (2, 32, 128, 64, 0, True, 32, 3, 1, True, False),
@@ -706,6 +711,112 @@ def test_upsampled_layer_pair_as_one_launch(monkeypatch):
             continue
         assert_close(g1[k], g0[k], 1e-4, "gradient %s, paired launch" % k)
         assert_close(g2[k], g0[k], 1e-4, "gradient %s, paired launch without gradient groups" % k)
+
+
+def test_style_layer_pair_as_one_launch(monkeypatch):
+    """The mlp_shared convolutions (+ReLU) of a StyledResUpBlock's two StyledDenorms read the same style tensor (blocks.py:72-75,
+    100-134): inside ops.winograd_forward() they run as ONE launch of the 64-cout Winograd kernel on concatenated weights with a
+    two-tensor epilogue (ops.conv2d_pair, vqw_conv3x3_wino_fwd_split).  Outputs and every gradient agree with the block run layer
+    by layer (VQW_CONV_PAIR=0) to rounding; outside the scope (the Winograd forward not admitted) the pair is not taken."""
+    from networks import blocks as B
+    from hipops import ops
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+
+    def run(pair, scope=True, groups=True, ch=32):
+        monkeypatch.setattr(ops, "CONV_PAIR", pair)
+        monkeypatch.setattr(B, "GRAD_GROUP_BLOCKS", groups)
+        torch.manual_seed(17)
+        mod = B.StyledResUpBlock(2 * ch, ch, ch).to(DEV).train()
+        down = cl(torch.randn(2, 2 * ch, 20, 32, device=DEV)).requires_grad_(True)
+        skip = cl(torch.randn(2, ch, 40, 64, device=DEV)).requires_grad_(True)
+        r = cl(torch.randn(2, ch, 40, 64, device=DEV))
+        n0 = ops.conv_pair_calls
+        import contextlib
+        with (ops.winograd_forward() if scope else contextlib.nullcontext()):
+            out = mod(down, skip)
+        (out * r).sum().backward()
+        torch.cuda.synchronize()
+        grads = {"down": down.grad.clone(), "skip": skip.grad.clone()}
+        grads.update({k: p.grad.clone() for k, p in mod.named_parameters()})
+        return out.detach(), grads, ops.conv_pair_calls - n0
+    for ch in (32, 64):
+        y0, g0, n0 = run(False, ch=ch)
+        y1, g1, n1 = run(True, ch=ch)
+        y2, g2, n2 = run(True, groups=False, ch=ch)
+        assert n0 == 0 and n1 == 1 and n2 == 1, (n0, n1, n2)
+        assert_close(y1, y0, 2e-5, "block output, paired style layers vs layer by layer")
+        gmax = max(float(v.abs().max()) for v in g0.values())
+        for k in g0:
+            if float(g0[k].abs().max()) < 1e-4 * gmax:      # a bias in front of a norm: analytically zero
+                continue
+            assert_close(g1[k], g0[k], 1e-4, "gradient %s, paired style layers" % k)
+            assert_close(g2[k], g0[k], 1e-4, "gradient %s, paired style layers without gradient groups" % k)
+    _, _, n3 = run(True, scope=False)
+    assert n3 == 0, "the pair is a Winograd-form forward: only where that form is admitted"
+
+
+def test_conv_pair_against_fp64():
+    """ops.conv2d_pair itself: both outputs, the input gradient and all four parameter gradients against an fp64 convolution
+    (2e-5), on both workgroup shapes' geometries (32-wide regions, ragged height; 16-wide regions)."""
+    from hipops import ops
+    for (N, C, Ca, H, W, relu) in [(2, 32, 32, 22, 64, True), (1, 64, 48, 16, 32, False), (2, 32, 64, 16, 16, True)]:
+        g = torch.Generator().manual_seed(N * 1000 + C + Ca)
+        x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+        ws = [torch.randn(Ca, C, 3, 3, generator=g, dtype=torch.float64) * 0.2 for _ in range(2)]
+        bs = [torch.randn(Ca, generator=g, dtype=torch.float64) for _ in range(2)]
+        rs = [torch.randn(N, Ca, H, W, generator=g, dtype=torch.float64) for _ in range(2)]
+        leaves = [t.clone().requires_grad_(True) for t in [x] + ws + bs]
+        ys = [F.conv2d(leaves[0], leaves[1 + i], leaves[3 + i], padding=1) for i in range(2)]
+        if relu:
+            ys = [torch.relu(y) for y in ys]
+        sum((y * r).sum() for y, r in zip(ys, rs)).backward()
+        dx = x.float().to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        dws = [w.float().to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) for w in ws]
+        dbs = [b.float().to(DEV).requires_grad_(True) for b in bs]
+        with ops.winograd_forward():
+            assert ops.conv2d_pair_supported(dx, dws[0], dws[1])
+            ya, yb = ops.conv2d_pair(dx, dws[0], dbs[0], dws[1], dbs[1], relu=relu)
+        ((ya * rs[0].float().to(DEV)).sum() + (yb * rs[1].float().to(DEV)).sum()).backward()
+        torch.cuda.synchronize()
+        tag = "pair %s" % ((N, C, Ca, H, W, relu),)
+        assert_close(ya, ys[0], 2e-5, tag + " y_a")
+        assert_close(yb, ys[1], 2e-5, tag + " y_b")
+        assert_close(dx.grad, leaves[0].grad, 2e-5, tag + " dx")
+        for i in range(2):
+            assert_close(dws[i].grad, leaves[1 + i].grad, 2e-5, tag + " dw%d" % i)
+            assert_close(dbs[i].grad, leaves[3 + i].grad, 2e-5, tag + " db%d" % i)
+
+
+def test_two_source_input_gradient_leaves_the_epilogue_split(monkeypatch):
+    """UpBlock's first convolution reads [nearest-up2x(down) | skip] (blocks.py:9-18): its input-gradient kernel writes the
+    gradient of `down` (each 2 x 2 Winograd tile summed to one low-resolution pixel) and of `skip` from its epilogue
+    (vqw_conv3x3_wino_fwd_split) instead of materialising the concatenated gradient and gathering it twice.  Both gradients
+    agree with the gather route (VQW_SPLIT_DGRAD=0) to rounding; shapes the 64-cout kernel does not serve keep the gather route."""
+    from hipops import ops
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+
+    def run(split, N, H, W, C0, C1, up, Cout):
+        monkeypatch.setattr(ops, "SPLIT_DGRAD", split)
+        torch.manual_seed(23)
+        hs, ws_ = (H // 2, W // 2) if up else (H, W)
+        x0 = cl(torch.randn(N, C0, hs, ws_, device=DEV)).requires_grad_(True)
+        x1 = cl(torch.randn(N, C1, H, W, device=DEV)).requires_grad_(True)
+        w = cl(torch.randn(Cout, C0 + C1, 3, 3, device=DEV) * 0.1).requires_grad_(True)
+        r = cl(torch.randn(N, Cout, H, W, device=DEV))
+        n0 = ops.split_dgrad_calls
+        y = ops.conv2d(x0, w, None, up2x=up, skip=x1)
+        (y * r).sum().backward()
+        torch.cuda.synchronize()
+        return x0.grad.clone(), x1.grad.clone(), w.grad.clone(), ops.split_dgrad_calls - n0
+    for shape, served in [((2, 20, 32, 64, 32, True, 32), True), ((1, 32, 16, 128, 64, True, 64), True),
+                          ((2, 24, 64, 64, 32, False, 32), True), ((1, 22, 64, 256, 128, True, 128), True),
+                          ((1, 16, 64, 32, 16, True, 64), False)]:
+        a0, a1, aw, na = run(False, *shape)
+        b0, b1, bw, nb = run(True, *shape)
+        assert na == 0 and nb == (1 if served else 0), (shape, na, nb)
+        assert_close(b0, a0, 2e-6, "gradient of the up-sampled source %s" % (shape,))
+        assert_close(b1, a1, 2e-6, "gradient of the skip source %s" % (shape,))
+        assert_close(bw, aw, 1e-6, "weight gradient %s" % (shape,))
 
 
 def test_deferred_slab_folds_match_immediate_folds(monkeypatch):
