@@ -131,6 +131,10 @@ int vqw_conv3x3_up2_wgrad(const float* x_low, const float* dy, float* dw_ohwi, f
 int vqw_conv3x3_wino_supported(int Cin, int Cout, int N, int H, int W);
 size_t vqw_conv3x3_wino_ws_bytes(int Cin, int Cout);
 int vqw_conv3x3_wino_prepare(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream);
+/* The same for a layer's INPUT-GRADIENT convolution, straight from the layer's own weight (ABI 8): w_ohwi = the layer's
+ * [Cin][3][3][Cout] tensor (its couts are this convolution's Cin input channels); equals vqw_pack_dgrad_weights followed by
+ * vqw_conv3x3_wino_prepare(.., Cin, Cout), bit for bit, without the packed copy. */
+int vqw_conv3x3_wino_prepare_dgrad(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream);
 int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
                          int relu, void* stream);
 /* ABI 7.  The same convolution with its outputs zeroed where mask <= 0 (mask shaped like y, no bias): the input gradient of

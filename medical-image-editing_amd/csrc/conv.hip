@@ -383,6 +383,11 @@ extern "C" int vqw_conv3x3_wino_prepare(const float* w_ohwi, void* ws, size_t ws
     VQW_CHECK(ws_bytes >= vqw_conv3x3_wino_ws_bytes(Cin, Cout), "vqw_conv3x3_wino_prepare: workspace too small");
     return conv_wino_prepare(w_ohwi, (float*)ws, Cin, Cout, (hipStream_t)stream);
 }
+extern "C" int vqw_conv3x3_wino_prepare_dgrad(const float* w_ohwi, void* ws, size_t ws_bytes, int Cin, int Cout, void* stream) {
+    VQW_CHECK(w_ohwi && ws && Cin > 0 && Cout > 0, "vqw_conv3x3_wino_prepare_dgrad: bad arguments");
+    VQW_CHECK(ws_bytes >= vqw_conv3x3_wino_ws_bytes(Cin, Cout), "vqw_conv3x3_wino_prepare_dgrad: workspace too small");
+    return conv_wino_prepare(w_ohwi, (float*)ws, Cin, Cout, (hipStream_t)stream, 1);
+}
 extern "C" int vqw_conv3x3_wino_fwd(const float* x, const void* ws, const float* bias, float* y, int N, int H, int W, int Cin,
                                     int Cout, int relu, void* stream) {
     VQW_CHECK(x && ws && y && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_fwd: bad arguments");

@@ -54,7 +54,7 @@ int conv_dil_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws, int 
 extern int g_wino_mode;
 bool conv_wino_ok(int Cin, int Cout, int N, int H, int W);
 size_t conv_wino_ws_floats(int Cin, int Cout);
-int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st);
+int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st, int transposed = 0);
 int conv_wino_stat_tiles(int Cin, int Cout, int H, int W);
 // ... on the low-VALU kernel of conv_wino64.hip: 64-cout tile (Cout % 64 == 0) or two M blocks x 32 couts (Cout % 32 == 0, W % 32 == 0)
 bool conv_wino64_ok(int Cin, int Cout, int W);
@@ -75,10 +75,10 @@ int conv_wino_wgrad_blocks(const ConvIn& in, int Cout, int N, int H, int W, int 
 bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);
 bool conv_wino32_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);       // (32 co x 32 ci) blocks: Cout % 64 == 32
 int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
-int conv_wino32_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+int conv_wino32_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
                       hipStream_t st);
 int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
-int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+int conv_wino64_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
                       hipStream_t st);
 int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st);

@@ -44,13 +44,18 @@ static const int g_max_blocks = []{ int v = env_int("VQW_CONV_MAX_BLOCKS", 256);
 
 // U[xi = i*4 + j][co][ci] = sum_{ky,kx} G[i][ky] g[co][ky][kx][ci] G[j][kx],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
 // chunked = 1: [ci / 8][xi][co][ci % 8] - what the kernels stream: the couts of a (chunk, xi) lie in a row, 32 bytes each
-__global__ void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int chunked) {
+// transposed = 1: w is the LAYER's OHWI weight [Cin][3][3][Cout] (its couts = this transform's "input" channels) and U is that
+// of the layer's input-gradient convolution, g[ky][kx] = w[ci][2-ky][2-kx][co] - what vqw_pack_dgrad_weights + this kernel give,
+// without the packed copy
+__global__ void k_wino_weights(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int chunked, int transposed) {
     const long n = (long)Cout * Cin;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int co = (int)(e / Cin), ci = (int)(e % Cin);
         double g[3][3], t[4][3];
         for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) g[ky][kx] = (double)w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+            for (int kx = 0; kx < 3; ++kx)
+                g[ky][kx] = transposed ? (double)w[(((long)ci * 3 + (2 - ky)) * 3 + (2 - kx)) * Cout + co]
+                                       : (double)w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
         for (int kx = 0; kx < 3; ++kx) {
             t[0][kx] = g[0][kx];
             t[1][kx] = 0.5 * (g[0][kx] + g[1][kx] + g[2][kx]);
@@ -471,9 +476,9 @@ bool conv_wino_ok(int Cin, int Cout, int N, int H, int W) {
     return (long)H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L && 16L * Cout * Cin * 4 <= 0xFFFFFFE0L;
 }
 size_t conv_wino_ws_floats(int Cin, int Cout) { return (size_t)16 * Cout * Cin; }
-int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st) {
+int conv_wino_prepare(const float* w, float* u, int Cin, int Cout, hipStream_t st, int transposed) {
     const long n = (long)Cout * Cin;
-    k_wino_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, u, Cout, Cin, 1);      // every kernel streams the chunked layout
+    k_wino_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, u, Cout, Cin, 1, transposed);      // every kernel streams the chunked layout
     VQW_LAUNCH_CHECK("wino_weights");
     return VQW_OK;
 }
@@ -826,8 +831,8 @@ int conv_wino_wgrad_blocks(const ConvIn& in, int Cout, int N, int H, int W, int 
 int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cout, int nsb, int kt,
                     hipStream_t st) {
     const int Cin = in.C0 + in.C1;
-    if (conv_wino64_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino64_wgrad(in.src0, dy, ws, bpart, N, H, W, Cin, Cout, nsb, kt, st);
-    if (conv_wino32_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino32_wgrad(in.src0, dy, ws, bpart, N, H, W, Cin, Cout, nsb, kt, st);
+    if (conv_wino64_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino64_wgrad(in, dy, ws, bpart, N, H, W, Cin, Cout, nsb, kt, st);
+    if (conv_wino32_wgrad_ok(in.C0, in.C1, in.up0, Cout, H, W)) return conv_wino32_wgrad(in, dy, ws, bpart, N, H, W, Cin, Cout, nsb, kt, st);
     constexpr size_t lds = (size_t)(2 * (WW_D + WW_X) + 512 * 4) * sizeof(float);
     static_assert(lds <= 160 * 1024 && lds >= 8 * 512 * sizeof(float), "Winograd wgrad tiles do not fit the LDS");
     static bool attr_set = false;

@@ -769,6 +769,12 @@ struct W64WgArgs {
     int tilesY, tilesX, nsp;
     int n_ci_b, nblk, kt;
     unsigned nbx, nbd;         // bytes of x / dy
+    // two sources [up2x?(x) | x1] (UpBlock's first convolution): ci blocks [0, C0) read x (C0 channels per pixel, at half
+    // resolution when up0), the others x1 (Cin - C0 channels); a ci block never straddles the two (C0 % 32 == 0).  C0 == Cin:
+    // one full-resolution source.
+    const float* x1;
+    int C0, up0;
+    unsigned nbx1;
 };
 
 #ifndef W6_WLS
@@ -820,6 +826,13 @@ __global__ void __launch_bounds__(512, 1) W6_WG_ATTR k_conv_wino_wgrad64(W64WgAr
     const unsigned d_jstride = (unsigned)((RW == 32 ? 1 : 2) * W) * Cout * 4u;      // 32 pixels further: one / two rows
     const int d_lds = d_px * WG_DP + (tid & 15) * 4;                      // + j * 32 * WG_DP
     // X float4 f = tid + 512 j -> halo pixel f / 8, ci quad f % 8 = tid & 7; slots past the end repeat another thread's
+    // the source of this workgroup's ci block (uniform): its pointer, channels per pixel, first channel, row length
+    const bool x_s1 = ci_base >= a.C0;
+    const bool x_up = !x_s1 && a.up0;
+    const float* x_ptr = x_s1 ? a.x1 : a.x;
+    const int x_cs = x_s1 ? Cin - a.C0 : a.C0, x_cb = x_s1 ? ci_base - a.C0 : ci_base;
+    const int x_w = x_up ? W >> 1 : W, x_h = x_up ? H >> 1 : H;
+    const long x_nb = x_s1 ? (long)a.nbx1 : (long)a.nbx;
     unsigned x_fix[LX];
     int x_lds[LX];
     unsigned x_bits = 0;                   // 4 bits per slot: the pixel lies on the halo's top / bottom row, left / right column
@@ -828,7 +841,8 @@ __global__ void __launch_bounds__(512, 1) W6_WG_ATTR k_conv_wino_wgrad64(W64WgAr
         int f = tid + j * NT;
         if (f >= XF) f -= XF;
         const int hp = f >> 3, hy = hp / XW, hx = hp - hy * XW;
-        x_fix[j] = ((unsigned)(hy * W + hx) * Cin + ci_base + (tid & 7) * 4) * 4u;     // against the pixel (y0 - 1, x0 - 1)
+        // against the pixel (y0 - 1, x0 - 1); an up-sampled source: against the low-resolution pixel (y0 / 2 - 1, x0 / 2 - 1)
+        x_fix[j] = ((unsigned)((x_up ? (hy + 1) >> 1 : hy) * x_w + (x_up ? (hx + 1) >> 1 : hx)) * x_cs + x_cb + (tid & 7) * 4) * 4u;
         x_lds[j] = 2 * DBUF + hp * WG_XP + (tid & 7) * 4;
         x_bits |= (unsigned)((hy == 0 ? 1 : 0) | (hy == G::XR - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == XW - 1 ? 8 : 0)) << (4 * j);
     }
@@ -851,9 +865,10 @@ __global__ void __launch_bounds__(512, 1) W6_WG_ATTR k_conv_wino_wgrad64(W64WgAr
         const long dpix = ((long)n * H + y0) * W + x0;
         const long doff = dpix * Cout * 4;
         rsd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + doff), 0, (int)(unsigned)((long)a.nbd - doff), 0x00020000);
-        const long xoff = (dpix - W - 1) * Cin * 4;                       // may lie before the tensor (first region): masked
-        const long xleft = (long)a.nbx - xoff;
-        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
+        const long xpix = x_up ? ((long)n * x_h + (y0 >> 1) - 1) * x_w + (x0 >> 1) - 1 : dpix - W - 1;
+        const long xoff = xpix * x_cs * 4;                                // may lie before the tensor (first region): masked
+        const long xleft = x_nb - xoff;
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x_ptr + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
         x_edges = ((y0 == 0 ? 1u : 0u) | (y0 + G::TRP == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + RW == W ? 8u : 0u)) * 0x1111u;
     };
     auto issue_d = [&](int j) { rd[j] = ld4(rsd, d_fix, j * d_jstride); };
@@ -1137,6 +1152,13 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
     const unsigned d_fix = ((unsigned)((d_px >> 5) * W + (d_px & 31)) * Cout + co_base + (tid & 7) * 4) * 4u;
     const unsigned d_jstride = (unsigned)(2 * W) * Cout * 4u;
     const int d_lds = d_px * WH_DP + (tid & 7) * 4;                       // + j * 64 * WH_DP
+    // the source of this workgroup's ci block (uniform): its pointer, channels per pixel, first channel, row length
+    const bool x_s1 = ci_base >= a.C0;
+    const bool x_up = !x_s1 && a.up0;
+    const float* x_ptr = x_s1 ? a.x1 : a.x;
+    const int x_cs = x_s1 ? Cin - a.C0 : a.C0, x_cb = x_s1 ? ci_base - a.C0 : ci_base;
+    const int x_w = x_up ? W >> 1 : W, x_h = x_up ? H >> 1 : H;
+    const long x_nb = x_s1 ? (long)a.nbx1 : (long)a.nbx;
     unsigned x_fix[LX];
     int x_lds[LX];
     unsigned x_bits = 0;
@@ -1145,7 +1167,7 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
         int f = tid + j * NT;
         if (f >= XF) f -= XF;
         const int hp = f >> 3, hy = hp / XW, hx = hp - hy * XW;
-        x_fix[j] = ((unsigned)(hy * W + hx) * Cin + ci_base + (tid & 7) * 4) * 4u;
+        x_fix[j] = ((unsigned)((x_up ? (hy + 1) >> 1 : hy) * x_w + (x_up ? (hx + 1) >> 1 : hx)) * x_cs + x_cb + (tid & 7) * 4) * 4u;
         x_lds[j] = 2 * DBUF + hp * WH_XP + (tid & 7) * 4;
         x_bits |= (unsigned)((hy == 0 ? 1 : 0) | (hy == G::XR - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == XW - 1 ? 8 : 0)) << (4 * j);
     }
@@ -1166,9 +1188,10 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
         const long dpix = ((long)n * H + y0) * W + x0;
         const long doff = dpix * Cout * 4;
         rsd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + doff), 0, (int)(unsigned)((long)a.nbd - doff), 0x00020000);
-        const long xoff = (dpix - W - 1) * Cin * 4;
-        const long xleft = (long)a.nbx - xoff;
-        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.x + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
+        const long xpix = x_up ? ((long)n * x_h + (y0 >> 1) - 1) * x_w + (x0 >> 1) - 1 : dpix - W - 1;
+        const long xoff = xpix * x_cs * 4;
+        const long xleft = x_nb - xoff;
+        rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x_ptr + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
         x_edges = ((y0 == 0 ? 1u : 0u) | (y0 + G::TRP == H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + RW == W ? 8u : 0u)) * 0x1111u;
     };
     auto issue_d = [&](int j) { rd[j] = ld4(rsd, d_fix, j * d_jstride); };
@@ -1395,12 +1418,18 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
 
 }  // namespace
 
-// one full-resolution source, whole regions (4 x 32 or 8 x 16 pixels)
+// one full-resolution source or two sources [up2x?(a) | b] with 32-channel-aligned widths (VQW_WGRAD_TWO_SRC=0: those on
+// k_conv_wino_wgrad, A/B timing); whole regions (4 x 32 or 8 x 16 pixels)
+static const int g_wg2src_env = env_int64("VQW_WGRAD_TWO_SRC", 1);
+static bool wgrad_sources_ok(int C0, int C1, int up0, int H, int W) {
+    if (C1 == 0) return !up0 && C0 % 32 == 0;          // (a single up-sampled source has the nine-product kernel)
+    return g_wg2src_env && C0 % 32 == 0 && C1 % 32 == 0 && (!up0 || (H % 2 == 0 && W % 2 == 0));
+}
 // VQW_WGRAD64=0 (experiment): the (64 co x 32 ci)-block kernel off; its 32-pixel-wide layers then take the (32 x 32)-block kernel
 static const int g_wg64_env = env_int64("VQW_WGRAD64", 1);
 bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W) {
     if (!g_wg64_env && W % 32 == 0 && H % 4 == 0) return false;
-    if (!g_w64_env || C1 != 0 || up0 || C0 % 32 != 0 || Cout % 64 != 0 || W % 16 != 0) return false;
+    if (!g_w64_env || !wgrad_sources_ok(C0, C1, up0, H, W) || Cout % 64 != 0 || W % 16 != 0) return false;
     return H % (W % 32 == 0 ? 4 : 8) == 0;
 }
 int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
@@ -1415,7 +1444,12 @@ int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_sla
     if (kt_out) *kt_out = kt;
     return ceil_div(nsp, kt);
 }
-int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+static void wgrad_sources(W64WgArgs& a, const ConvIn& in, long P) {
+    a.x = in.src0; a.x1 = in.C1 ? in.src1 : in.src0; a.C0 = in.C0; a.up0 = in.C1 ? in.up0 : 0;
+    a.nbx = (unsigned)((a.up0 ? P / 4 : P) * in.C0 * 4);
+    a.nbx1 = (unsigned)(P * in.C1 * 4);
+}
+int conv_wino64_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
                       hipStream_t st) {
     const int rw = W % 32 == 0 ? 32 : 16;
     const size_t lds = (size_t)2 * (rw == 32 ? WgGeo<32>::DBUF + WgGeo<32>::XBUF : WgGeo<16>::DBUF + WgGeo<16>::XBUF) * sizeof(float);
@@ -1432,11 +1466,11 @@ int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, 
     }
     const long P = (long)N * H * W;
     W64WgArgs a;
-    a.x = x; a.dy = dy; a.part = ws; a.bias_part = bpart;
+    a.dy = dy; a.part = ws; a.bias_part = bpart;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.tilesY = H / (128 / rw); a.tilesX = W / rw; a.nsp = N * a.tilesY * a.tilesX;
     a.n_ci_b = Cin / 32; a.nblk = (Cout / 64) * a.n_ci_b; a.kt = kt;
-    a.nbx = (unsigned)(P * Cin * 4);
+    wgrad_sources(a, in, P);
     a.nbd = (unsigned)(P * Cout * 4);
     if (rw == 32) k_conv_wino_wgrad64<32><<<a.nblk * nsb, 512, lds, st>>>(a);
     else k_conv_wino_wgrad64<16><<<a.nblk * nsb, 512, lds, st>>>(a);
@@ -1448,7 +1482,7 @@ int conv_wino64_wgrad(const float* x, const float* dy, float* ws, float* bpart, 
 // 32-pixel-wide whole regions (4 x 32 pixels).  VQW_WINOGRAD32W=0: these layers on k_conv_wino_wgrad (A/B timing).
 static const int g_w32w_env = env_int64("VQW_WINOGRAD32W", 1);
 bool conv_wino32_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W) {
-    if (!g_w64_env || !g_w32w_env || C1 != 0 || up0 || C0 % 32 != 0 || Cout % 32 != 0 || (Cout % 64 == 0 && g_wg64_env) || W % 32 != 0) return false;
+    if (!g_w64_env || !g_w32w_env || !wgrad_sources_ok(C0, C1, up0, H, W) || Cout % 32 != 0 || (Cout % 64 == 0 && g_wg64_env) || W % 32 != 0) return false;
     return H % 4 == 0;
 }
 int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out) {
@@ -1462,7 +1496,7 @@ int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_sla
     if (kt_out) *kt_out = kt;
     return ceil_div(nsp, kt);
 }
-int conv_wino32_wgrad(const float* x, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
+int conv_wino32_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
                       hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (WhGeo::DBUF + WhGeo::XBUF) * sizeof(float);
     static_assert(lds <= 160 * 1024 && lds >= 64 * 1024, "the fold needs 64 KB");
@@ -1476,11 +1510,11 @@ int conv_wino32_wgrad(const float* x, const float* dy, float* ws, float* bpart, 
     }
     const long P = (long)N * H * W;
     W64WgArgs a;
-    a.x = x; a.dy = dy; a.part = ws; a.bias_part = bpart;
+    a.dy = dy; a.part = ws; a.bias_part = bpart;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.tilesY = H / 4; a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
     a.n_ci_b = Cin / 32; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
-    a.nbx = (unsigned)(P * Cin * 4);
+    wgrad_sources(a, in, P);
     a.nbd = (unsigned)(P * Cout * 4);
     k_conv_wino_wgrad32<<<a.nblk * nsb, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino32_wgrad");

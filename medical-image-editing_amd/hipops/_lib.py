@@ -48,6 +48,7 @@ SIGNATURES = {
     "vqw_conv3x3_wino_supported": (c_i, [c_i, c_i, c_i, c_i, c_i]),
     "vqw_conv3x3_wino_ws_bytes": (c_sz, [c_i, c_i]),
     "vqw_conv3x3_wino_prepare": (c_i, [c_p, c_p, c_sz, c_i, c_i, c_p]),
+    "vqw_conv3x3_wino_prepare_dgrad": (c_i, [c_p, c_p, c_sz, c_i, c_i, c_p]),
     "vqw_conv3x3_wino_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_wino_masked_supported": (c_i, [c_i] * 5),
     "vqw_conv3x3_wino_fwd_masked": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -448,6 +448,14 @@ def _wino_weights(L, w_ohwi, Cin, Cout):
     return buf
 
 
+def _wino_weights_dgrad(L, w_ohwi, Cin, Cout):
+    """U of a 3x3 layer's INPUT-GRADIENT convolution (Cin = the layer's couts, Cout = its input channels), straight from the
+    layer's weight: what _wino_weights gives on the packed input-gradient weights, without the pack launch."""
+    buf = _ws(L.vqw_conv3x3_wino_ws_bytes(Cin, Cout), w_ohwi)
+    _lib.check(L.vqw_conv3x3_wino_prepare_dgrad(_p(w_ohwi), _p(buf), buf.numel(), Cin, Cout, _st()), "vqw_conv3x3_wino_prepare_dgrad")
+    return buf
+
+
 def _conv_fwd_raw(x0, up0, x1, w, bias, N, H, W, Cout, ks, dil, relu=False):
     y = empty_nhwc(N, Cout, H, W, x0)
     _lib.check(_L().vqw_conv2d_fwd(_p(x0), x0.shape[1], int(up0), _p(x1), 0 if x1 is None else x1.shape[1],
@@ -916,7 +924,7 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             buf = torch.empty(Cin * ks * ks * Cout, dtype=torch.float32, device=gy.device)
             _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Cout, Cin, ks, _st()), "vqw_pack_dgrad_weights")
             return buf
-        wt = _cached(w, "dgrad", _pack)
+        wt_of = lambda: _cached(w, "dgrad", _pack)          # noqa: E731  (only the non-Winograd routes read the packed weights)
         if SPLIT_DGRAD and x1 is not None and need0 and need1 and group is None and ks == 3 and dilation == 1 \
                 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W) \
                 and L.vqw_conv3x3_wino_split_supported(Cout, Cin, C0, int(up0), N, H, W):
@@ -924,7 +932,7 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             # tile when x0 was up-sampled: a Winograd tile IS one low-resolution pixel) instead of two gather passes over the
             # concatenated gradient
             global split_dgrad_calls
-            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights_dgrad(L, w, Cout, Cin))
             g0 = torch.empty_like(x0, memory_format=CL)
             g1 = torch.empty_like(x1, memory_format=CL)
             _lib.check(L.vqw_conv3x3_wino_fwd_split(_p(gy), _p(ut), None, _p(g0), _p(g1), N, H, W, Cout, Cin, C0, int(up0), 0, _st()),
@@ -940,14 +948,14 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             if ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W) \
                     and L.vqw_conv3x3_wino_masked_supported(Cout, Cin, N, H, W):
                 # Winograd form, the shared buffer read and added in the kernel's epilogue
-                ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+                ut = _cached(w, "wino_dgrad", lambda: _wino_weights_dgrad(L, w, Cout, Cin))
                 _lib.check(L.vqw_conv3x3_wino_fwd_acc(_p(gy), _p(ut), _p(group.buf), N, H, W, Cout, Cin, _st()),
                            "vqw_conv3x3_wino_fwd_acc(dgrad)")
                 group_acc_calls += 1
                 g_full = None
             elif L.vqw_conv2d_fwd_acc_supported(Cout, N, H, W, Cin, ks, dilation):
                 # row-chain kernel (dilated 3x3) or the implicit-GEMM kernel (1x1): y += conv in the epilogue
-                _lib.check(L.vqw_conv2d_fwd_acc(_p(gy), Cout, _p(wt), _p(group.buf), N, H, W, Cin, ks, dilation, _st()),
+                _lib.check(L.vqw_conv2d_fwd_acc(_p(gy), Cout, _p(wt_of()), _p(group.buf), N, H, W, Cin, ks, dilation, _st()),
                            "vqw_conv2d_fwd_acc")
                 if ks == 1:
                     group_acc_calls += 1
@@ -963,18 +971,18 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             # x0 is the output of an InstanceNorm (+ReLU) and feeds this layer only: the norm's backward sums ride in this launch
             global in_bwd_fused_calls
             nparts = L.vqw_conv3x3_wino_fwd_inbwd_parts(Cout, Cin, N, H, W)
-            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights_dgrad(L, w, Cout, Cin))
             bpart = torch.empty(N * nparts * Cin * 2, dtype=torch.float32, device=gy.device)
             xraw, mr, nrelu = in_src
             _lib.check(L.vqw_conv3x3_wino_fwd_inbwd(_p(gy), _p(ut), _p(xraw), _p(mr), int(nrelu), _p(g_full), _p(bpart),
                                                     N, H, W, Cout, Cin, _st()), "vqw_conv3x3_wino_fwd_inbwd(dgrad)")
             _IN_BWD_PARTS.put(g_full, (bpart, nparts, xraw.data_ptr()))
         elif ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W):
-            ut = _cached(w, "wino_dgrad", lambda: _wino_weights(L, wt, Cout, Cin))
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights_dgrad(L, w, Cout, Cin))
             _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(g_full), N, H, W, Cout, Cin, 0, _st()),
                        "vqw_conv3x3_wino_fwd(dgrad)")
         else:
-            _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
+            _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt_of()), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
                        "vqw_conv2d_fwd(dgrad)")
         if group is not None and need0:
             g0 = group.member_done(g_full)
@@ -1177,10 +1185,9 @@ class _ConvCat(torch.autograd.Function):
                 buf = torch.empty(Cin * ks * ks * Ct, dtype=torch.float32, device=gy.device)
                 _lib.check(L.vqw_pack_dgrad_weights(_p(w), _p(buf), Ct, Cin, ks, _st()), "vqw_pack_dgrad_weights")
                 return buf
-            wt = _cached(wa, "cat_dgrad", _pack, deps=(wb,))
             gx = empty_nhwc(N, Cin, H, W, gy)
             if ks == 3 and L.vqw_conv3x3_wino_supported(Ct, Cin, N, H, W):
-                ut = _cached(wa, "cat_wino_dgrad", lambda: _wino_weights(L, wt, Ct, Cin), deps=(wb,))
+                ut = _cached(wa, "cat_wino_dgrad", lambda: _wino_weights_dgrad(L, w, Ct, Cin), deps=(wb,))
                 if ctx.relu_in and FUSE_RELU_MASK and L.vqw_conv3x3_wino_masked_supported(Ct, Cin, N, H, W):
                     # the gradient in FRONT of the producer's ReLU: its mask (x > 0) applied in this kernel's epilogue
                     _lib.check(L.vqw_conv3x3_wino_fwd_masked(_p(gy), _p(ut), _p(x), _p(gx), N, H, W, Ct, Cin, _st()),
@@ -1192,6 +1199,7 @@ class _ConvCat(torch.autograd.Function):
                     _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(gx), N, H, W, Ct, Cin, 0, _st()),
                                "vqw_conv3x3_wino_fwd(dgrad)")
             else:
+                wt = _cached(wa, "cat_dgrad", _pack, deps=(wb,))
                 _lib.check(L.vqw_conv2d_fwd(_p(gy), Ct, 0, None, 0, _p(wt), None, _p(gx), N, H, W, Cin, ks, 1, 0, _st()),
                            "vqw_conv2d_fwd(dgrad)")
         if ctx.defer:

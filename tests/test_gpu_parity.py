@@ -713,6 +713,27 @@ def test_upsampled_layer_pair_as_one_launch(monkeypatch):
         assert_close(g2[k], g0[k], 1e-4, "gradient %s, paired launch without gradient groups" % k)
 
 
+def test_input_gradient_winograd_weights_straight_from_the_layer_weight():
+    """vqw_conv3x3_wino_prepare_dgrad(w) == vqw_conv3x3_wino_prepare(vqw_pack_dgrad_weights(w)), bit for bit: the transformed
+    weights of a layer's input-gradient convolution no longer need the packed copy (one launch less per 3x3 layer and step)."""
+    import ctypes
+    from hipops import _lib
+    L = _lib.load()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())      # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for co, ci in [(32, 16), (64, 64), (24, 40), (128, 96)]:
+        w = (torch.randn(co, ci, 3, 3, device=DEV) * 0.3).contiguous(memory_format=torch.channels_last)
+        wt = torch.empty(ci * 9 * co, device=DEV)
+        _lib.check(L.vqw_pack_dgrad_weights(p(w), p(wt), co, ci, 3, st), "pack")
+        nb = L.vqw_conv3x3_wino_ws_bytes(co, ci)
+        ua = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        ub = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        _lib.check(L.vqw_conv3x3_wino_prepare(p(wt), p(ua), nb, co, ci, st), "prepare")
+        _lib.check(L.vqw_conv3x3_wino_prepare_dgrad(p(w), p(ub), nb, co, ci, st), "prepare_dgrad")
+        torch.cuda.synchronize()
+        assert torch.equal(ua, ub), (co, ci)
+
+
 def test_style_layer_pair_as_one_launch(monkeypatch):
     """The mlp_shared convolutions (+ReLU) of a StyledResUpBlock's two StyledDenorms read the same style tensor (blocks.py:72-75,
     100-134): inside ops.winograd_forward() they run as ONE launch of the 64-cout Winograd kernel on concatenated weights with a
