@@ -112,6 +112,9 @@ template <int RW, int MBW, int NW = 8> struct W64Geo {
                                            // 2 -> 4: 32->64 @256 dgrad 0.447 -> 0.425 ms, 64->128 @128 0.318 -> 0.306, nothing slower)
 #endif
 constexpr int W6_CP = 26;                  // MFMA position of the first LDS commit of the prefetched data
+#ifndef W6_CP1
+#define W6_CP1 26                          // ... of the 64-cout shape (MBW = 1), which has registers to hold the loads longer
+#endif
 constexpr int W6_PB = 33, W6_CB = 58;      // second phase of U slots (four-wave workgroups): first issue, first commit
 
 template <int RW, int MBW, int EPI, int NW = 8>
@@ -127,9 +130,11 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
     static_assert(HF > (LH - 1) * NT && HF >= NT, "every halo slot but the last is full");
     // All slots in the first half of an item where they fit; otherwise the second half of the U slots forms a second phase
     // (issued from position W6_PB on, committed from W6_CB on) that re-uses the registers of the first.
-    constexpr bool ONE_PHASE = 1 + (LH + LU) * W6_LS <= W6_CP && W6_CP + LH + LU <= 32;
+    constexpr int CP = MBW == 1 ? W6_CP1 : W6_CP;
+    constexpr int CPMAX = MBW == 1 ? 64 : 32;
+    constexpr bool ONE_PHASE = 1 + (LH + LU) * W6_LS <= CP && CP + LH + LU <= CPMAX;
     constexpr int LUA = ONE_PHASE ? LU : LU / 2;
-    static_assert(1 + (LH + LUA) * W6_LS <= W6_CP && W6_CP + LH + LUA <= 32, "prefetch slots fit the first half of an item");
+    static_assert(1 + (LH + LUA) * W6_LS <= CP && CP + LH + LUA <= CPMAX, "prefetch slots fit the first half of an item");
     static_assert(ONE_PHASE || (LU == 2 * LUA && W6_PB + LUA * W6_LS <= W6_CB && W6_CB + LUA <= 64), "second U phase fits the second half");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -358,11 +363,11 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
         auto slot = [&](int p) {       // p = 0..63: MFMA position (compile-time after unrolling)
 #if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_HLOADS)      // timing-only A/B builds (tools/wino_ab.sh): wrong results
             if (p >= 1 && p < 1 + LH * W6_LS && (p - 1) % W6_LS == 0) issue_h((p - 1) / W6_LS, ch2);
-            if (p >= W6_CP && p < W6_CP + LH) commit_h(p - W6_CP, Hw);
+            if (p >= CP && p < CP + LH) commit_h(p - CP, Hw);
 #endif
 #if !defined(W6_EXP_NO_LOADS) && !defined(W6_EXP_NO_ULOADS)
             if (p >= 1 + LH * W6_LS && p < 1 + (LH + LUA) * W6_LS && (p - 1) % W6_LS == 0) issue_u((p - 1) / W6_LS - LH, ch1);
-            if (p >= W6_CP + LH && p < W6_CP + LH + LUA) commit_u(p - W6_CP - LH, Uw);
+            if (p >= CP + LH && p < CP + LH + LUA) commit_u(p - CP - LH, Uw);
             if (!ONE_PHASE) {
                 if (p >= W6_PB && p < W6_PB + LUA * W6_LS && (p - W6_PB) % W6_LS == 0) issue_u(LUA + (p - W6_PB) / W6_LS, ch1);
                 if (p >= W6_CB && p < W6_CB + LUA) commit_u(LUA + p - W6_CB, Uw);
