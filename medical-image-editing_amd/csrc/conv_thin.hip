@@ -3,13 +3,15 @@
 #include "common.h"
 #include "conv_common.h"
 #include "mfma_util.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // stem forward: y[p][0..Cout) = b + sum_t x[p + shift(t)] * w[co][t]          (Cin == 1, Cout % 4 == 0, Cout <= 64)
-template <int CO>
+template <int CO, bool STAGED = false>
 __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                   float* __restrict__ y, int N, int H, int W, int ks, int dil, int relu) {
     __shared__ float sw[CO * 9 + CO];
+    __shared__ float4 stage[STAGED ? 4 * 64 * (CO / 4 + 1) : 1];
     const int taps = ks * ks, half = ks >> 1;
     for (int i = threadIdx.x; i < CO * taps; i += 256) sw[i] = w[i];
     for (int i = threadIdx.x; i < CO; i += 256) sw[CO * 9 + i] = bias ? bias[i] : 0.f;
@@ -23,6 +25,37 @@ __global__ void __launch_bounds__(256) k_stem_fwd(const float* __restrict__ x, c
         for (int t = 0; t < taps; ++t) {
             int hy = yh + (t / ks - half) * dil, wx = xw + (t % ks - half) * dil;
             v[t] = (hy >= 0 && hy < H && wx >= 0 && wx < W) ? x[p + (long)(hy - yh) * W + (wx - xw)] : 0.f;
+        }
+        if (STAGED) {
+            // A thread's CO floats are CO / 4 stores 4 CO bytes apart: every store instruction of the wave would touch 64 separate
+            // 16-byte pieces.  The wave's 64 x CO tile goes through its own LDS rows instead (row = one pixel, padded by one
+            // float4) and leaves as CO / 4 stores of 1 KB in a row.  (P % 64 == 0: a wave's pixels are all valid.)
+            constexpr int C4 = CO / 4, RS = C4 + 1;
+            float4* tile = stage + (threadIdx.x >> 6) * 64 * RS;
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) {
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int co = c4 * 4 + k;
+                    float a = sw[CO * 9 + co];
+                    for (int t = 0; t < taps; ++t) a = fmaf(v[t], sw[co * taps + t], a);
+                    r[k] = relu ? fmaxf(a, 0.f) : a;
+                }
+                float4 o;
+                o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+                tile[lane * RS + c4] = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float4* out = (float4*)(y + (p - lane) * CO);          // the wave's first pixel
+#pragma unroll
+            for (int k = 0; k < C4; ++k) {
+                const int f = k * 64 + lane;                       // float4 index inside the wave's tile
+                out[f] = tile[(f / C4) * RS + (f % C4)];
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
         float4* out = (float4*)(y + p * CO);
 #pragma unroll
@@ -205,7 +238,11 @@ int conv_stem_fwd(const ConvIn& in, const float* w, const float* bias, float* y,
         VQW_LAUNCH_CHECK("conv_stem_fwd(wide)");
         return VQW_OK;
     }
-    if (Cout == 16) k_stem_fwd<16><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
+    static const bool staged_env = []{ const char* e = getenv("VQW_STEM_STAGED"); return !e || atoi(e) != 0; }();
+    const bool staged = staged_env && ((long)N * H * W) % 64 == 0;      // whole waves of valid pixels
+    if (Cout == 16 && staged) k_stem_fwd<16, true><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
+    else if (Cout == 32 && staged) k_stem_fwd<32, true><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
+    else if (Cout == 16) k_stem_fwd<16><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
     else if (Cout == 32) k_stem_fwd<32><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
     else k_stem_fwd<64><<<g, 256, 0, st>>>(in.src0, w, bias, y, N, H, W, ks, dil, relu);
     VQW_LAUNCH_CHECK("conv_stem_fwd");

@@ -50,6 +50,12 @@ CONV_CASES = [
     (2, 16, 16, 128, 0, False, 160, 3, 1, True, False),    # >128 couts: two N tiles
     (2, 16, 16, 1, 0, False, 16, 3, 1, True, False),       # 1-channel stem  (generic kernel)
     (2, 16, 16, 32, 0, False, 1, 1, 1, True, False),       # 32->1 head      (generic kernel)
+    # stems whose 64 x Cout wave tiles leave through LDS as 1 KB stores (round 4): 1 -> 16 / 32, 3x3 and 1x1, ReLU; the 32 -> 1 head's
+    # input gradient is the 1 -> 32 1x1 form; a pixel count that is not a multiple of 64 keeps the per-thread stores
+    (2, 24, 16, 1, 0, False, 16, 1, 1, False, False),
+    (1, 32, 64, 1, 0, False, 32, 3, 1, True, True),
+    (2, 8, 64, 32, 0, False, 1, 1, 1, True, False),
+    (1, 10, 6, 1, 0, False, 32, 3, 1, True, False),
     (2, 10, 10, 3, 0, False, 5, 3, 1, True, False),        # odd channels    (generic kernel)
     (1, 2, 2, 32, 0, False, 64, 3, 1, True, False),        # tiny map (deepest level of a 32x32 input)
     (2, 4, 4, 64, 32, True, 32, 3, 1, True, False),
