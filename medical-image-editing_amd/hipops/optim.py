@@ -20,7 +20,9 @@ from . import ops as _ops
 # 95.04 / 94.88 ms multi-tensor.  VQW_ADAM_MULTI=0 restores the per-tensor launches; a group whose tensors do not share a
 # step count or a layout falls back to them by itself.
 MULTI_TENSOR = os.environ.get("VQW_ADAM_MULTI", "1") != "0"
-CHUNK = 1 << 16          # elements per workgroup of the multi-tensor launch
+# elements per workgroup of the multi-tensor launch (VQW_ADAM_CHUNK): ~950 workgroups for the R-cfg model; 8 192 ... 65 536 measure
+# the same step time - the optimiser's launches overlap the next step's first kernels
+CHUNK = int(os.environ.get("VQW_ADAM_CHUNK", 1 << 14))
 
 
 def _same_layout(a, b):
