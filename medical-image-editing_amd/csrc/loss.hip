@@ -23,12 +23,17 @@ extern "C" size_t vqw_cross_ws_bytes(int B, int K, long HW) {
 // labels variant.  part[b][split][k][2] = (sum of squared distances, count)
 __global__ void __launch_bounds__(CL_BLOCK) k_cross_partial(const float* __restrict__ embed, const int32_t* __restrict__ labels,
                                                             const float* __restrict__ cb, float* __restrict__ part, long HW,
-                                                            int D, int K, int splits) {
+                                                            int D, int K, int splits, int cb_lds) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_acc = smem;  // [waves][K][2]: one slab per wave, single writer, folded in wave order (deterministic)
     const int b = blockIdx.y, s = blockIdx.x, t = threadIdx.x;
     constexpr int NWV = CL_BLOCK / 64;
     for (int i = t; i < NWV * 2 * K; i += CL_BLOCK) s_acc[i] = 0.f;
+    // a small codebook (cb_lds: K * D floats behind the slabs) is read from LDS, the pixel's row with 16-byte loads: the same
+    // differences summed in the same order as the scalar walk below
+    float* s_cb = s_acc + NWV * 2 * K;
+    if (cb_lds)
+        for (int i = t; i < K * D; i += CL_BLOCK) s_cb[i] = cb[i];
     __syncthreads();
     float* slab = s_acc + (t >> 6) * 2 * K;
     long per = (HW + splits - 1) / splits;
@@ -37,7 +42,17 @@ __global__ void __launch_bounds__(CL_BLOCK) k_cross_partial(const float* __restr
         const long p = base + t;
         int l = p < p1 ? labels[(long)b * HW + p] : 0;
         float d2 = 0.f;
-        if (l >= 1 && l <= K) {
+        if (l >= 1 && l <= K && cb_lds) {
+            const float4* e4 = (const float4*)(embed + ((long)b * HW + p) * D);
+            const float* c = s_cb + (l - 1) * D;
+            for (int d = 0; d < D; d += 4) {
+                const float4 ev = e4[d >> 2];
+                float a = ev.x - c[d]; d2 = fmaf(a, a, d2);
+                a = ev.y - c[d + 1]; d2 = fmaf(a, a, d2);
+                a = ev.z - c[d + 2]; d2 = fmaf(a, a, d2);
+                a = ev.w - c[d + 3]; d2 = fmaf(a, a, d2);
+            }
+        } else if (l >= 1 && l <= K) {
             const float* e = embed + ((long)b * HW + p) * D;
             const float* c = cb + (long)(l - 1) * D;
             for (int d = 0; d < D; ++d) { float a = e[d] - c[d]; d2 = fmaf(a, a, d2); }
@@ -154,7 +169,8 @@ extern "C" int vqw_cross_loss_fwd(const float* embed, const int32_t* labels, con
     VQW_CHECK(K <= 8192, "vqw_cross_loss_fwd: K too large");
     hipStream_t st = (hipStream_t)stream;
     int splits = cl_splits(B, HW);
-    k_cross_partial<<<dim3(splits, B), CL_BLOCK, (CL_BLOCK / 64) * 2 * K * sizeof(float), st>>>(embed, labels, codebook_kd, (float*)ws, HW, D, K, splits);
+    const int cb_lds = (D % 4 == 0 && (long)K * D <= 4096 && (((uintptr_t)embed) & 15) == 0) ? 1 : 0;
+    k_cross_partial<<<dim3(splits, B), CL_BLOCK, ((CL_BLOCK / 64) * 2 * K + (cb_lds ? K * D : 0)) * sizeof(float), st>>>(embed, labels, codebook_kd, (float*)ws, HW, D, K, splits, cb_lds);
     k_cross_finalize<<<1, 256, 0, st>>>((const float*)ws, loss, coef, B * K, K, splits);
     VQW_LAUNCH_CHECK("vqw_cross_loss_fwd");
     return VQW_OK;
@@ -190,11 +206,43 @@ __global__ void k_cross_bwd(const float* __restrict__ embed, const int32_t* __re
         ge[i] = v;
     }
 }
+// float4 form for D = 4 * 2^lg (no integer divisions: the flat kernel spends most of its time in i / D, i % D, p / HW)
+__global__ void __launch_bounds__(256) k_cross_bwd4(const float4* __restrict__ embed, const int32_t* __restrict__ labels, const float* __restrict__ cb,
+                                                    const float* __restrict__ coef, const float* __restrict__ gl, float4* __restrict__ ge,
+                                                    unsigned per_image4, int lg, int D, int K) {
+    const float g2 = 2.f * gl[0];
+    const unsigned b = blockIdx.y;
+    const unsigned d4m = (1u << lg) - 1u;
+    for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < per_image4; j += gridDim.x * 256u) {
+        const size_t i4 = (size_t)b * per_image4 + j;
+        const size_t p = i4 >> lg;
+        const int l = labels[p];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l >= 1 && l <= K) {
+            const float s = g2 * coef[b * K + (l - 1)];
+            const float4 e = embed[i4];
+            const float* c = cb + (long)(l - 1) * D + 4 * (j & d4m);
+            v.x = s * (e.x - c[0]); v.y = s * (e.y - c[1]); v.z = s * (e.z - c[2]); v.w = s * (e.w - c[3]);
+        }
+        ge[i4] = v;
+    }
+}
 extern "C" int vqw_cross_loss_bwd(const float* embed, const int32_t* labels, const float* codebook_kd, const float* coef,
                                   const float* gloss, float* gembed, int B, long HW, int D, int K, void* stream) {
     VQW_CHECK(embed && labels && codebook_kd && coef && gloss && gembed && B > 0 && HW > 0 && D > 0 && K > 0,
               "vqw_cross_loss_bwd: bad arguments");
     long total = (long)B * HW * D;
+    const int D4 = D / 4;
+    if (D % 4 == 0 && (D4 & (D4 - 1)) == 0 && HW * D4 < (1L << 31) && B <= 65535 && ((((uintptr_t)embed | (uintptr_t)gembed)) & 15) == 0) {
+        int lg = 0;
+        while ((1 << lg) < D4) ++lg;
+        const unsigned per = (unsigned)(HW * D4);
+        unsigned gx = (per + 255u) / 256u;
+        if (gx > 2048u) gx = 2048u;
+        k_cross_bwd4<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>((const float4*)embed, labels, codebook_kd, coef, gloss, (float4*)gembed, per, lg, D, K);
+        VQW_LAUNCH_CHECK("vqw_cross_loss_bwd");
+        return VQW_OK;
+    }
     k_cross_bwd<<<stream_grid(total, 256), 256, 0, (hipStream_t)stream>>>(embed, labels, codebook_kd, coef, gloss, gembed, total, HW, D, K);
     VQW_LAUNCH_CHECK("vqw_cross_loss_bwd");
     return VQW_OK;
