@@ -268,7 +268,7 @@ def main():
             # names the digest of the kernel sources it was taken with, and a stale or missing file gives null
             traffic, traffic_source = None, "none: profiles/r04_hbm_traffic.json missing"
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")))
                 if tj.get("csrc_digest") == csrc_digest():
                     # per API launch of the family (a call may be several kernel launches): bytes per step / calls per step
                     traffic = tj["families"][dom]["hbm_bytes_per_step"] / primary[dom]["launches_per_step"]
@@ -360,6 +360,9 @@ def main():
             line["mfma_active_fraction"] = tl["mfma_active_fraction"]
             line["timeline_source"] = "profiles/r04_stream_timeline.json (rocprofv3 --kernel-trace of this command)" + \
                 (": taken with other kernel sources" if stale else "")
+            # (the tracer slows the host to about the GPU's pace and the two views' forward passes stop overlapping: the fraction is a
+            # lower bound for the untraced step, whose phase schedule is in profiles/r04_phase_events.txt)
+            line["timeline_note"] = "traced step %.1f ms; lower bound for the untraced step (profiles/r04_phase_events.txt)" % tl.get("step_ms", float("nan"))
         except Exception:
             line["launches_per_step"] = line["mfma_active_fraction"] = None
         if world == 1 and not args.no_cpu_baseline:

@@ -40,6 +40,9 @@ bash $R/tools/sq_counters.sh "128->128 k3 d1  @ 64" dgrad > $O/sq_dgrad.txt 2>&1
 bash $R/tools/sq_counters.sh "128->128 k3 d1  @ 64" wgrad > $O/sq_wgrad.txt 2>&1
 bash $R/tools/sq_counters.sh "256->128 k3 d1  @ 64 up" "" > $O/sq_up.txt 2>&1
 echo "sq done"
+# the UNTRACED schedule of the two views (HIP events around the phases of a step)
+timeout -k 10 300 python3 $R/tools/debug/phase_events.py 6 2> /dev/null | tail -13 > $O/phase_events.txt
+echo "phase events done"
 cd /tmp
 VQW_DP_FORCE=1 timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline > $O/bench_rccl_world1.json 2> $O/bench_rccl_world1.err
 echo "rccl done"
