@@ -188,6 +188,9 @@ int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int y_coff, flo
 /* statistics only: mean_rstd[N][C][2] by reduction over x, or from a convolution's partials */
 int vqw_inorm_stats(const float* x, float* mean_rstd, void* ws, size_t ws_bytes, int N, int HW, int C, float eps, void* stream);
 int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_rstd, int N, int HW, int C, float eps, void* stream);
+/* Two norms of one shape in one launch (ABI 8; a ResBlock's main and 1x1 branches, blocks.py:21-36). */
+int vqw_inorm_stats_parts2(const float* part_a, int nparts_a, float* mean_rstd_a, const float* part_b, int nparts_b,
+                           float* mean_rstd_b, int N, int HW, int C, float eps, void* stream);
 int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
                   float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
 /* ABI 7.  The same with the two sums taken from part[N][nparts][C][2] = (sum gm, sum gm * xhat) per region, left by the
@@ -211,6 +214,10 @@ int vqw_bn_stats_from_parts(const float* part, double* sums /*[C][2]*/, int rows
 int vqw_bn_finalize(const double* sums /*[C][2]*/, double count, float* mean_rstd /*[C][2]*/,
                     float* running_mean, float* running_var, float momentum, float eps,
                     int C, void* stream);
+/* vqw_bn_stats_from_parts + vqw_bn_finalize in one launch (ABI 8): for a BatchNorm without a collective between its sums and its
+ * statistics (one rank, or SyncBN off).  `sums` [C][2] doubles is written as vqw_bn_stats_from_parts writes it. */
+int vqw_bn_finalize_parts(const float* part, int rows, double tile_count, double* sums, double count, float* mean_rstd,
+                          float* running_mean, float* running_var, float momentum, float eps, int C, void* stream);
 int vqw_bn_eval_stats(const float* running_mean, const float* running_var, float* mean_rstd,
                       float eps, int C, void* stream);
 /* gamma / beta (and dgamma / dbeta) are addressed as ptr[pixel * gb_stride + c]: gb_stride = C for two dense

@@ -705,6 +705,43 @@ __global__ void __launch_bounds__(256) k_inorm_finalize_parts(const float* __res
     mr[2 * i] = (float)mean;
     mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
+// two norms of one shape (a ResBlock's tail: main branch and 1x1 branch) in ONE launch: blockIdx.y selects the job
+__global__ void __launch_bounds__(256) k_inorm_finalize_parts2(const float* __restrict__ part_a, float* __restrict__ mr_a, int nparts_a,
+                                                               const float* __restrict__ part_b, float* __restrict__ mr_b, int nparts_b,
+                                                               int NC, int C, double inv_hw, float eps) {
+    const float* part = blockIdx.y ? part_b : part_a;
+    float* mr = blockIdx.y ? mr_b : mr_a;
+    const int nparts = blockIdx.y ? nparts_b : nparts_a;
+    const double inv_tile = (double)nparts * inv_hw;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;
+    if (i >= NC) return;              // wave-uniform
+    const int n = i / C, c = i % C;
+    double a = 0.0, b = 0.0;
+    for (int t = s; t < nparts; t += 64) {
+        const float* o = part + (((long)n * nparts + t) * C + c) * 2;
+        const double st = (double)o[0];
+        a += st;
+        b += (double)o[1] + st * st * inv_tile;
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (s != 0) return;
+    double mean = a * inv_hw;
+    double var = b * inv_hw - mean * mean;
+    if (var < 0.0) var = 0.0;
+    mr[2 * i] = (float)mean;
+    mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+extern "C" int vqw_inorm_stats_parts2(const float* part_a, int nparts_a, float* mean_rstd_a, const float* part_b, int nparts_b,
+                                      float* mean_rstd_b, int N, int HW, int C, float eps, void* stream) {
+    VQW_CHECK(part_a && part_b && mean_rstd_a && mean_rstd_b && nparts_a > 0 && nparts_b > 0 && N > 0 && HW > 0 && C > 0,
+              "vqw_inorm_stats_parts2: bad arguments");
+    k_inorm_finalize_parts2<<<dim3(ceil_div((long)N * C, 4), 2), 256, 0, (hipStream_t)stream>>>(part_a, mean_rstd_a, nparts_a, part_b, mean_rstd_b,
+                                                                                                  nparts_b, N * C, C, 1.0 / (double)HW, eps);
+    VQW_LAUNCH_CHECK("vqw_inorm_stats_parts2");
+    return VQW_OK;
+}
+
 extern "C" int vqw_inorm_fwd_parts(const float* x, float* y, int y_cstride, int y_coff, float* mean_rstd, const float* part,
                                    int nparts, int N, int HW, int C, float eps, int relu, void* stream) {
     VQW_PROF_HBM(stream, 2, (double)N * HW * C);
@@ -792,6 +829,28 @@ struct FInBwd {
 __global__ void __launch_bounds__(256) k_plane_sum_finalize(const double* __restrict__ part, float* __restrict__ out, int NC, int C,
                                                             int splits, double scale) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;       // one wave per (n, c), see k_inorm_finalize
+    if (i >= NC) return;
+    int n = i / C, c = i % C;
+    double a = 0.0, b = 0.0;
+    if (s < splits) {
+        const double* o = part + (((long)n * splits + s) * C + c) * 2;
+        a = o[0];
+        b = o[1];
+    }
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
+    if (s != 0) return;
+    out[2 * i] = (float)(a * scale);
+    out[2 * i + 1] = (float)(b * scale);
+}
+
+// two jobs of one shape in one launch (the paired backward of a ResBlock's tail norms): blockIdx.y selects the job
+__global__ void __launch_bounds__(256) k_plane_sum_finalize2(const double* __restrict__ part_a, float* __restrict__ out_a,
+                                                             const double* __restrict__ part_b, float* __restrict__ out_b, int NC, int C,
+                                                             int splits, double scale) {
+    const double* part = blockIdx.y ? part_b : part_a;
+    float* out = blockIdx.y ? out_b : out_a;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), s = threadIdx.x & 63;
     if (i >= NC) return;
     int n = i / C, c = i % C;
     double a = 0.0, b = 0.0;
@@ -1014,8 +1073,7 @@ extern "C" int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float
     float* eb = (float*)((char*)ws + one + plane_part_bytes(N, C));
     k_inorm_bwd_pair_reduce4<<<dim3(splits, N), 256, 0, st>>>((const float4*)xa, mra, (const float4*)xb, mrb, (const float4*)gy, parta,
                                                                partb, HW, C, splits);
-    k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(parta, ea, N * C, C, splits, 1.0 / (double)HW);
-    k_plane_sum_finalize<<<ceil_div((long)N * C, 4), 256, 0, st>>>(partb, eb, N * C, C, splits, 1.0 / (double)HW);
+    k_plane_sum_finalize2<<<dim3(ceil_div((long)N * C, 4), 2), 256, 0, st>>>(parta, ea, partb, eb, N * C, C, splits, 1.0 / (double)HW);
     const long t4 = (long)N * HW * C / 4;
     if (walk_ok(C / 4)) {
         const int R = 256 / (C / 4);
@@ -1119,6 +1177,51 @@ __global__ void k_bn_finalize(const double* __restrict__ sums, double count, flo
         rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
         rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
     }
+}
+// k_channel_sum_finalize_f + k_bn_finalize in one launch (no collective between them: one GPU, or SyncBN off): same sums, same
+// arithmetic; `sums` is still written (the caller may want it)
+__global__ void __launch_bounds__(256) k_bn_finalize_parts(const float* __restrict__ part, double* __restrict__ sums, int C, int rows,
+                                                           double inv_tile, double count, float* __restrict__ mr, float* __restrict__ rm,
+                                                           float* __restrict__ rv, float momentum, float eps) {
+    __shared__ double sa[256], sb[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int r = t; r < rows; r += 256) {
+        const float* o = part + ((long)r * C + c) * 2;
+        const double st = (double)o[0];
+        a += st;
+        b += (double)o[1] + st * st * inv_tile;
+    }
+    sa[t] = a;
+    sb[t] = b;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) { sa[t] += sa[t + w]; sb[t] += sb[t + w]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        sums[2 * c] = sa[0];
+        sums[2 * c + 1] = sb[0];
+        double mean = sa[0] / count;
+        double var = sb[0] / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[2 * c] = (float)mean;
+        mr[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rm) {
+            double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            rm[c] = (1.f - momentum) * rm[c] + momentum * (float)mean;
+            rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+        }
+    }
+}
+extern "C" int vqw_bn_finalize_parts(const float* part, int rows, double tile_count, double* sums, double count, float* mean_rstd,
+                                     float* running_mean, float* running_var, float momentum, float eps, int C, void* stream) {
+    VQW_CHECK(part && sums && mean_rstd && rows > 0 && C > 0 && tile_count >= 1.0 && count > 0, "vqw_bn_finalize_parts: bad arguments");
+    VQW_CHECK((running_mean == nullptr) == (running_var == nullptr), "vqw_bn_finalize_parts: running stats must both be set or both NULL");
+    k_bn_finalize_parts<<<C, 256, 0, (hipStream_t)stream>>>(part, sums, C, rows, 1.0 / tile_count, count, mean_rstd, running_mean, running_var,
+                                                            momentum, eps);
+    VQW_LAUNCH_CHECK("vqw_bn_finalize_parts");
+    return VQW_OK;
 }
 extern "C" int vqw_bn_finalize(const double* sums, double count, float* mean_rstd, float* running_mean,
                                float* running_var, float momentum, float eps, int C, void* stream) {

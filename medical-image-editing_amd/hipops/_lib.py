@@ -69,11 +69,13 @@ SIGNATURES = {
     "vqw_inorm_fwd_parts": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "vqw_inorm_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_p]),
     "vqw_inorm_stats_parts": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "vqw_inorm_stats_parts2": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqw_inorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_inorm_bwd_pair": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_partial_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_stats_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_d, c_p]),
     "vqw_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_f, c_f, c_i, c_p]),
+    "vqw_bn_finalize_parts": (c_i, [c_p, c_i, c_d, c_p, c_d, c_p, c_p, c_p, c_f, c_f, c_i, c_p]),
     "vqw_bn_eval_stats": (c_i, [c_p, c_p, c_p, c_f, c_i, c_p]),
     "vqw_spade_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_p]),
     "vqw_spade_fwd_res": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_i, c_p]),

@@ -339,6 +339,9 @@ def join_streams():
     for br in _branch_streams.values():
         if br.device == cur.device:
             cur.wait_stream(br)
+    global _defer_counters
+    _defer_counters = False
+    flush_counters()
 
 
 # Derived weight layouts (dgrad-packed, tap-collapsed) are cached on the parameter until it changes: both views of a
@@ -867,8 +870,42 @@ _IN_BWD_PARTS = _GradNotes()
 FUSE_IN_BWD = os.environ.get("VQW_FUSE_IN_BWD", "1") != "0"
 
 
+# BatchNorm's num_batches_tracked counters (read by nobody on this path: momentum is a number, not None) are bumped by ONE
+# multi-tensor launch at the end of a trainer's step instead of one launch per normalisation call; outside a trainer step
+# (begin_step() ... join_streams()) every call bumps its counter at once.
+_defer_counters = False
+_pending_counters = []
+
+
+def _bump_counter(t):
+    if _defer_counters:
+        _pending_counters.append(t)
+    else:
+        t.add_(1)
+
+
+def flush_counters():
+    global _pending_counters
+    if _pending_counters:
+        pend, _pending_counters = _pending_counters, []
+        uniq, times = [], {}
+        for t in pend:
+            k = id(t)
+            if k not in times:
+                uniq.append(t)
+            times[k] = times.get(k, 0) + 1
+        by = {}
+        for t in uniq:
+            by.setdefault(times[id(t)], []).append(t)
+        for n, ts in by.items():
+            torch._foreach_add_(ts, n)
+
+
 def begin_step():
     """Call before the forwards of a training step: drops fusion notes and a lane join that a failed backward pass left."""
+    global _defer_counters
+    flush_counters()               # (whatever an aborted step left)
+    _defer_counters = True         # until join_streams()
     _MASKED_GRADS.clear()
     _IN_BWD_PARTS.clear()
     if _join_queued_for is not None:
@@ -1387,7 +1424,10 @@ class _Spade(torch.autograd.Function):
         count = float(N * H * W)
         if training:
             sums = torch.empty(2 * C, dtype=torch.float64, device=x.device)
-            if part is not None:    # per-tile sums left by the producing convolution's epilogue
+            fused_finalize = part is not None and not (sync and _dist_on())
+            if fused_finalize:      # no collective between the sums and the statistics: one launch for both (below)
+                pass
+            elif part is not None:    # per-tile sums left by the producing convolution's epilogue
                 rows = part.numel() // (2 * C)
                 _lib.check(L.vqw_bn_stats_from_parts(_p(part), _p(sums), rows, C, count / rows, _st()), "vqw_bn_stats_from_parts")
             else:
@@ -1399,10 +1439,15 @@ class _Spade(torch.autograd.Function):
                 _all_reduce(sums)
                 count *= dist.get_world_size()
             cur = _order_begin(running_mean)
-            _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
-                       "vqw_bn_finalize")
+            if fused_finalize:
+                rows = part.numel() // (2 * C)
+                _lib.check(L.vqw_bn_finalize_parts(_p(part), rows, count / rows, _p(sums), count, _p(mr), _p(running_mean), _p(running_var),
+                                                   momentum, eps, C, _st()), "vqw_bn_finalize_parts")
+            else:
+                _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
+                           "vqw_bn_finalize")
             if nbt is not None:
-                nbt.add_(1)
+                _bump_counter(nbt)
             _order_end(running_mean, cur)
         else:
             _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
@@ -1575,13 +1620,18 @@ class _ResTailNorm(torch.autograd.Function):
         L = _L()
         mr2 = torch.empty(N * C * 2, dtype=torch.float32, device=x2.device)
         mrid = torch.empty(N * C * 2, dtype=torch.float32, device=x2.device)
-        if part2 is not None:
+        if part2 is not None and partid is not None:      # both norms' statistics from their convolutions' partials: one launch
+            _lib.check(L.vqw_inorm_stats_parts2(_p(part2), part2.numel() // (N * C * 2), _p(mr2), _p(partid), partid.numel() // (N * C * 2),
+                                                _p(mrid), N, H * W, C, eps, _st()), "vqw_inorm_stats_parts2")
+        elif part2 is not None:
             _lib.check(L.vqw_inorm_stats_parts(_p(part2), part2.numel() // (N * C * 2), _p(mr2), N, H * W, C, eps, _st()),
                        "vqw_inorm_stats_parts")
         else:
             ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x2)
             _lib.check(L.vqw_inorm_stats(_p(x2), _p(mr2), _p(ws), ws.numel(), N, H * W, C, eps, _st()), "vqw_inorm_stats")
-        if partid is not None:
+        if part2 is not None and partid is not None:
+            pass
+        elif partid is not None:
             _lib.check(L.vqw_inorm_stats_parts(_p(partid), partid.numel() // (N * C * 2), _p(mrid), N, H * W, C, eps, _st()),
                        "vqw_inorm_stats_parts")
         else:
@@ -2127,7 +2177,7 @@ class _BnLrelu(torch.autograd.Function):
             _lib.check(L.vqw_bn_finalize(_p(sums), count, _p(mr), _p(running_mean), _p(running_var), momentum, eps, C, _st()),
                        "vqw_bn_finalize")
             if nbt is not None:
-                nbt.add_(1)
+                _bump_counter(nbt)
             _order_end(running_mean, cur)
         else:
             _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
