@@ -10,6 +10,43 @@ struct ConvIn {
     int C0, C1, up0;
 };
 
+// One element of the collapsed weights of a 3x3 layer over a nearest x2 up-sampled input (conv_mfma.hip: conv_up2_prepare):
+// i < 4 * Cout * 4 * Cin: wc[par][co][a*2+b][ci] (forward, per output parity); else wd[ci][r*4+s][co] (input gradient)
+#ifdef __HIPCC__
+static __device__ inline void collapse_up_element(const float* __restrict__ w, float* __restrict__ wc, float* __restrict__ wd, long i, int Cout, int Cin) {
+    const long nfwd = 4L * Cout * 4 * Cin;
+    if (i < nfwd) {          // wc[par][co][a*2+b][ci]
+            int ci = (int)(i % Cin);
+            long r = i / Cin;
+            int ab = (int)(r % 4);
+            r /= 4;
+            int co = (int)(r % Cout);
+            int par = (int)(r / Cout);
+            int py = par >> 1, px = par & 1, a = ab >> 1, b = ab & 1;
+            // rows of the 3x3 kernel that fall on low-res row offset a for parity py: (0,0)->{0} (0,1)->{1,2} (1,0)->{0,1} (1,1)->{2}
+            int ky0 = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+            int kx0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+            float acc = 0.f;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+            wc[i] = acc;
+        } else {                 // wd[ci][r*4+s][co], offsets r-1, s-1 in {-1,0,1,2}: {-1}->{2} {0}->{1,2} {1}->{0,1} {2}->{0}
+            long k = i - nfwd;
+            int co = (int)(k % Cout);
+            long r = k / Cout;
+            int rs = (int)(r % 16);
+            int ci = (int)(r / 16);
+            int rr = rs >> 2, ss = rs & 3;
+            int ky0 = rr == 0 ? 2 : (rr == 1 ? 1 : 0), ky1 = rr == 0 ? 2 : (rr == 1 ? 2 : (rr == 2 ? 1 : 0));
+            int kx0 = ss == 0 ? 2 : (ss == 1 ? 1 : 0), kx1 = ss == 0 ? 2 : (ss == 1 ? 2 : (ss == 2 ? 1 : 0));
+            float acc = 0.f;
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
+            wd[k] = acc;
+        }
+}
+#endif
+
 // generic VALU kernels (conv_generic.hip)
 int conv_direct_fwd(const ConvIn& in, const float* w, const float* bias, float* y, int N, int H, int W, int Cout, int ks,
                     int dil, int relu, hipStream_t st);
@@ -85,7 +122,7 @@ int conv_wino_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, 
 // 3x3 over an up-sampled input in Winograd form, nine of the sixteen products (conv_wino_up.hip)
 bool conv_wino_up_dgrad_ok(int Cin, int Cout, int N, int h, int w);
 size_t conv_wino_up_ws_floats(int Cin, int Cout);
-int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st);
+int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st, float* wc = nullptr, float* wd = nullptr);
 int conv_wino_up_dgrad(const float* dy, const float* ws, float* g_low, int N, int h, int w, int Cin, int Cout, hipStream_t st,
                        int accumulate = 0);
 bool conv_up2_dgrad_is_wino(int Cin, int Cout, int N, int h, int w);

@@ -405,37 +405,7 @@ int conv_up2_stat_tiles(int Cin, int Cout, int N, int h, int w) {
 __global__ void k_collapse_up_weights(const float* __restrict__ w, float* __restrict__ wc, float* __restrict__ wd, int Cout, int Cin) {
     long nfwd = 4L * Cout * 4 * Cin, nbwd = (long)Cin * 16 * Cout;
     long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nfwd + nbwd; i += stride) {
-        if (i < nfwd) {          // wc[par][co][a*2+b][ci]
-            int ci = (int)(i % Cin);
-            long r = i / Cin;
-            int ab = (int)(r % 4);
-            r /= 4;
-            int co = (int)(r % Cout);
-            int par = (int)(r / Cout);
-            int py = par >> 1, px = par & 1, a = ab >> 1, b = ab & 1;
-            // rows of the 3x3 kernel that fall on low-res row offset a for parity py: (0,0)->{0} (0,1)->{1,2} (1,0)->{0,1} (1,1)->{2}
-            int ky0 = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
-            int kx0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
-            float acc = 0.f;
-            for (int ky = ky0; ky <= ky1; ++ky)
-                for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
-            wc[i] = acc;
-        } else {                 // wd[ci][r*4+s][co], offsets r-1, s-1 in {-1,0,1,2}: {-1}->{2} {0}->{1,2} {1}->{0,1} {2}->{0}
-            long k = i - nfwd;
-            int co = (int)(k % Cout);
-            long r = k / Cout;
-            int rs = (int)(r % 16);
-            int ci = (int)(r / 16);
-            int rr = rs >> 2, ss = rs & 3;
-            int ky0 = rr == 0 ? 2 : (rr == 1 ? 1 : 0), ky1 = rr == 0 ? 2 : (rr == 1 ? 2 : (rr == 2 ? 1 : 0));
-            int kx0 = ss == 0 ? 2 : (ss == 1 ? 1 : 0), kx1 = ss == 0 ? 2 : (ss == 1 ? 2 : (ss == 2 ? 1 : 0));
-            float acc = 0.f;
-            for (int ky = ky0; ky <= ky1; ++ky)
-                for (int kx = kx0; kx <= kx1; ++kx) acc += w[(((long)co * 3 + ky) * 3 + kx) * Cin + ci];
-            wd[k] = acc;
-        }
-    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nfwd + nbwd; i += stride) collapse_up_element(w, wc, wd, i, Cout, Cin);
 }
 
 bool conv_up2_ok(int Cin, int Cout, long Plow) {
@@ -447,9 +417,10 @@ size_t conv_up2_ws_floats(int Cin, int Cout) { return (size_t)32 * Cout * Cin + 
 // ws: [4][Cout][4][Cin] forward weights, [Cin][16][Cout] dgrad weights, then the nine-product Winograd weights (conv_wino_up.hip)
 int conv_up2_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st) {
     long n = 32L * Cout * Cin;
+    // (with the nine-product Winograd weights behind them: ONE launch builds the collapsed and the transformed weights)
+    if (up2_has_wino(Cin, Cout)) return conv_wino_up_prepare(w, ws + 32L * Cout * Cin, Cin, Cout, st, ws, ws + 16L * Cout * Cin);
     k_collapse_up_weights<<<stream_grid(n, 256), 256, 0, st>>>(w, ws, ws + 16L * Cout * Cin, Cout, Cin);
     VQW_LAUNCH_CHECK("collapse_up_weights");
-    if (up2_has_wino(Cin, Cout)) return conv_wino_up_prepare(w, ws + 32L * Cout * Cin, Cin, Cout, st);
     return VQW_OK;
 }
 int conv_up2_fwd(const float* x_low, const float* ws, const float* bias, float* y, int N, int h, int w, int Cin, int Cout, int relu,

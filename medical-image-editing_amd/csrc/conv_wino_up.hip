@@ -38,7 +38,12 @@ __device__ __host__ constexpr int up_row(int s) { return s == 2 ? 3 : s; }      
 // Transformed weights of the three passes, all in the chunked layout [K / 8][9][N][8] the kernels stream:
 //   uf (forward):        K = Cin,  N = Cout: (G w G^T)[i][j] x 2^(i == 1) x 2^(j == 1)    (the factor 2 of V's row / column 1)
 //   ud (input gradient): K = Cout, N = Cin:  c_i c_j (G wt G^T)[i][j], wt = w flipped and transposed, c = (1, 2, -1)
-__global__ void k_wino_up_weights(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin) {
+__global__ void k_wino_up_weights(const float* __restrict__ w, float* __restrict__ uf, float* __restrict__ ud, int Cout, int Cin,
+                                  float* __restrict__ wc, float* __restrict__ wd) {
+    if (wc) {      // the collapsed 2x2-tap weights of the same layer ride in this launch (conv_up2_prepare)
+        const long nc = 32L * Cout * Cin;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += (long)gridDim.x * blockDim.x) collapse_up_element(w, wc, wd, i, Cout, Cin);
+    }
     const long n = (long)Cout * Cin;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
         const int co = (int)(e / Cin), ci = (int)(e % Cin);
@@ -991,9 +996,9 @@ bool conv_wino_up_dgrad_ok(int Cin, int Cout, int N, int h, int w) {
 }
 size_t conv_wino_up_ws_floats(int Cin, int Cout) { return (size_t)18 * Cout * Cin; }
 // ws: uf [Cin / 8][9][Cout][8] then ud [Cout / 8][9][Cin][8] (needs Cin % 8 == 0 and Cout % 8 == 0)
-int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st) {
+int conv_wino_up_prepare(const float* w, float* ws, int Cin, int Cout, hipStream_t st, float* wc, float* wd) {
     const long n = (long)Cout * Cin;
-    k_wino_up_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, ws, ws + 9L * Cout * Cin, Cout, Cin);
+    k_wino_up_weights<<<(int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), 256, 0, st>>>(w, ws, ws + 9L * Cout * Cin, Cout, Cin, wc, wd);
     VQW_LAUNCH_CHECK("wino_up_weights");
     return VQW_OK;
 }

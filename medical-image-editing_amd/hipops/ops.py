@@ -424,7 +424,8 @@ def _deferred_wgrad(weight, bias, x0, x1, gy, up0, ks, dilation, N, H, W, Cout, 
         side.wait_event(ev)
         acc = weight.grad is not None
         if not acc:
-            weight.grad = torch.empty((Cout, C0 + C1, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+            # (the parameter's own strides: channels_last for a 3 x 3 weight, the default ones for a 1 x 1 weight - the same memory order)
+            weight.grad = torch.empty_strided((Cout, C0 + C1, ks, ks), weight.stride(), dtype=torch.float32, device=gy.device)
             if bias is not None:
                 bias.grad = torch.empty(Cout, dtype=torch.float32, device=gy.device)
         gw, gb = weight.grad, (bias.grad if bias is not None else None)
@@ -520,6 +521,11 @@ class _Conv2d(torch.autograd.Function):
         x1 = nhwc(x1) if x1 is not None else None
         w = nhwc(weight)
         Cout, Cin, ks, _ = weight.shape
+        if w is not weight and ks == 1 and weight.is_contiguous() and w.data_ptr() == weight.data_ptr():
+            # a 1 x 1 weight is dense in both memory formats and keeps the default strides: nhwc() re-strides the same memory.  The
+            # parameter itself serves (the kernels take pointers): its derived layouts stay cached on it from step to step and its
+            # gradient takes the side-lane route like every other layer's
+            w = weight
         N = x0.shape[0]
         H, W = (x0.shape[2] * 2, x0.shape[3] * 2) if up0 else (x0.shape[2], x0.shape[3])
         c1 = 0 if x1 is None else x1.shape[1]
