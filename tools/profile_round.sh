@@ -19,9 +19,14 @@ timeout -k 10 500 python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > 
 echo "bench20 done"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/conc.err
 echo "conc done"
-# per-stream timeline of the last CONCURRENT step of that trace (the run ends with the serialised roofline pass: one warm step + --serial-steps 5 -> steps_back 7)
-F=$(ls $O/conc/*/t_kernel_trace.csv 2>/dev/null | head -1); [ -z "$F" ] && F=$O/conc/t_kernel_trace.csv
-python3 $R/tools/stream_timeline.py $F 5 7 --json $O/stream_timeline.json > $O/stream_timeline.txt || echo "timeline failed"
+# per-stream timeline of one CONCURRENT step: from a trace of its own WITHOUT the in-library event timing (two event records per conv
+# launch on top of the tracer slow the host further, and the traced schedule drifts away from the untraced one: 102.6 ms / 0.78
+# matrix-core-active with the timing on, 92.4 ms / 0.86 without, 90.6 ms untraced)
+timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d $O/tl -o t -- python3 $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-kernel-timing > $O/bench_traced_for_timeline.json 2> $O/tl.err
+F=$(ls $O/tl/*/t_kernel_trace.csv 2>/dev/null | head -1); [ -z "$F" ] && F=$O/tl/t_kernel_trace.csv
+python3 $R/tools/stream_timeline.py $F 5 1 --json $O/stream_timeline.json > $O/stream_timeline.txt || echo "timeline failed"
+cp $O/stream_timeline.json $R/profiles/r04_stream_timeline.json      # the bench lines below (RCCL run) and a later bench.py read it
+echo "timeline done"
 export VQW_WGRAD_STREAM=0 VQW_CONCURRENT_VIEWS=0
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ser -o t -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof_serialised.json 2> $O/ser.err
 unset VQW_WGRAD_STREAM VQW_CONCURRENT_VIEWS
