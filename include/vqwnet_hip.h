@@ -149,6 +149,15 @@ int vqw_conv3x3_wino_fwd_masked(const float* x, const void* ws, const float* mas
  * blocks.py:100-134) - adds its input gradient to the shared buffer in its epilogue instead of leaving the sum to a separate
  * add pass.  Served where ..._masked_supported says so. */
 int vqw_conv3x3_wino_fwd_acc(const float* x, const void* ws, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
+/* A 3x3 layer of dilation 2 (the pyramid's first branch, aspp.py:27-30) in Winograd form (ABI 8): the plain kernel on the four
+ * phase images of x and y; ws = vqw_conv3x3_wino_prepare of the layer (forward) or vqw_conv3x3_wino_prepare_dgrad (input
+ * gradient: x = dY, Cin / Cout swapped).  part (optional, forward with relu == 0): the following norm's statistics partials
+ * [N][parts][Cout][2], parts = ..._dil2_stats_parts; accumulate: y += result (no bias, no ReLU).  The weight gradient of such a
+ * layer takes the same route inside vqw_conv2d_wgrad.  Served where ..._dil2_supported says so (H even, W a multiple of 64). */
+int vqw_conv3x3_wino_dil2_supported(int Cin, int Cout, int N, int H, int W);
+int vqw_conv3x3_wino_dil2_stats_parts(int Cin, int Cout, int N, int H, int W);
+int vqw_conv3x3_wino_dil2_fwd(const float* x, const void* ws, const float* bias, float* y, float* part, int accumulate,
+                              int N, int H, int W, int Cin, int Cout, int relu, void* stream);
 /* One launch, two output tensors (ABI 8): couts [0, split) -> y0 [N,H,W,split] - or, with pool0, summed over each 2 x 2 output
  * tile into y0 [N,H/2,W/2,split] - and couts [split, Cout) -> y1 [N,H,W,Cout-split].  Two uses: (i) the input gradient of a 3x3
  * layer over [nearest-up2x(a) | b] (UpBlock, blocks.py:9-18 with unet_encoder.py's torch.cat): x = dY, ws = the transformed

@@ -414,6 +414,30 @@ extern "C" int vqw_conv3x3_wino_fwd_acc(const float* x, const void* ws, float* y
     ProfScope ps(4, 2.0 * px * 4.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + 2.0 * px * Cout + 16.0 * Cout * Cin));
     return conv_wino_fwd(x, (const float*)ws, nullptr, y, N, H, W, Cin, Cout, 0, (hipStream_t)stream, nullptr, nullptr, 1);
 }
+// A 3x3 layer of DILATION 2 in Winograd form: the plain kernel on the four phase images of the tensors (rows / columns of one
+// parity: pixel pitch 2, row pitch 2 W), same transformed weights as the plain layer.  part: optional statistics partials
+// [N][parts][Cout][2] (forward, needs relu == 0); accumulate: y += result (a member of a gradient group).
+static const int g_wino_dil2_fwd = []{ const char* e = getenv("VQW_WINOGRAD_DIL2"); return e ? atoi(e) : 1; }();
+extern "C" int vqw_conv3x3_wino_dil2_supported(int Cin, int Cout, int N, int H, int W) {
+    if (!g_wino_dil2_fwd || g_conv_backend != 0 || N < 1 || H < 2 || W < 2) return 0;
+    if (!conv_wino_ok(Cin, Cout, N, H / 2, W / 2) || !conv_wino64_dil2_ok(Cin, Cout, H, W)) return 0;
+    return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L ? 1 : 0;
+}
+extern "C" int vqw_conv3x3_wino_dil2_stats_parts(int Cin, int Cout, int N, int H, int W) {
+    if (!vqw_conv3x3_wino_dil2_supported(Cin, Cout, N, H, W)) return 0;
+    return 4 * conv_wino64_stat_tiles(Cin, Cout, H / 2, W / 2);
+}
+extern "C" int vqw_conv3x3_wino_dil2_fwd(const float* x, const void* ws, const float* bias, float* y, float* part, int accumulate,
+                                         int N, int H, int W, int Cin, int Cout, int relu, void* stream) {
+    VQW_CHECK(x && ws && y && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_dil2_fwd: bad arguments");
+    VQW_CHECK(vqw_conv3x3_wino_dil2_supported(Cin, Cout, N, H, W), "vqw_conv3x3_wino_dil2_fwd: unsupported shape (query vqw_conv3x3_wino_dil2_supported)");
+    VQW_CHECK(!part || (!relu && !accumulate && vqw_conv3x3_wino_dil2_stats_parts(Cin, Cout, N, H, W) > 0),
+              "vqw_conv3x3_wino_dil2_fwd: statistics partials need relu == 0, accumulate == 0 and a served height");
+    VQW_CHECK(!accumulate || (!bias && !relu), "vqw_conv3x3_wino_dil2_fwd: the accumulating form takes no bias / ReLU");
+    const double px = (double)N * H * W;
+    ProfScope ps(4, 2.0 * px * 4.0 * Cout * Cin, (hipStream_t)stream, 4.0 * (px * Cin + (accumulate ? 2.0 : 1.0) * px * Cout + 16.0 * Cout * Cin));
+    return conv_wino64_fwd(x, (const float*)ws, bias, y, N, H, W, Cin, Cout, relu, (hipStream_t)stream, part, nullptr, accumulate, nullptr, 0, 2);
+}
 extern "C" int vqw_conv3x3_wino_split_supported(int Cin, int Cout, int split, int pool0, int N, int H, int W) {
     return (g_conv_backend == 0 && conv_wino_ok(Cin, Cout, N, H, W) && conv_wino64_split_ok(Cin, Cout, split, pool0, N, H, W)) ? 1 : 0;
 }

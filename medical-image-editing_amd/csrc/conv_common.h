@@ -101,7 +101,8 @@ int conv_wino64_fwd_split(const float* x, const float* u, const float* bias, flo
                           int split, int pool0, int relu, hipStream_t st);
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
                     hipStream_t st, float* stats = nullptr, const float* mask = nullptr, int accumulate = 0,
-                    const float* in_mr = nullptr, int in_relu = 0);
+                    const float* in_mr = nullptr, int in_relu = 0, int dil = 1);
+bool conv_wino64_dil2_ok(int Cin, int Cout, int H, int W);
 // in_mr (with mask = the raw input of the InstanceNorm in front of the layer, stats = [N][tiles][Cout][2]): the launch is the
 // layer's input gradient and leaves that norm's backward sums per region.  accumulate (low-VALU kernel only): y += result.  mask (optional, shaped like y, low-VALU kernel only: conv_wino64_ok): outputs are zeroed where mask <= 0
 int conv_wino_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
@@ -113,7 +114,8 @@ bool conv_wino64_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);
 bool conv_wino32_wgrad_ok(int C0, int C1, int up0, int Cout, int H, int W);       // (32 co x 32 ci) blocks: Cout % 64 == 32
 int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
 int conv_wino32_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
-                      hipStream_t st);
+                      hipStream_t st, int dil = 1);
+bool conv_wino32_wgrad_dil2_ok(int C0, int Cout, int H, int W);
 int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_slabs, int* kt_out);
 int conv_wino64_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
                       hipStream_t st);

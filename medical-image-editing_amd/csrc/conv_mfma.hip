@@ -1156,7 +1156,15 @@ static int launch_wgrad(const ConvIn& in, const float* dy, float* dw, float* ws,
 
 // dbias != nullptr asks the kernel to produce the bias gradient too; returns 1 (not an error) in *bias_done when it did.
 // true when conv_mfma_wgrad takes the Winograd form for the layer (the profile scope prices it at the FLOPs it executes)
+// dilation 2 in Winograd form: the (32 x 32)-block kernel on the four phase images (VQW_WINOGRAD_DIL2=0: the row-chain kernels)
+static const int g_wino_dil2 = []{ const char* e = getenv("VQW_WINOGRAD_DIL2"); return e ? atoi(e) : 1; }();
+extern int g_wino_mode;
+static bool wgrad_is_wino_dil2(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil) {
+    return g_wino_dil2 && g_wino_mode == 0 && g_wgrad_variant != 1 && g_wino_wgrad && ks == 3 && dil == 2 && in.C1 == 0 && !in.up0 &&
+           fits_u32((long)N * H * W, in.C0, Cout) && conv_wino32_wgrad_dil2_ok(in.C0, Cout, H, W);
+}
 bool conv_mfma_wgrad_is_wino(const ConvIn& in, int N, int H, int W, int Cout, int ks, int dil) {
+    if (wgrad_is_wino_dil2(in, N, H, W, Cout, ks, dil)) return true;
     if (in.C1 > 0 && (in.C0 % 16 != 0 || in.C1 % 16 != 0)) return false;      // a 16-channel ci block must not straddle the sources
     if (in.up0 && ((H | W) & 1)) return false;
     return g_wgrad_variant != 1 && g_wino_wgrad && ks == 3 && dil == 1 && (long)N * H * W >= 32 &&
@@ -1171,9 +1179,12 @@ int conv_mfma_wgrad(const ConvIn& in, const float* dy, float* dw, float* dbias, 
         const long nout = (long)Cout * 9 * Cin;
         *bias_done = dbias != nullptr;
         int kt = 1;
-        const int nsbw = conv_wino_wgrad_blocks(in, Cout, N, H, W, wg9_split_blocks(Cin, Cout, (long)N * H * W), &kt);
+        const bool d2 = wgrad_is_wino_dil2(in, N, H, W, Cout, ks, dil);
+        const int nsbw = d2 ? conv_wino32_wgrad_blocks(Cin, Cout, 4 * N, H / 2, W / 2, wg9_split_blocks(Cin, Cout, (long)N * H * W), &kt)
+                            : conv_wino_wgrad_blocks(in, Cout, N, H, W, wg9_split_blocks(Cin, Cout, (long)N * H * W), &kt);
         float* bp = dbias ? ws + (size_t)nsbw * nout : nullptr;
-        int rc = conv_wino_wgrad(in, dy, ws, bp, N, H, W, Cout, nsbw, kt, st);
+        int rc = d2 ? conv_wino32_wgrad(in, dy, ws, bp, N, H, W, Cin, Cout, nsbw, kt, st, 2)
+                    : conv_wino_wgrad(in, dy, ws, bp, N, H, W, Cout, nsbw, kt, st);
         if (rc) return rc;
         if (dbias) {
             rc = reduce_rows(bp, dbias, Cout, nsbw, st, acc);

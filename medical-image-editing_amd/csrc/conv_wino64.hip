@@ -71,6 +71,12 @@ struct W64Args {
     float* y2;
     int split, pool0;
     unsigned nby2;
+    // Pixel (n, y, x) of input AND output sits at pixel index (n >> n_sh) * img_px + ((n >> 1) & n_m) * rowb_px + (n & n_m) + y * rpx
+    // + x * ppx.  Dense tensors: n_sh = n_m = 0, img_px = H W, rpx = W, ppx = 1.  A 3x3 layer of dilation 2 is four plain layers
+    // on the phase images (rows / columns of one parity) of its tensors: N = 4 x images, H and W halved, n_sh = 2, n_m = 1,
+    // img_px = the full image, rowb_px = the full width, rpx = 2 x full width, ppx = 2 (conv_wino64_fwd_dil2).
+    unsigned img_px, rowb_px, rpx, ppx;
+    int n_sh, n_m;
 };
 
 constexpr int W6_KPH = 10;                 // floats per halo pixel in LDS (8 channels + 2: conflict-free ds_read_b64 patches)
@@ -180,15 +186,19 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
         h_lds[j] = (hy * HWS + hx) * W6_KPH + c4 * 4;
     }
     unsigned h_voff[LH];                   // byte offsets of the slots in the region whose halo is fetched next
+    auto basepix = [&](int n) {                // (scalar: n is uniform)
+        return (unsigned)(n >> a.n_sh) * a.img_px + (unsigned)((n >> 1) & a.n_m) * a.rowb_px + (unsigned)(n & a.n_m);
+    };
     auto region_offsets = [&](int n, int tx, int ty) {
         const int y0 = ty * G::TR - 1, x0 = tx * RW - 1;
+        const unsigned nb = basepix(n);
 #pragma unroll
         for (int j = 0; j < LH; ++j) {
             int hy, hx;
             halo_pixel(j, hy, hx);
             const int yy = y0 + hy, xx = x0 + hx;
             const bool ok = ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
-            const unsigned pix = ((unsigned)n * H + (unsigned)yy) * W + (unsigned)xx;
+            const unsigned pix = nb + (unsigned)yy * a.rpx + (unsigned)xx * a.ppx;
             h_voff[j] = sel_u32(ok, pix * (unsigned)Cin * 4u + (unsigned)c4 * 16u, 0xFFFFFFFFu);
         }
     };
@@ -483,7 +493,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa) {
                     const int yy = yrow0 + aa;
-                    const unsigned base = (((unsigned)cn * H + (unsigned)yy) * W + (unsigned)xcol0) * cs + cc;
+                    const unsigned base = (basepix(cn) + (unsigned)yy * a.rpx + (unsigned)xcol0 * a.ppx) * cs + cc;
                     voffs[aa] = (int)sel_u32(yy < H, base * 4u, 0xFFFFFFFFu);
                 }
                 float mk[16];
@@ -494,7 +504,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
                         for (int r = 0; r < 4; ++r)
 #pragma unroll
                             for (int b = 0; b < 2; ++b)
-                                mk[r * 4 + aa * 2 + b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsm, voffs[aa], (2 * r + b) * Cout * 4, 0));
+                                mk[r * 4 + aa * 2 + b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsm, voffs[aa], (2 * r + b) * (int)a.ppx * Cout * 4, 0));
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -519,7 +529,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
                     for (int k = 0; k < 16; ++k) yv[k] = mk[k] + yv[k];
                 } else if (EPI == 3) {
                     // the norm's backward sums over this lane's 16 pixels of (image cn, channel co)
-                    const unsigned mo = ((unsigned)cn * (unsigned)Cout + co) * 8u;
+                    const unsigned mo = ((unsigned)(cn >> a.n_sh) * (unsigned)Cout + co) * 8u;
                     const float mean = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsr, (int)mo, 0, 0));
                     const float rstd = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsr, (int)mo, 4, 0));
                     float s1 = 0.f, s2 = 0.f;
@@ -552,7 +562,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
 #pragma unroll
                             for (int b = 0; b < 2; ++b)
                                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yv[r * 4 + aa * 2 + b]), (EPI == 4 && !part0) ? rsy2 : rsy, voff,
-                                                                      (2 * r + b) * (int)cs * 4, 0);
+                                                                      (2 * r + b) * (int)(a.ppx * cs) * 4, 0);
                     }
                 }
                 if (EPI != 3 && a.stats) {     // uniform: H % TR == 0 whenever statistics are requested
@@ -681,16 +691,25 @@ static int launch_wino64(W64Args& a, hipStream_t st) {
     return VQW_OK;
 }
 
+// A dilation-2 layer = the plain layer on the four phase images of its tensors (see W64Args): even H, W; W / 2 a multiple of 32
+bool conv_wino64_dil2_ok(int Cin, int Cout, int H, int W) {
+    return H % 2 == 0 && W % 64 == 0 && wino64_shape(Cin, Cout, W / 2) != 0;
+}
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
-                    hipStream_t st, float* stats, const float* mask, int accumulate, const float* in_mr, int in_relu) {
+                    hipStream_t st, float* stats, const float* mask, int accumulate, const float* in_mr, int in_relu, int dil) {
     W64Args a;
+    const long P = (long)N * H * W;
+    a.img_px = (unsigned)(H * W); a.rowb_px = 0; a.rpx = (unsigned)W; a.ppx = 1; a.n_sh = 0; a.n_m = 0;
+    if (dil == 2) {
+        a.rowb_px = (unsigned)W; a.rpx = 2u * (unsigned)W; a.ppx = 2; a.n_sh = 2; a.n_m = 1;
+        N *= 4; H /= 2; W /= 2;
+    }
     a.y2 = nullptr; a.split = 0; a.pool0 = 0; a.nby2 = 0;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.mask = mask; a.mr = in_mr; a.in_relu = in_relu;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.nch = Cin / 8;
     a.relu = relu;
     a.stats = stats;
-    const long P = (long)N * H * W;
     a.nbx = (unsigned)(P * Cin * 4);
     a.nbu = (unsigned)(16L * Cout * Cin * 4);
     a.nby = (unsigned)(P * Cout * 4);
@@ -733,6 +752,7 @@ bool conv_wino64_split_ok(int Cin, int Cout, int split, int pool0, int N, int H,
 int conv_wino64_fwd_split(const float* x, const float* u, const float* bias, float* y0, float* y1, int N, int H, int W, int Cin, int Cout,
                           int split, int pool0, int relu, hipStream_t st) {
     W64Args a;
+    a.img_px = (unsigned)(H * W); a.rowb_px = 0; a.rpx = (unsigned)W; a.ppx = 1; a.n_sh = 0; a.n_m = 0;
     a.x = x; a.u = u; a.bias = bias; a.y = y0; a.y2 = y1; a.mask = nullptr; a.mr = nullptr; a.in_relu = 0;
     a.split = split; a.pool0 = pool0;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -780,6 +800,9 @@ struct W64WgArgs {
     const float* x1;
     int C0, up0;
     unsigned nbx1;
+    // pixel index of (n, y, x) as in W64Args (k_conv_wino_wgrad32 only): dense, or the phase images of a dilation-2 layer
+    unsigned img_px, rowb_px, rpx, ppx;
+    int n_sh, n_m;
 };
 
 #ifndef W6_WLS
@@ -1154,8 +1177,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
     // ---- loader slots ----
     // dY float4 f = tid + 512 j -> pixel f / 8 = (tid >> 3) + 64 j (two pixel rows per slot), co quad tid & 7
     const int d_px = tid >> 3;
-    const unsigned d_fix = ((unsigned)((d_px >> 5) * W + (d_px & 31)) * Cout + co_base + (tid & 7) * 4) * 4u;
-    const unsigned d_jstride = (unsigned)(2 * W) * Cout * 4u;
+    const unsigned d_fix = (((unsigned)(d_px >> 5) * a.rpx + (unsigned)(d_px & 31) * a.ppx) * Cout + co_base + (tid & 7) * 4) * 4u;
+    const unsigned d_jstride = 2u * a.rpx * Cout * 4u;
     const int d_lds = d_px * WH_DP + (tid & 7) * 4;                       // + j * 64 * WH_DP
     // the source of this workgroup's ci block (uniform): its pointer, channels per pixel, first channel, row length
     const bool x_s1 = ci_base >= a.C0;
@@ -1172,7 +1195,8 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
         int f = tid + j * NT;
         if (f >= XF) f -= XF;
         const int hp = f >> 3, hy = hp / XW, hx = hp - hy * XW;
-        x_fix[j] = ((unsigned)((x_up ? (hy + 1) >> 1 : hy) * x_w + (x_up ? (hx + 1) >> 1 : hx)) * x_cs + x_cb + (tid & 7) * 4) * 4u;
+        const unsigned xpx = x_up ? (unsigned)(((hy + 1) >> 1) * x_w + ((hx + 1) >> 1)) : (unsigned)hy * a.rpx + (unsigned)hx * a.ppx;
+        x_fix[j] = (xpx * x_cs + x_cb + (tid & 7) * 4) * 4u;
         x_lds[j] = 2 * DBUF + hp * WH_XP + (tid & 7) * 4;
         x_bits |= (unsigned)((hy == 0 ? 1 : 0) | (hy == G::XR - 1 ? 2 : 0) | (hx == 0 ? 4 : 0) | (hx == XW - 1 ? 8 : 0)) << (4 * j);
     }
@@ -1190,10 +1214,11 @@ __global__ void __launch_bounds__(512, 1) k_conv_wino_wgrad32(W64WgArgs a) {
     unsigned x_edges = 0;
     auto region_setup = [&](int n, int tx, int ty) {
         const int y0 = ty * G::TRP, x0 = tx * RW;
-        const long dpix = ((long)n * H + y0) * W + x0;
+        const long nbase = (long)(n >> a.n_sh) * a.img_px + (long)((n >> 1) & a.n_m) * a.rowb_px + (n & a.n_m);
+        const long dpix = nbase + (long)y0 * a.rpx + (long)x0 * a.ppx;
         const long doff = dpix * Cout * 4;
         rsd = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.dy + doff), 0, (int)(unsigned)((long)a.nbd - doff), 0x00020000);
-        const long xpix = x_up ? ((long)n * x_h + (y0 >> 1) - 1) * x_w + (x0 >> 1) - 1 : dpix - W - 1;
+        const long xpix = x_up ? ((long)n * x_h + (y0 >> 1) - 1) * x_w + (x0 >> 1) - 1 : dpix - (long)a.rpx - (long)a.ppx;
         const long xoff = xpix * x_cs * 4;
         const long xleft = x_nb - xoff;
         rsx = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)x_ptr + xoff), 0, (int)(unsigned)(xleft > 0xFFFFFFF0L ? 0xFFFFFFF0L : xleft), 0x00020000);
@@ -1449,7 +1474,11 @@ int conv_wino64_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_sla
     if (kt_out) *kt_out = kt;
     return ceil_div(nsp, kt);
 }
+static void wgrad_dense(W64WgArgs& a) {
+    a.img_px = (unsigned)(a.H * a.W); a.rowb_px = 0; a.rpx = (unsigned)a.W; a.ppx = 1; a.n_sh = 0; a.n_m = 0;
+}
 static void wgrad_sources(W64WgArgs& a, const ConvIn& in, long P) {
+    wgrad_dense(a);
     a.x = in.src0; a.x1 = in.C1 ? in.src1 : in.src0; a.C0 = in.C0; a.up0 = in.C1 ? in.up0 : 0;
     a.nbx = (unsigned)((a.up0 ? P / 4 : P) * in.C0 * 4);
     a.nbx1 = (unsigned)(P * in.C1 * 4);
@@ -1501,8 +1530,12 @@ int conv_wino32_wgrad_blocks(int Cin, int Cout, int N, int H, int W, int max_sla
     if (kt_out) *kt_out = kt;
     return ceil_div(nsp, kt);
 }
+// the weight gradient of a dilation-2 layer = the plain one summed over the four phase images of x and dy (see W64Args)
+bool conv_wino32_wgrad_dil2_ok(int C0, int Cout, int H, int W) {
+    return H % 2 == 0 && W % 2 == 0 && conv_wino32_wgrad_ok(C0, 0, 0, Cout, H / 2, W / 2);
+}
 int conv_wino32_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart, int N, int H, int W, int Cin, int Cout, int nsb, int kt,
-                      hipStream_t st) {
+                      hipStream_t st, int dil) {
     constexpr size_t lds = (size_t)2 * (WhGeo::DBUF + WhGeo::XBUF) * sizeof(float);
     static_assert(lds <= 160 * 1024 && lds >= 64 * 1024, "the fold needs 64 KB");
     static bool attr_set = false;
@@ -1517,9 +1550,13 @@ int conv_wino32_wgrad(const ConvIn& in, const float* dy, float* ws, float* bpart
     W64WgArgs a;
     a.dy = dy; a.part = ws; a.bias_part = bpart;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.tilesY = H / 4; a.tilesX = W / 32; a.nsp = N * a.tilesY * a.tilesX;
-    a.n_ci_b = Cin / 32; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
     wgrad_sources(a, in, P);
+    if (dil == 2) {        // (nsb, kt: from conv_wino32_wgrad_blocks(Cin, Cout, 4 N, H / 2, W / 2, ..))
+        a.img_px = (unsigned)(H * W); a.rowb_px = (unsigned)W; a.rpx = 2u * (unsigned)W; a.ppx = 2; a.n_sh = 2; a.n_m = 1;
+        a.N = 4 * N; a.H = H / 2; a.W = W / 2;
+    }
+    a.tilesY = a.H / 4; a.tilesX = a.W / 32; a.nsp = a.N * a.tilesY * a.tilesX;
+    a.n_ci_b = Cin / 32; a.nblk = (Cout / 32) * a.n_ci_b; a.kt = kt;
     a.nbd = (unsigned)(P * Cout * 4);
     k_conv_wino_wgrad32<<<a.nblk * nsb, 512, lds, st>>>(a);
     VQW_LAUNCH_CHECK("conv_wino32_wgrad");

@@ -54,6 +54,9 @@ SIGNATURES = {
     "vqw_conv3x3_wino_fwd_masked": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_wino_fwd_acc": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_conv3x3_wino_split_supported": (c_i, [c_i] * 7),
+    "vqw_conv3x3_wino_dil2_supported": (c_i, [c_i] * 5),
+    "vqw_conv3x3_wino_dil2_stats_parts": (c_i, [c_i] * 5),
+    "vqw_conv3x3_wino_dil2_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
     "vqw_conv3x3_wino_fwd_split": (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     "vqw_conv3x3_wino_fwd_inbwd_parts": (c_i, [c_i] * 5),
     "vqw_conv3x3_wino_fwd_inbwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -573,6 +573,18 @@ class _Conv2d(torch.autograd.Function):
             else:
                 _lib.check(L.vqw_conv3x3_wino_fwd(_p(x0), _p(u), _p(bias), _p(y), N, H, W, Cin, Cout, int(relu), _st()),
                            "vqw_conv3x3_wino_fwd")
+        elif wino_fwd and not up0 and x1 is None and ks == 3 and dilation == 2 and \
+                _L().vqw_conv3x3_wino_dil2_supported(Cin, Cout, N, H, W) and \
+                (not (want_stats and not relu) or _L().vqw_conv3x3_wino_dil2_stats_parts(Cin, Cout, N, H, W) > 0):
+            # dilation 2: the plain Winograd kernel on the four phase images of the tensors (same U as the plain layer)
+            L = _L()
+            u = _cached(weight, "wino", lambda: _wino_weights(L, w, Cin, Cout))
+            y = empty_nhwc(N, Cout, H, W, x0)
+            nparts = L.vqw_conv3x3_wino_dil2_stats_parts(Cin, Cout, N, H, W) if (want_stats and not relu) else 0
+            if nparts > 0:
+                part = torch.empty(N * nparts * Cout * 2, dtype=torch.float32, device=x0.device)
+            _lib.check(L.vqw_conv3x3_wino_dil2_fwd(_p(x0), _p(u), _p(bias), _p(y), _p(part) if nparts > 0 else None, 0, N, H, W, Cin, Cout,
+                                                   int(relu), _st()), "vqw_conv3x3_wino_dil2_fwd")
         else:
             nparts = 0
             if want_stats and not relu:
@@ -996,6 +1008,12 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
                            "vqw_conv3x3_wino_fwd_acc(dgrad)")
                 group_acc_calls += 1
                 g_full = None
+            elif ks == 3 and dilation == 2 and L.vqw_conv3x3_wino_dil2_supported(Cout, Cin, N, H, W):
+                # dilation 2: the Winograd kernel on the phase images, adding to the shared buffer in its epilogue
+                ut = _cached(w, "wino_dgrad", lambda: _wino_weights_dgrad(L, w, Cout, Cin))
+                _lib.check(L.vqw_conv3x3_wino_dil2_fwd(_p(gy), _p(ut), None, _p(group.buf), None, 1, N, H, W, Cout, Cin, 0, _st()),
+                           "vqw_conv3x3_wino_dil2_fwd(dgrad, acc)")
+                g_full = None
             elif L.vqw_conv2d_fwd_acc_supported(Cout, N, H, W, Cin, ks, dilation):
                 # row-chain kernel (dilated 3x3) or the implicit-GEMM kernel (1x1): y += conv in the epilogue
                 _lib.check(L.vqw_conv2d_fwd_acc(_p(gy), Cout, _p(wt_of()), _p(group.buf), N, H, W, Cin, ks, dilation, _st()),
@@ -1024,6 +1042,10 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
             ut = _cached(w, "wino_dgrad", lambda: _wino_weights_dgrad(L, w, Cout, Cin))
             _lib.check(L.vqw_conv3x3_wino_fwd(_p(gy), _p(ut), None, _p(g_full), N, H, W, Cout, Cin, 0, _st()),
                        "vqw_conv3x3_wino_fwd(dgrad)")
+        elif ks == 3 and dilation == 2 and x1 is None and not up0 and L.vqw_conv3x3_wino_dil2_supported(Cout, Cin, N, H, W):
+            ut = _cached(w, "wino_dgrad", lambda: _wino_weights_dgrad(L, w, Cout, Cin))
+            _lib.check(L.vqw_conv3x3_wino_dil2_fwd(_p(gy), _p(ut), None, _p(g_full), None, 0, N, H, W, Cout, Cin, 0, _st()),
+                       "vqw_conv3x3_wino_dil2_fwd(dgrad)")
         else:
             _lib.check(L.vqw_conv2d_fwd(_p(gy), Cout, 0, None, 0, _p(wt_of()), None, _p(g_full), N, H, W, Cin, ks, dilation, 0, _st()),
                        "vqw_conv2d_fwd(dgrad)")

@@ -117,6 +117,11 @@ CONV_CASES = [
     (1, 8, 32, 32, 0, False, 32, 3, 8, True, False),
     (4, 130, 64, 32, 0, False, 32, 3, 7, False, False),
     (2, 200, 32, 32, 0, False, 32, 3, 5, True, True),
+    # dilation 2 in Winograd form on the four phase images of the tensors (round 4: pitch parameters of the 32-cout kernels): even
+    # sizes with W / 2 a multiple of 32; several regions per phase image, 2 ... 8 channel chunks, bias / ReLU epilogues
+    (2, 16, 64, 32, 0, False, 32, 3, 2, True, False),
+    (1, 40, 128, 64, 0, False, 32, 3, 2, False, True),
+    (3, 24, 64, 32, 0, False, 96, 3, 2, True, False),
     # Winograd F(2x2, 3x3) form of plain 3x3 layers (conv_wino.hip): ragged H (not a multiple of the 16-row region, odd),
     # several 32-pixel strips, two cout tiles with a partial one, 2 .. 16 channel chunks, bias + ReLU epilogue
     (2, 16, 32, 16, 0, False, 32, 3, 1, True, True),
@@ -738,6 +743,43 @@ def test_input_gradient_winograd_weights_straight_from_the_layer_weight():
         _lib.check(L.vqw_conv3x3_wino_prepare_dgrad(p(w), p(ub), nb, co, ci, st), "prepare_dgrad")
         torch.cuda.synchronize()
         assert torch.equal(ua, ub), (co, ci)
+
+
+def test_dilation_two_layer_in_winograd_form_on_its_phase_images():
+    """A 3x3 layer of dilation 2 (the pyramid's first branch, aspp.py:27-30) is four plain layers on the phase images of its
+    tensors: forward with the following norm's statistics partials, input gradient alone and added to a gradient group's buffer,
+    weight gradient - against an fp64 convolution (2e-5), and the statistics against the tensor's own (the norm built on them
+    against F.instance_norm)."""
+    from hipops import ops
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+    for (N, C, K, H, W) in [(2, 32, 32, 16, 64), (1, 64, 32, 24, 128)]:
+        g = torch.Generator().manual_seed(N * 100 + C)
+        x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+        w2 = torch.randn(K, C, 3, 3, generator=g, dtype=torch.float64) * 0.2
+        w1 = torch.randn(K, C, 1, 1, generator=g, dtype=torch.float64) * 0.2
+        r2 = torch.randn(N, K, H, W, generator=g, dtype=torch.float64)
+        r1 = torch.randn(N, K, H, W, generator=g, dtype=torch.float64)
+        xd = x.clone().requires_grad_(True); w2d = w2.clone().requires_grad_(True); w1d = w1.clone().requires_grad_(True)
+        y2 = F.instance_norm(F.conv2d(xd, w2d, padding=2, dilation=2), eps=1e-5)
+        y1 = F.conv2d(xd, w1d)
+        ((y2 * r2).sum() + (y1 * r1).sum()).backward()
+        dx = cl(x.float().to(DEV)).requires_grad_(True)
+        dw2 = cl(w2.float().to(DEV)).requires_grad_(True)
+        dw1 = cl(w1.float().to(DEV)).requires_grad_(True)
+        grp = ops.GradGroup(2)
+        with ops.winograd_forward():
+            # the 1x1 member is created last: it runs first in backward and its gradient becomes the group's buffer
+            raw, part = ops.conv2d(dx, dw2, None, dilation=2, want_stats=True, grad_group=grp)
+            assert part is not None and ops._L().vqw_conv3x3_wino_dil2_supported(C, K, N, H, W) == 1
+            z2 = ops.instance_norm(raw, relu=False, eps=1e-5, part=part)
+            z1 = ops.conv2d(dx, dw1, None, grad_group=grp)
+        ((z2 * r2.float().to(DEV)).sum() + (z1 * r1.float().to(DEV)).sum()).backward()
+        torch.cuda.synchronize()
+        tag = "dilation 2 on phase images %s" % ((N, C, K, H, W),)
+        assert_close(z2, y2, 2e-5, tag + " norm(conv)")
+        assert_close(dx.grad, xd.grad, 5e-5, tag + " dx (group of two)")
+        assert_close(dw2.grad, w2d.grad, 5e-5, tag + " dw")
+        assert_close(dw1.grad, w1d.grad, 2e-5, tag + " dw (1x1 member)")
 
 
 def test_style_layer_pair_as_one_launch(monkeypatch):
