@@ -237,6 +237,13 @@ int vqw_spade_fwd(const float* x, const float* mean_rstd /*[C][2]*/, const float
 /* the same with the block's residual added after the activation: y = act(...) + res (blocks.py:134, `shortcut + main`) */
 int vqw_spade_fwd_res(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
                       const float* res, float* y, long P, int C, int relu, void* stream);
+/* The same with the residual given RAW together with its InstanceNorm statistics (ABI 8): y = act(spade(x)) +
+ * InstanceNorm(+ReLU)(res_raw), res_mean_rstd [N][C][2] - the shortcut branch of a StyledResUpBlock (blocks.py:113-116, 134)
+ * normalised while it is read, its normalised tensor never written.  HW a power of two, C / 4 a power of two <= 256. */
+int vqw_spade_fwd_res_norm_supported(long HW, int C);
+int vqw_spade_fwd_res_norm(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
+                           const float* res_raw, const float* res_mean_rstd, int res_relu, float* y, int N, long HW, int C,
+                           int relu, void* stream);
 /* backward, phase 1: dgamma, dbeta and per-channel sums [sum dxhat, sum dxhat*xhat] */
 int vqw_spade_bwd_reduce(const float* x, const float* mean_rstd, const float* gamma, const float* beta,
                          const float* gy, float* dgamma, float* dbeta, int gb_stride,

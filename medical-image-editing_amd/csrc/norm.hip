@@ -572,13 +572,17 @@ __global__ void __launch_bounds__(256) k_inorm_bwd_pair_apply4w(const float4* __
 }
 
 // SPADE: constants per channel only; the walk runs over the P = N * HW pixels of the batch (grid.x only)
+// RES 2: the residual is InstanceNorm(+ReLU) of `res`, applied here from its per-(image, channel) statistics rmr [N][C][2]
+// (StyledResUpBlock's shortcut branch: its normalised tensor is never written; HW = 2^lgHW pixels per image)
 template <int RELU, int RES>
 __global__ void __launch_bounds__(256) k_spade_fwd4w(const float4* __restrict__ x, const float* __restrict__ mr,
                                                      const float4* __restrict__ gamma, const float4* __restrict__ beta,
                                                      float4* __restrict__ y, long P, int C4, int lgC4, int gbs4,
-                                                     const float4* __restrict__ res) {
+                                                     const float4* __restrict__ res, const float* __restrict__ rmr = nullptr,
+                                                     int lgHW = 0, int rrelu = 0) {
     WALK4_SETUP;
     const float4 m0 = ((const float4*)(mr + 8 * c4))[0], m1 = ((const float4*)(mr + 8 * c4))[1];
+    const float rlo = rrelu ? 0.f : -__builtin_inff();
     for (long p0 = (long)blockIdx.x * 4 * R + r; p0 < P; p0 += (long)gridDim.x * 4 * R) {
         float4 v[4], ga[4], be[4], rr[4];
 #pragma unroll
@@ -587,6 +591,12 @@ __global__ void __launch_bounds__(256) k_spade_fwd4w(const float4* __restrict__ 
                 const long p = p0 + u * R;
                 v[u] = x[p * C4 + c4]; ga[u] = gamma[p * gbs4 + c4]; be[u] = beta[p * gbs4 + c4];
                 if (RES) rr[u] = res[p * C4 + c4];
+                if (RES == 2) {
+                    const float4* q = (const float4*)(rmr + (((p >> lgHW) << lgC4) + c4) * 8);      // (mean, rstd) of 4 channels
+                    const float4 q0 = q[0], q1 = q[1];
+                    rr[u].x = fmaxf((rr[u].x - q0.x) * q0.y, rlo); rr[u].y = fmaxf((rr[u].y - q0.z) * q0.w, rlo);
+                    rr[u].z = fmaxf((rr[u].z - q1.x) * q1.y, rlo); rr[u].w = fmaxf((rr[u].w - q1.z) * q1.w, rlo);
+                }
             }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1298,6 +1308,30 @@ extern "C" int vqw_spade_fwd_res(const float* x, const float* mean_rstd, const f
     if (relu) k_spade_fwd4<1><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4, (const float4*)res);
     else k_spade_fwd4<0><<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, t4, C / 4, gb_stride / 4, (const float4*)res);
     VQW_LAUNCH_CHECK("vqw_spade_fwd_res");
+    return VQW_OK;
+}
+// y = act(spade(x)) + InstanceNorm(+ReLU)(res_raw): the block's shortcut branch normalised while it is read (its statistics
+// res_mean_rstd [N][C][2] from vqw_inorm_stats_parts / vqw_inorm_stats) - the normalised shortcut tensor is never materialised
+extern "C" int vqw_spade_fwd_res_norm_supported(long HW, int C) {
+    return (C % 4 == 0 && walk_ok(C / 4) && HW > 0 && (HW & (HW - 1)) == 0) ? 1 : 0;
+}
+extern "C" int vqw_spade_fwd_res_norm(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,
+                                      const float* res_raw, const float* res_mean_rstd, int res_relu, float* y, int N, long HW, int C,
+                                      int relu, void* stream) {
+    VQW_PROF_HBM(stream, 5, (double)N * HW * C);
+    VQW_CHECK(x && mean_rstd && gamma && beta && res_raw && res_mean_rstd && y && N > 0 && HW > 0 && C > 0 && gb_stride >= C,
+              "vqw_spade_fwd_res_norm: bad arguments");
+    VQW_CHECK(vqw_spade_fwd_res_norm_supported(HW, C) && (gb_stride & 3) == 0 && al16(x) && al16(gamma) && al16(beta) && al16(y) &&
+                  al16(mean_rstd) && al16(res_raw) && al16(res_mean_rstd),
+              "vqw_spade_fwd_res_norm: shape not served (query vqw_spade_fwd_res_norm_supported) or unaligned tensors");
+    const long P = (long)N * HW;
+    int lg = 0;
+    while ((1L << lg) < HW) ++lg;
+    const int C4 = C / 4, gr = walk_blocks_flat(P, C4, 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) k_spade_fwd4w<1, 2><<<gr, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, P, C4, ilog2_exact(C4), gb_stride / 4, (const float4*)res_raw, res_mean_rstd, lg, res_relu);
+    else k_spade_fwd4w<0, 2><<<gr, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)gamma, (const float4*)beta, (float4*)y, P, C4, ilog2_exact(C4), gb_stride / 4, (const float4*)res_raw, res_mean_rstd, lg, res_relu);
+    VQW_LAUNCH_CHECK("vqw_spade_fwd_res_norm");
     return VQW_OK;
 }
 extern "C" int vqw_spade_fwd(const float* x, const float* mean_rstd, const float* gamma, const float* beta, int gb_stride,

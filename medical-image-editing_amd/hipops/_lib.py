@@ -82,6 +82,8 @@ SIGNATURES = {
     "vqw_bn_eval_stats": (c_i, [c_p, c_p, c_p, c_f, c_i, c_p]),
     "vqw_spade_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_l, c_i, c_i, c_p]),
     "vqw_spade_fwd_res": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_l, c_i, c_i, c_p]),
+    "vqw_spade_fwd_res_norm_supported": (c_i, [c_l, c_i]),
+    "vqw_spade_fwd_res_norm": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_l, c_i, c_i, c_p]),
     "vqw_spade_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_spade_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_d, c_p, c_l, c_i, c_i, c_i, c_p]),
     "vqw_add": (c_i, [c_p, c_p, c_p, c_l, c_i, c_p]),

@@ -1433,7 +1433,10 @@ def _all_reduce(t):
 
 class _Spade(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt, res=None, part=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync, nbt, res=None, part=None,
+                res_norm=None):
+        """res_norm = (statistics partials of res or None, relu, eps): `res` is the RAW input of an InstanceNorm(+ReLU) whose output is
+        the residual; it is normalised inside the modulation kernel (vqw_spade_fwd_res_norm) and never materialised."""
         _dev(x, gamma, beta, res)
         x, gamma = nhwc(x), nhwc(gamma)
         N, C, H, W = x.shape
@@ -1480,22 +1483,36 @@ class _Spade(torch.autograd.Function):
         else:
             _lib.check(L.vqw_bn_eval_stats(_p(running_mean), _p(running_var), _p(mr), eps, C, _st()), "vqw_bn_eval_stats")
         y = torch.empty_like(x, memory_format=CL)
+        rmr = None
         if res is not None:         # y = act(...) + res: the block's `shortcut + main` inside this kernel
             res = nhwc(res)
             if res.shape != x.shape:
                 raise RuntimeError("spade_norm: residual shape %s does not match %s" % (tuple(res.shape), tuple(x.shape)))
+        if res is not None and res_norm is not None:
+            rpart, rrelu, reps = res_norm
+            rmr = torch.empty(N * C * 2, dtype=torch.float32, device=x.device)
+            if rpart is not None:
+                _lib.check(L.vqw_inorm_stats_parts(_p(rpart), rpart.numel() // (N * C * 2), _p(rmr), N, H * W, C, reps, _st()),
+                           "vqw_inorm_stats_parts")
+            else:
+                ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), res)
+                _lib.check(L.vqw_inorm_stats(_p(res), _p(rmr), _p(ws), ws.numel(), N, H * W, C, reps, _st()), "vqw_inorm_stats")
+            _lib.check(L.vqw_spade_fwd_res_norm(_p(x), _p(mr), gptr, bptr, gbs, _p(res), _p(rmr), int(rrelu), _p(y), N, H * W, C,
+                                                int(relu), _st()), "vqw_spade_fwd_res_norm")
+            ctx.res_relu = bool(rrelu)
+        elif res is not None:
             _lib.check(L.vqw_spade_fwd_res(_p(x), _p(mr), gptr, bptr, gbs, _p(res), _p(y), N * H * W, C, int(relu), _st()),
                        "vqw_spade_fwd_res")
         else:
             _lib.check(L.vqw_spade_fwd(_p(x), _p(mr), gptr, bptr, gbs, _p(y), N * H * W, C, int(relu), _st()), "vqw_spade_fwd")
-        ctx.save_for_backward(x, gamma, beta, mr)
+        ctx.save_for_backward(x, gamma, beta, mr, res if rmr is not None else None, rmr)
         ctx.cfg = (training, relu, count, sync, fused)
         ctx.has_res = res is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, beta, mr = ctx.saved_tensors
+        x, gamma, beta, mr, res_raw, rmr = ctx.saved_tensors
         training, relu, count, sync, fused = ctx.cfg
         N, C, H, W = x.shape
         L = _L()
@@ -1517,13 +1534,36 @@ class _Spade(torch.autograd.Function):
             _all_reduce(sums)
         _lib.check(L.vqw_spade_bwd_apply(_p(x), _p(mr), gptr, bptr, gbs, _p(gy), _p(sums), count, _p(gx), N * H * W, C,
                                          int(relu), int(training), _st()), "vqw_spade_bwd_apply")
-        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None, (gy if ctx.has_res else None), None
+        gres = gy if ctx.has_res else None
+        if rmr is not None and ctx.needs_input_grad[11]:
+            # the residual was normalised in the forward kernel: its gradient goes back through that InstanceNorm(+ReLU) here
+            gres = torch.empty_like(res_raw, memory_format=CL)
+            ws2 = _ws(L.vqw_plane_ws_bytes(N, C, H * W), res_raw)
+            _lib.check(L.vqw_inorm_bwd(_p(res_raw), _p(rmr), _p(gy), C, 0, _p(gres), _p(ws2), ws2.numel(), N, H * W, C,
+                                       int(ctx.res_relu), _st()), "vqw_inorm_bwd(residual)")
+        return gx, dgamma, dbeta, None, None, None, None, None, None, None, None, gres, None, None
+
+
+RES_NORM_FUSED = os.environ.get("VQW_RES_NORM_FUSED", "1") != "0"      # 0: the shortcut's norm writes its tensor first (A/B)
 
 
 def spade_norm(x, gamma, beta, running_mean, running_var, training, momentum=0.1, eps=1e-5, relu=False, sync=True,
-               num_batches_tracked=None, residual=None, part=None):
+               num_batches_tracked=None, residual=None, part=None, residual_norm=None):
     """residual: added AFTER the activation (y = act(spade(x)) + residual); needs C % 4 == 0.
-    part: statistics partials of x from conv2d(..., want_stats=True) (training mode skips its reduction pass)."""
+    part: statistics partials of x from conv2d(..., want_stats=True) (training mode skips its reduction pass).
+    residual_norm = (partials or None, relu, eps): `residual` is the RAW input of an InstanceNorm(+ReLU) - the block's shortcut
+    branch - and is normalised inside the modulation kernel where the shape allows, by a separate pass otherwise."""
+    if residual is not None and residual_norm is not None:
+        N, C, H, W = x.shape
+        if not (RES_NORM_FUSED and x.is_cuda and not (C & 3) and not (gamma.shape[1] & 3) and tuple(residual.shape) == tuple(x.shape)
+                and _L().vqw_spade_fwd_res_norm_supported(H * W, C)):
+            rpart, rrelu, reps = residual_norm
+            residual = instance_norm(residual, relu=rrelu, eps=reps, part=rpart)
+            residual_norm = None
+    if residual_norm is not None:
+        return _Spade.apply(x, gamma, beta, running_mean, running_var, bool(training), float(momentum), float(eps), bool(relu),
+                            bool(sync), num_batches_tracked, residual, part if training else None,
+                            (residual_norm[0], bool(residual_norm[1]), float(residual_norm[2])))
     if residual is not None and (x.shape[1] & 3 or gamma.shape[1] & 3):
         return add(spade_norm(x, gamma, beta, running_mean, running_var, training, momentum, eps, relu, sync,
                               num_batches_tracked, part=part), residual)

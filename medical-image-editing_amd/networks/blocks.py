@@ -171,13 +171,13 @@ class StyledDenorm(nn.Module):
             return ops.conv2d_cat(actv, self.mlp_gamma.weight, self.mlp_gamma.bias, self.mlp_beta.weight, self.mlp_beta.bias, relu_input=True), None
         return self.mlp_gamma(actv), self.mlp_beta(actv)
 
-    def forward(self, x, style, relu=False, maps=None, residual=None, part=None):
+    def forward(self, x, style, relu=False, maps=None, residual=None, part=None, residual_norm=None):
         bn = self.param_free_norm
         gamma, beta = maps if maps is not None else self.style_maps(style)
         return ops.spade_norm(x, gamma, beta, bn.running_mean, bn.running_var, self.training,
                               momentum=bn.momentum, eps=bn.eps, relu=relu,
                               num_batches_tracked=bn.num_batches_tracked if self.training else None, residual=residual,
-                              part=part)
+                              part=part, residual_norm=residual_norm)
 
 
 class PixelShuffle(nn.Module):
@@ -252,8 +252,11 @@ class StyledResUpBlock(nn.Module):
         else:
             s, part = self.conv[0](x, up2x=up, want_stats=True, grad_group=gx)      # the shortcut conv's epilogue leaves its norm's statistics
             h, part1 = self.conv1(x, up2x=up, want_stats=True, grad_group=gx)      # ... and norm1's batch statistics
-        s = self.conv[1](s, part=part)
+        # the shortcut's InstanceNorm(+ReLU) is applied where its output is consumed - inside norm2's modulation kernel, from the
+        # statistics its convolution's epilogue left: the normalised shortcut tensor is never written (ops.spade_norm, residual_norm)
+        sn, part_s = self.conv[1], part
         br.join(*m1, *m2)
         h = self.norm1(h, skip_input, relu=True, maps=m1, part=part1)
         h, part = self.conv2(h, want_stats=True)       # the epilogue leaves norm2's batch statistics
-        return self.norm2(h, skip_input, relu=self.use_output_act, maps=m2, residual=s, part=part)   # shortcut + main, in the kernel
+        return self.norm2(h, skip_input, relu=self.use_output_act, maps=m2, residual=s, part=part,
+                          residual_norm=(part_s, sn.relu, sn.eps))   # shortcut + main, in the kernel

@@ -782,6 +782,42 @@ def test_dilation_two_layer_in_winograd_form_on_its_phase_images():
         assert_close(dw1.grad, w1d.grad, 2e-5, tag + " dw (1x1 member)")
 
 
+def test_shortcut_norm_applied_inside_the_modulation_kernel(monkeypatch):
+    """StyledResUpBlock's shortcut branch ends in InstanceNorm + ReLU and is added to the main path after norm2 (blocks.py:113-116,
+    134).  Its normalisation runs inside norm2's modulation kernel from the statistics the shortcut convolution's epilogue left
+    (vqw_spade_fwd_res_norm); the normalised tensor is never written.  Output and every gradient agree with the separate
+    normalisation pass (VQW_RES_NORM_FUSED=0) to rounding, in both up-sampling modes and without the output activation."""
+    from networks import blocks as B
+    from hipops import ops
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+
+    def run(fused, **kw):
+        monkeypatch.setattr(ops, "RES_NORM_FUSED", fused)
+        torch.manual_seed(29)
+        mod = B.StyledResUpBlock(64, 32, 32, **kw).to(DEV).train()
+        down = cl(torch.randn(2, 64, 16, 32, device=DEV)).requires_grad_(True)
+        skip = cl(torch.randn(2, 32, 32, 64, device=DEV)).requires_grad_(True)
+        r = cl(torch.randn(2, 32, 32, 64, device=DEV))
+        out = mod(down, skip)
+        (out * r).sum().backward()
+        torch.cuda.synchronize()
+        grads = {"down": down.grad.clone(), "skip": skip.grad.clone()}
+        grads.update({k: p.grad.clone() for k, p in mod.named_parameters()})
+        stats = {k: v.clone() for k, v in mod.state_dict().items() if "running" in k}
+        return out.detach(), grads, stats
+    for kw in (dict(), dict(use_output_act=False), dict(use_pixel_shuffle=True)):
+        y0, g0, s0 = run(False, **kw)
+        y1, g1, s1 = run(True, **kw)
+        assert_close(y1, y0, 1e-6, "block output %s" % (kw,))
+        gmax = max(float(v.abs().max()) for v in g0.values())
+        for k in g0:
+            if float(g0[k].abs().max()) < 1e-4 * gmax:
+                continue
+            assert_close(g1[k], g0[k], 2e-6, "gradient %s %s" % (k, kw))
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k
+
+
 def test_style_layer_pair_as_one_launch(monkeypatch):
     """The mlp_shared convolutions (+ReLU) of a StyledResUpBlock's two StyledDenorms read the same style tensor (blocks.py:72-75,
     100-134): inside ops.winograd_forward() they run as ONE launch of the 64-cout Winograd kernel on concatenated weights with a
