@@ -200,6 +200,11 @@ int vqw_inorm_stats_parts(const float* part, int nparts, float* mean_rstd, int N
 /* Two norms of one shape in one launch (ABI 8; a ResBlock's main and 1x1 branches, blocks.py:21-36). */
 int vqw_inorm_stats_parts2(const float* part_a, int nparts_a, float* mean_rstd_a, const float* part_b, int nparts_b,
                            float* mean_rstd_b, int N, int HW, int C, float eps, void* stream);
+/* y = a + InstanceNorm(+ReLU)(x) from x's statistics mean_rstd [N][C][2] (ABI 8): the residual add behind a block that ends in
+ * that norm (the decoder's tail `x + conv_last(x)`, unet_decoder.py:169-171); the normalised tensor is never written.  The
+ * backward is vqw_inorm_bwd on the gradient of y (and the gradient of `a` is that gradient).  C / 4 a power of two <= 256. */
+int vqw_inorm_add_supported(int C);
+int vqw_inorm_add_fwd(const float* x, const float* mean_rstd, const float* a, float* y, int N, int HW, int C, int relu, void* stream);
 int vqw_inorm_bwd(const float* x, const float* mean_rstd, const float* gy, int gy_cstride, int gy_coff,
                   float* gx, void* ws, size_t ws_bytes, int N, int HW, int C, int relu, void* stream);
 /* ABI 7.  The same with the two sums taken from part[N][nparts][C][2] = (sum gm, sum gm * xhat) per region, left by the

@@ -504,6 +504,48 @@ __global__ void __launch_bounds__(256) k_inorm_apply4w(const float4* __restrict_
     }
 }
 
+// out = a + InstanceNorm(+ReLU)(x): the residual add behind a block whose last operator is that norm (the decoder's tail,
+// unet_decoder.py:169-171 `x + conv_last(x)`): the normalised tensor is never written
+template <int RELU>
+__global__ void __launch_bounds__(256) k_inorm_add4w(const float4* __restrict__ x, const float* __restrict__ mr, const float4* __restrict__ a,
+                                                     float4* __restrict__ y, int HW, int C4, int lgC4) {
+    WALK4_SETUP;
+    const int n = blockIdx.y;
+    const float4* m = (const float4*)(mr + 8 * ((long)n * C4 + c4));
+    const float4 m0 = m[0], m1 = m[1];
+    const long base = (long)n * HW * C4 + c4;
+    for (int p0 = blockIdx.x * 4 * R + r; p0 < HW; p0 += gridDim.x * 4 * R) {
+        float4 v[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (p0 + u * R < HW) { v[u] = x[base + (long)(p0 + u * R) * C4]; w[u] = a[base + (long)(p0 + u * R) * C4]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * R >= HW) break;
+            float4 o;
+            o.x = (v[u].x - m0.x) * m0.y; o.y = (v[u].y - m0.z) * m0.w; o.z = (v[u].z - m1.x) * m1.y; o.w = (v[u].w - m1.z) * m1.w;
+            if (RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            o.x = w[u].x + o.x; o.y = w[u].y + o.y; o.z = w[u].z + o.z; o.w = w[u].w + o.w;
+            y[base + (long)(p0 + u * R) * C4] = o;
+        }
+    }
+}
+extern "C" int vqw_inorm_add_supported(int C) { return (C % 4 == 0 && walk_ok(C / 4)) ? 1 : 0; }
+extern "C" int vqw_inorm_add_fwd(const float* x, const float* mean_rstd, const float* a, float* y, int N, int HW, int C, int relu,
+                                 void* stream) {
+    VQW_PROF_HBM(stream, 3, (double)N * HW * C);
+    VQW_CHECK(x && mean_rstd && a && y && N > 0 && HW > 0 && C > 0, "vqw_inorm_add_fwd: bad arguments");
+    VQW_CHECK(vqw_inorm_add_supported(C) && al16(x) && al16(a) && al16(y) && al16(mean_rstd),
+              "vqw_inorm_add_fwd: shape not served (query vqw_inorm_add_supported) or unaligned tensors");
+    const int C4 = C / 4;
+    const dim3 g(walk_blocks(N, HW, C4), N);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) k_inorm_add4w<1><<<g, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)a, (float4*)y, HW, C4, ilog2_exact(C4));
+    else k_inorm_add4w<0><<<g, 256, 0, st>>>((const float4*)x, mean_rstd, (const float4*)a, (float4*)y, HW, C4, ilog2_exact(C4));
+    VQW_LAUNCH_CHECK("vqw_inorm_add_fwd");
+    return VQW_OK;
+}
+
 __device__ __forceinline__ float4 inorm_bwd_elem(const float4 v, const float4 g, const float4 m0, const float4 m1, const float4 e0,
                                                  const float4 e1, const bool relu) {
     float4 o;

@@ -73,6 +73,8 @@ SIGNATURES = {
     "vqw_inorm_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_f, c_p]),
     "vqw_inorm_stats_parts": (c_i, [c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     "vqw_inorm_stats_parts2": (c_i, [c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
+    "vqw_inorm_add_supported": (c_i, [c_i]),
+    "vqw_inorm_add_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_inorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_inorm_bwd_pair": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_partial_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),

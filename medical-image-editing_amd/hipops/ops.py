@@ -1605,6 +1605,61 @@ class _Add(torch.autograd.Function):
         return gy, gy, None, None
 
 
+ADD_NORM_FUSED = os.environ.get("VQW_ADD_NORM_FUSED", "1") != "0"      # 0: the norm writes its tensor, then the add reads it (A/B)
+
+
+class _AddNorm(torch.autograd.Function):
+    """y = a + InstanceNorm(+ReLU)(x) with x the RAW convolution output and `part` its statistics partials (or None): the norm is
+    applied inside the add's kernel (vqw_inorm_add_fwd), its output never written.  Backward: the gradient of `a` is gy (handed to
+    `a_group` like _Add does), the gradient of x is the norm's backward of gy."""
+
+    @staticmethod
+    def forward(ctx, a, x, part, relu, eps, a_group):
+        _dev(a, x)
+        a, x = nhwc(a), nhwc(x)
+        if a.shape != x.shape:
+            raise RuntimeError("add_norm: shape mismatch %s vs %s" % (tuple(a.shape), tuple(x.shape)))
+        N, C, H, W = x.shape
+        L = _L()
+        mr = torch.empty(N * C * 2, dtype=torch.float32, device=x.device)
+        if part is not None:
+            _lib.check(L.vqw_inorm_stats_parts(_p(part), part.numel() // (N * C * 2), _p(mr), N, H * W, C, eps, _st()), "vqw_inorm_stats_parts")
+        else:
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+            _lib.check(L.vqw_inorm_stats(_p(x), _p(mr), _p(ws), ws.numel(), N, H * W, C, eps, _st()), "vqw_inorm_stats")
+        y = torch.empty_like(x, memory_format=CL)
+        _lib.check(L.vqw_inorm_add_fwd(_p(x), _p(mr), _p(a), _p(y), N, H * W, C, int(relu), _st()), "vqw_inorm_add_fwd")
+        ctx.save_for_backward(x, mr)
+        ctx.relu, ctx.a_group = bool(relu), a_group
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mr = ctx.saved_tensors
+        N, C, H, W = x.shape
+        L = _L()
+        gy = nhwc(gy)
+        gx = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.empty_like(x, memory_format=CL)
+            ws = _ws(L.vqw_plane_ws_bytes(N, C, H * W), x)
+            _lib.check(L.vqw_inorm_bwd(_p(x), _p(mr), _p(gy), C, 0, _p(gx), _p(ws), ws.numel(), N, H * W, C, int(ctx.relu), _st()),
+                       "vqw_inorm_bwd(add_norm)")
+        ga = gy
+        if ctx.a_group is not None:
+            ga = ctx.a_group.member_done(gy)
+        return ga, gx, None, None, None, None
+
+
+def add_norm_supported(a, x):
+    return bool(ADD_NORM_FUSED and x.is_cuda and x.dim() == 4 and tuple(a.shape) == tuple(x.shape) and _L().vqw_inorm_add_supported(x.shape[1]))
+
+
+def add_norm(a, x, part=None, relu=False, eps=1e-5, a_group=None):
+    """a + instance_norm(x, relu, eps, part) in one kernel (see _AddNorm); query add_norm_supported first."""
+    return _AddNorm.apply(a, x, part, bool(relu), float(eps), a_group)
+
+
 def add(a, b, relu=False, a_group=None):
     """a + b (+ReLU).  a_group: an ops.GradGroup that the OTHER consumers of `a` belong to, sized for them plus this op; `b`
     must be computed from `a` through those consumers (x + f(x)), so that their backward runs after b's whole chain."""

@@ -69,6 +69,12 @@ class UNetDecoder(nn.Module):
             # buffer the branches' input-gradient kernels add to (no add pass by autograd: ops.add(..., a_group=))
             aspp, dc = self.conv_last[0], self.conv_last[1]
             grp = ops.GradGroup(len(list(aspp.stages.children())) + 1) if (ops.GRAD_GROUPS and torch.is_grad_enabled() and x.requires_grad) else None
-            out = ops.add(x, dc(aspp(x, grad_group=grp)), a_group=grp)
+            y = aspp(x, grad_group=grp)
+            if dc.ends_in_norm_relu() and ops.add_norm_supported(x, x) and x.shape[1] == dc.double_conv[3].weight.shape[0]:
+                # the DoubleConv's last InstanceNorm + ReLU is applied inside the residual add (its tensor is never written)
+                raw, part = dc(y, raw_tail=True)
+                out = ops.add_norm(x, raw, part, relu=True, eps=dc.double_conv[4].eps, a_group=grp)
+            else:
+                out = ops.add(x, dc(y), a_group=grp)
             out = self.conv1x1(out)
             return ops.tanh(out)

@@ -818,6 +818,35 @@ def test_shortcut_norm_applied_inside_the_modulation_kernel(monkeypatch):
             assert torch.equal(s0[k], s1[k]), k
 
 
+def test_norm_applied_inside_the_residual_add():
+    """ops.add_norm(a, x, part, relu) = a + instance_norm(x, relu) with the norm applied inside the add's kernel (the decoder's tail
+    `x + conv_last(x)`, unet_decoder.py:169-171): output and the gradients of both operands agree with the two-kernel form to
+    rounding."""
+    from hipops import ops
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+    for (N, C, H, W, relu) in [(2, 32, 24, 32, True), (1, 64, 16, 16, False)]:
+        torch.manual_seed(31)
+        a0 = cl(torch.randn(N, C, H, W, device=DEV)); x0 = cl(torch.randn(N, C, H, W, device=DEV) * 2 + 0.5)
+        w = cl(torch.randn(C, C, 3, 3, device=DEV) * 0.1)
+        r = cl(torch.randn(N, C, H, W, device=DEV))
+        outs = []
+        for fused in (False, True):
+            a = a0.clone().requires_grad_(True); x = x0.clone().requires_grad_(True)
+            with ops.winograd_forward():
+                raw, part = ops.conv2d(x, w, None, want_stats=True)
+            if fused:
+                assert ops.add_norm_supported(a, raw)
+                y = ops.add_norm(a, raw, part, relu=relu, eps=1e-5)
+            else:
+                y = ops.add(a, ops.instance_norm(raw, relu=relu, eps=1e-5, part=part))
+            (y * r).sum().backward()
+            torch.cuda.synchronize()
+            outs.append((y.detach(), a.grad.clone(), x.grad.clone()))
+        # (without the ReLU the compiler contracts `a + (x - mean) * rstd` into one fma: one rounding fewer than the two-kernel form)
+        for k, name in enumerate(("y", "grad a", "grad x")):
+            assert_close(outs[1][k], outs[0][k], 1e-6, "%s (%s)" % (name, (N, C, H, W, relu)))
+
+
 def test_style_layer_pair_as_one_launch(monkeypatch):
     """The mlp_shared convolutions (+ReLU) of a StyledResUpBlock's two StyledDenorms read the same style tensor (blocks.py:72-75,
     100-134): inside ops.winograd_forward() they run as ONE launch of the 64-cout Winograd kernel on concatenated weights with a
