@@ -215,6 +215,13 @@ int vqw_inorm_bwd_parts(const float* x, const float* mean_rstd, const float* gy,
  * b: norm): the common gradient is read once per pass.  ws: 2 x vqw_plane_ws_bytes(N, C, HW).  C % 4 == 0.          */
 int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float* xb, const float* mrb, const float* gy,
                        float* gxa, float* gxb, void* ws, size_t ws_bytes, int N, int HW, int C, void* stream);
+/* vqw_res_tail_bwd followed by vqw_inorm_bwd_pair as one entry point (ABI 8; a ResBlock's tail, blocks.py:29-36): the first
+ * kernel forms g = [out > 0] (g_out + the pooled gradient routed to each window's first maximum), stores it in `g` (a workspace
+ * tensor shaped like out) and adds it to both norms' backward sums in the same pass; the apply pass reads g once.  g_pooled or
+ * g_out may be NULL.  ws as for vqw_inorm_bwd_pair. */
+int vqw_res_tail_bwd_pair(const float* out, const float* g_pooled, const float* g_out, const float* xa, const float* mra,
+                          const float* xb, const float* mrb, float* g, float* gxa, float* gxb, void* ws, size_t ws_bytes,
+                          int N, int H, int W, int C, void* stream);
 
 /* ---- StyledDenorm = BatchNorm2d(affine=False)(x)*(1+gamma)+beta [+ReLU]: blocks.py:82-90,126-132.
  * training=1: batch statistics, running stats updated in place (momentum, unbiased var);

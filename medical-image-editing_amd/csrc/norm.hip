@@ -1075,6 +1075,100 @@ __global__ void __launch_bounds__(256, 4) k_inorm_bwd_pair_reduce4(const float4*
         __syncthreads();
     }
 }
+// k_res_tail_bwd4 (elementwise.hip) and k_inorm_bwd_pair_reduce4 in ONE pass: a thread takes a 2 x 2 pooling window of its channel
+// quad, forms the gradient g in front of the tail's ReLU (g_out + the pooled gradient routed to the window's first maximum, masked
+// by out > 0), stores it for the apply pass and adds its four pixels to the two norms' backward sums - g is not read back for
+// the reduction.  Same partial layout and LDS fold as k_inorm_bwd_pair_reduce4; the splits cut the image's windows.
+__global__ void __launch_bounds__(256, 2) k_res_tail_bwd_pair_reduce4(const float4* __restrict__ out, const float4* __restrict__ gp,
+                                                                      const float4* __restrict__ go, const float4* __restrict__ xa,
+                                                                      const float* __restrict__ mra, const float4* __restrict__ xb,
+                                                                      const float* __restrict__ mrb, float4* __restrict__ gw,
+                                                                      double* __restrict__ parta, double* __restrict__ partb, int H,
+                                                                      int W, int C, int splits) {
+    __shared__ double sq[4][4][256];
+    const int n = blockIdx.y, s = blockIdx.x;
+    const int C4 = C >> 2, Wo = W >> 1, HWo = (H >> 1) * Wo;
+    const int tcn = C4 < 256 ? C4 : 256;
+    const int rows = 256 / tcn;
+    const int t = threadIdx.x;
+    const int tc = t % tcn, tr = t / tcn;
+    const int per = (HWo + splits - 1) / splits;
+    const int w0 = s * per;
+    const int w1 = (w0 + per < HWo) ? w0 + per : HWo;
+    const bool active = tr < rows;
+    for (int cb = 0; cb < C4; cb += tcn) {
+        const int c4 = cb + tc;
+        double acc[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[q][k] = 0.0;
+        if (active && c4 < C4) {
+            const float4* ma = (const float4*)(mra + 2 * ((long)n * C + c4 * 4));
+            const float4* mb = (const float4*)(mrb + 2 * ((long)n * C + c4 * 4));
+            const float4 a0 = ma[0], a1 = ma[1], b0 = mb[0], b1 = mb[1];
+            const float am[4] = {a0.x, a0.z, a1.x, a1.z}, ar[4] = {a0.y, a0.w, a1.y, a1.w};
+            const float bm[4] = {b0.x, b0.z, b1.x, b1.z}, br[4] = {b0.y, b0.w, b1.y, b1.w};
+            for (int wv = w0 + tr; wv < w1; wv += rows) {
+                const int ho = wv / Wo, wo = wv - ho * Wo;
+                const long b = (((long)n * H + 2 * ho) * W + 2 * wo) * C4 + c4;
+                const long idx[4] = {b, b + C4, b + (long)W * C4, b + (long)W * C4 + C4};
+                float4 v[4], g[4], va[4], vb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = out[idx[k]]; va[k] = xa[idx[k]]; vb[k] = xb[idx[k]]; }
+                const float4 gy = gp ? gp[((long)n * HWo + wv) * C4 + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = go ? go[idx[k]] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* vf = (const float*)v;
+                float* gf = (float*)g;
+                const float* af = (const float*)va;
+                const float* bf = (const float*)vb;
+                const float gyf[4] = {gy.x, gy.y, gy.z, gy.w};
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    float m = vf[ch];
+                    int amx = 0;
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        if (vf[4 * k + ch] > m) { m = vf[4 * k + ch]; amx = k; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float tt = gf[4 * k + ch] + (k == amx ? gyf[ch] : 0.f);
+                        const float gg = vf[4 * k + ch] > 0.f ? tt : 0.f;
+                        gf[4 * k + ch] = gg;
+                        const float xha = (af[4 * k + ch] - am[ch]) * ar[ch], xhb = (bf[4 * k + ch] - bm[ch]) * br[ch];
+                        const float qa = !(xha > 0.f) ? 0.f : gg;        // branch a: ReLU after the norm
+                        acc[0][ch] += (double)qa;
+                        acc[1][ch] += (double)(qa * xha);
+                        acc[2][ch] += (double)gg;
+                        acc[3][ch] += (double)(gg * xhb);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) gw[idx[k]] = g[k];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sq[q][k][t] = acc[q][k];
+        __syncthreads();
+        if (tr == 0 && c4 < C4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double tq[4] = {acc[0][k], acc[1][k], acc[2][k], acc[3][k]};
+                for (int r = 1; r < rows; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tq[q] += sq[q][k][r * tcn + tc];
+                double* oa = parta + (((long)n * splits + s) * C + c4 * 4 + k) * 2;
+                double* ob = partb + (((long)n * splits + s) * C + c4 * 4 + k) * 2;
+                oa[0] = tq[0]; oa[1] = tq[1];
+                ob[0] = tq[2]; ob[1] = tq[3];
+            }
+        }
+        __syncthreads();
+    }
+}
 __global__ void k_inorm_bwd_pair_apply4(const float4* __restrict__ xa, const float* __restrict__ mra, const float* __restrict__ ea,
                                         const float4* __restrict__ xb, const float* __restrict__ mrb, const float* __restrict__ eb,
                                         const float4* __restrict__ gy, float4* __restrict__ gxa, float4* __restrict__ gxb,
@@ -1136,6 +1230,42 @@ extern "C" int vqw_inorm_bwd_pair(const float* xa, const float* mra, const float
     k_inorm_bwd_pair_apply4<<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)xa, mra, ea, (const float4*)xb, mrb, eb,
                                                                   (const float4*)gy, (float4*)gxa, (float4*)gxb, t4, HW, C / 4);
     VQW_LAUNCH_CHECK("vqw_inorm_bwd_pair");
+    return VQW_OK;
+}
+
+// The backward of a ResBlock's tail and of the two norms in front of it as one entry point: g (N, H, W, C: the gradient in front
+// of the tail's ReLU, a workspace tensor of the caller) is written by the fused first kernel and read by the apply pass only.
+extern "C" int vqw_res_tail_bwd_pair(const float* out, const float* g_pooled, const float* g_out, const float* xa, const float* mra,
+                                     const float* xb, const float* mrb, float* g, float* gxa, float* gxb, void* ws, size_t ws_bytes,
+                                     int N, int H, int W, int C, void* stream) {
+    const int HW = H * W;
+    VQW_PROF_HBM(stream, 10.25, (double)N * HW * C);
+    VQW_CHECK(out && xa && mra && xb && mrb && g && gxa && gxb && ws && N > 0 && H > 0 && W > 0 && C > 0, "vqw_res_tail_bwd_pair: bad arguments");
+    VQW_CHECK((C & 3) == 0 && (H & 1) == 0 && (W & 1) == 0, "vqw_res_tail_bwd_pair: needs even H, W and C %% 4 == 0");
+    VQW_CHECK(((((uintptr_t)out | (uintptr_t)g_pooled | (uintptr_t)g_out | (uintptr_t)xa | (uintptr_t)xb | (uintptr_t)g | (uintptr_t)gxa |
+                 (uintptr_t)gxb | (uintptr_t)mra | (uintptr_t)mrb) & 15) == 0), "vqw_res_tail_bwd_pair: 16-byte alignment");
+    const size_t one = vqw_plane_ws_bytes(N, C, HW);
+    VQW_CHECK(ws_bytes >= 2 * one && (one & 15) == 0, "vqw_res_tail_bwd_pair: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int splits = plane_splits(N, HW);
+    double* parta = (double*)ws;
+    float* ea = (float*)((char*)ws + plane_part_bytes(N, C));
+    double* partb = (double*)((char*)ws + one);
+    float* eb = (float*)((char*)ws + one + plane_part_bytes(N, C));
+    k_res_tail_bwd_pair_reduce4<<<dim3(splits, N), 256, 0, st>>>((const float4*)out, (const float4*)g_pooled, (const float4*)g_out,
+                                                                  (const float4*)xa, mra, (const float4*)xb, mrb, (float4*)g, parta, partb, H, W, C,
+                                                                  splits);
+    k_plane_sum_finalize2<<<dim3(ceil_div((long)N * C, 4), 2), 256, 0, st>>>(parta, ea, partb, eb, N * C, C, splits, 1.0 / (double)HW);
+    const long t4 = (long)N * HW * C / 4;
+    if (walk_ok(C / 4)) {
+        const int R = 256 / (C / 4);
+        const dim3 gr(imax(1, imin(ceil_div(2048, N), ceil_div(HW, 2 * R))), N);
+        k_inorm_bwd_pair_apply4w<<<gr, 256, 0, st>>>((const float4*)xa, mra, ea, (const float4*)xb, mrb, eb, (const float4*)g, (float4*)gxa,
+                                                      (float4*)gxb, HW, C / 4, ilog2_exact(C / 4));
+    } else
+    k_inorm_bwd_pair_apply4<<<stream_grid(t4, 256), 256, 0, st>>>((const float4*)xa, mra, ea, (const float4*)xb, mrb, eb,
+                                                                  (const float4*)g, (float4*)gxa, (float4*)gxb, t4, HW, C / 4);
+    VQW_LAUNCH_CHECK("vqw_res_tail_bwd_pair");
     return VQW_OK;
 }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "vqw_inorm_add_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "vqw_inorm_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_inorm_bwd_pair": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
+    "vqw_res_tail_bwd_pair": (c_i, [c_p] * 11 + [c_sz, c_i, c_i, c_i, c_i, c_p]),
     "vqw_bn_partial_stats": (c_i, [c_p, c_p, c_p, c_sz, c_i, c_i, c_i, c_p]),
     "vqw_bn_stats_from_parts": (c_i, [c_p, c_p, c_i, c_i, c_d, c_p]),
     "vqw_bn_finalize": (c_i, [c_p, c_d, c_p, c_p, c_p, c_f, c_f, c_i, c_p]),

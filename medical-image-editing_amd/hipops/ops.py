@@ -1725,6 +1725,7 @@ class _ResTail(torch.autograd.Function):
 
 
 IN_BWD_PAIR = os.environ.get("VQW_IN_BWD_PAIR", "1") != "0"      # 0: two separate InstanceNorm backward calls (A/B timing)
+RES_TAIL_BWD_FUSED = os.environ.get("VQW_RES_TAIL_BWD_FUSED", "1") != "0"      # 0: vqw_res_tail_bwd, then vqw_inorm_bwd_pair (A/B)
 
 
 class _ResTailNorm(torch.autograd.Function):
@@ -1778,6 +1779,15 @@ class _ResTailNorm(torch.autograd.Function):
         gp = nhwc(g_pooled) if g_pooled is not None else None
         go = nhwc(g_out) if g_out is not None else None
         g = torch.empty_like(out, memory_format=CL)
+        if RES_TAIL_BWD_FUSED and IN_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and not (C & 3):
+            # the tail's backward and both norms' backward sums in one pass over (out, gradients, x2, xid); g is written for the
+            # apply pass only
+            gx2 = torch.empty_like(x2, memory_format=CL)
+            gxid = torch.empty_like(xid, memory_format=CL)
+            ws = _ws(2 * L.vqw_plane_ws_bytes(N, C, H * W), x2)
+            _lib.check(L.vqw_res_tail_bwd_pair(_p(out), _p(gp), _p(go), _p(x2), _p(mr2), _p(xid), _p(mrid), _p(g), _p(gx2), _p(gxid),
+                                               _p(ws), ws.numel(), N, H, W, C, _st()), "vqw_res_tail_bwd_pair")
+            return gx2, gxid, None, None, None
         _lib.check(L.vqw_res_tail_bwd(_p(out), _p(gp), _p(go), _p(g), N, H, W, C, _st()), "vqw_res_tail_bwd")
         gx2 = gxid = None
         if IN_BWD_PAIR and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:      # both norms' backward, common gradient read once

@@ -847,6 +847,37 @@ def test_norm_applied_inside_the_residual_add():
             assert_close(outs[1][k], outs[0][k], 1e-6, "%s (%s)" % (name, (N, C, H, W, relu)))
 
 
+def test_res_block_tail_backward_with_the_norm_sums_in_one_pass(monkeypatch):
+    """The backward of a ResBlock's tail (ReLU of the branch sum + 2x2 max-pool, blocks.py:29-36) and the backward sums of the two
+    InstanceNorms in front of it in ONE pass (vqw_res_tail_bwd_pair): input and parameter gradients agree with the two-kernel
+    route (VQW_RES_TAIL_BWD_FUSED=0) to rounding (the sums are taken window by window instead of pixel by pixel), for both
+    outputs used, the pooled one only, and a ragged channel count that keeps the separate kernels."""
+    from networks import blocks as B
+    from hipops import ops
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
+
+    def run(fused, cin, cout, H, W, use):
+        monkeypatch.setattr(ops, "RES_TAIL_BWD_FUSED", fused)
+        torch.manual_seed(37)
+        mod = B.ResBlock(cin, cout).to(DEV).train()
+        x = cl(torch.randn(2, cin, H, W, device=DEV)).requires_grad_(True)
+        pooled, out = mod(x)
+        rp = cl(torch.randn_like(pooled)); ro = cl(torch.randn_like(out))
+        loss = (pooled * rp).sum() * (1.0 if "p" in use else 0.0) + (out * ro).sum() * (1.0 if "o" in use else 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        g = {"x": x.grad.clone()}
+        g.update({k: p.grad.clone() for k, p in mod.named_parameters()})
+        return g
+    for (cin, cout, H, W, use) in [(16, 32, 24, 32, "po"), (32, 64, 16, 16, "p"), (8, 24, 12, 20, "po")]:
+        a, b = run(False, cin, cout, H, W, use), run(True, cin, cout, H, W, use)
+        gmax = max(float(v.abs().max()) for v in a.values())
+        for k in a:
+            if float(a[k].abs().max()) < 1e-4 * gmax:
+                continue
+            assert_close(b[k], a[k], 2e-6, "gradient %s %s" % (k, (cin, cout, H, W, use)))
+
+
 def test_style_layer_pair_as_one_launch(monkeypatch):
     """The mlp_shared convolutions (+ReLU) of a StyledResUpBlock's two StyledDenorms read the same style tensor (blocks.py:72-75,
     100-134): inside ops.winograd_forward() they run as ONE launch of the 64-cout Winograd kernel on concatenated weights with a
