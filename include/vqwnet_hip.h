@@ -168,6 +168,12 @@ int vqw_conv3x3_wino_dil2_fwd(const float* x, const void* ws, const float* bias,
 int vqw_conv3x3_wino_split_supported(int Cin, int Cout, int split, int pool0, int N, int H, int W);
 int vqw_conv3x3_wino_fwd_split(const float* x, const void* ws, const float* bias, float* y0, float* y1, int N, int H, int W,
                                int Cin, int Cout, int split, int pool0, int relu, void* stream);
+/* The same for a layer widened to the kernel's cout tile (ABI 8): ws = the transformed weights of Cout couts of which only
+ * split + c1 are real (zero weights behind them), y1 has c1 channels, the padding couts are not stored.  The input gradient of the
+ * 48-channel two-source layer at the encoder's full-resolution level (unet_encoder.py's last UpBlock) runs as a 64-cout launch. */
+int vqw_conv3x3_wino_split_padded_supported(int Cin, int Cout, int split, int c1, int pool0, int N, int H, int W);
+int vqw_conv3x3_wino_fwd_split_padded(const float* x, const void* ws, const float* bias, float* y0, float* y1, int N, int H, int W,
+                                      int Cin, int Cout, int split, int c1, int pool0, int relu, void* stream);
 /* The input gradient of a layer whose forward read the output of an InstanceNorm (+ReLU) (DoubleConv: conv -> norm -> ReLU ->
  * conv, blocks.py:39-61): y = the gradient as usual, and part[N][parts][Cout][2] = that norm's backward sums per region,
  * (sum gm, sum gm * xhat) with xhat = (norm_x - mean) * rstd and gm = the gradient where the norm's ReLU passed - what

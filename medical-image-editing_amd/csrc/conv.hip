@@ -450,6 +450,22 @@ extern "C" int vqw_conv3x3_wino_fwd_split(const float* x, const void* ws, const 
                  4.0 * (px * Cin + (pool0 ? 0.25 : 1.0) * px * split + px * (Cout - split) + 16.0 * Cout * Cin));
     return conv_wino64_fwd_split(x, (const float*)ws, bias, y0, y1, N, H, W, Cin, Cout, split, pool0, relu, (hipStream_t)stream);
 }
+// The same on a layer WIDENED to the kernel's cout tile: ws holds Cout transformed couts of which only split + c1 are real (the
+// others are zero weights); y1 has c1 channels.  Serves a two-source layer whose channel total (48 at the encoder's full-resolution
+// level) is not a multiple of the tile.
+extern "C" int vqw_conv3x3_wino_split_padded_supported(int Cin, int Cout, int split, int c1, int pool0, int N, int H, int W) {
+    return (g_conv_backend == 0 && conv_wino_ok(Cin, Cout, N, H, W) && conv_wino64_split_ok(Cin, Cout, split, pool0, N, H, W, c1)) ? 1 : 0;
+}
+extern "C" int vqw_conv3x3_wino_fwd_split_padded(const float* x, const void* ws, const float* bias, float* y0, float* y1, int N, int H,
+                                                 int W, int Cin, int Cout, int split, int c1, int pool0, int relu, void* stream) {
+    VQW_CHECK(x && ws && y0 && y1 && N > 0 && H > 0 && W > 0, "vqw_conv3x3_wino_fwd_split_padded: bad arguments");
+    VQW_CHECK(vqw_conv3x3_wino_split_padded_supported(Cin, Cout, split, c1, pool0, N, H, W),
+              "vqw_conv3x3_wino_fwd_split_padded: unsupported shape (query vqw_conv3x3_wino_split_padded_supported)");
+    const double px = (double)N * H * W;
+    ProfScope ps(4, 2.0 * px * 4.0 * Cout * Cin, (hipStream_t)stream,
+                 4.0 * (px * Cin + (pool0 ? 0.25 : 1.0) * px * split + px * c1 + 16.0 * Cout * Cin));
+    return conv_wino64_fwd_split(x, (const float*)ws, bias, y0, y1, N, H, W, Cin, Cout, split, pool0, relu, (hipStream_t)stream, c1);
+}
 extern "C" int vqw_conv3x3_wino_fwd_inbwd_parts(int Cin, int Cout, int N, int H, int W) {
     if (!vqw_conv3x3_wino_masked_supported(Cin, Cout, N, H, W)) return 0;
     return conv_wino64_stat_tiles(Cin, Cout, H, W);

@@ -96,9 +96,9 @@ int conv_wino_stat_tiles(int Cin, int Cout, int H, int W);
 // ... on the low-VALU kernel of conv_wino64.hip: 64-cout tile (Cout % 64 == 0) or two M blocks x 32 couts (Cout % 32 == 0, W % 32 == 0)
 bool conv_wino64_ok(int Cin, int Cout, int W);
 int conv_wino64_stat_tiles(int Cin, int Cout, int H, int W);
-bool conv_wino64_split_ok(int Cin, int Cout, int split, int pool0, int N, int H, int W);
+bool conv_wino64_split_ok(int Cin, int Cout, int split, int pool0, int N, int H, int W, int c1 = 0);
 int conv_wino64_fwd_split(const float* x, const float* u, const float* bias, float* y0, float* y1, int N, int H, int W, int Cin, int Cout,
-                          int split, int pool0, int relu, hipStream_t st);
+                          int split, int pool0, int relu, hipStream_t st, int c1 = 0);
 int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int relu,
                     hipStream_t st, float* stats = nullptr, const float* mask = nullptr, int accumulate = 0,
                     const float* in_mr = nullptr, int in_relu = 0, int dil = 1);

@@ -70,6 +70,7 @@ struct W64Args {
     // and stored at half resolution - the adjoint of a nearest x2 up-sampling that fed those channels), [split, Cout) -> y2
     float* y2;
     int split, pool0;
+    int c1;                    // channels of y2 (<= Cout - split: the couts beyond split + c1 are padding and are not stored)
     unsigned nby2;
     // Pixel (n, y, x) of input AND output sits at pixel index (n >> n_sh) * img_px + ((n >> 1) & n_m) * rowb_px + (n & n_m) + y * rpx
     // + x * ppx.  Dense tensors: n_sh = n_m = 0, img_px = H W, rpx = W, ppx = 1.  A 3x3 layer of dilation 2 is four plain layers
@@ -487,7 +488,7 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
                 // EPI 4: which tensor this N block belongs to (uniform), its channel stride and the lane's channel in it
                 const bool part0 = EPI == 4 && co0 < a.split;
                 const bool pooled = part0 && a.pool0;
-                const unsigned cs = EPI != 4 ? (unsigned)Cout : (unsigned)(part0 ? a.split : Cout - a.split);
+                const unsigned cs = EPI != 4 ? (unsigned)Cout : (unsigned)(part0 ? a.split : a.c1);
                 const unsigned cc = EPI != 4 ? co : (part0 ? co : co - (unsigned)a.split);
                 int voffs[2];
 #pragma unroll
@@ -545,7 +546,8 @@ __global__ void __launch_bounds__(64 * NW, 8 / NW) k_conv_wino64(W64Args a) {
                     if (w == 0) { st1[i] = s1; st2[i] = s2; }
                     else { st1[i] += s1; st2[i] += s2; }
                 }
-                if (EPI == 4 && pooled) {       // one value per tile at half resolution: tile r of the lane = low-res column xcol0 / 2 + r
+                if (EPI == 4 && !part0 && co0 - a.split >= a.c1) {      // (uniform) padding couts of a layer widened to the 64-cout tile
+                } else if (EPI == 4 && pooled) {       // one value per tile at half resolution: tile r of the lane = low-res column xcol0 / 2 + r
                     const unsigned base = (((unsigned)cn * (unsigned)(H >> 1) + (unsigned)(yrow0 >> 1)) * (unsigned)(W >> 1) + (unsigned)(xcol0 >> 1)) * cs + cc;
                     const int voff = (int)sel_u32(yrow0 < H, base * 4u, 0xFFFFFFFFu);
 #pragma unroll
@@ -704,7 +706,7 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
         a.rowb_px = (unsigned)W; a.rpx = 2u * (unsigned)W; a.ppx = 2; a.n_sh = 2; a.n_m = 1;
         N *= 4; H /= 2; W /= 2;
     }
-    a.y2 = nullptr; a.split = 0; a.pool0 = 0; a.nby2 = 0;
+    a.y2 = nullptr; a.split = 0; a.pool0 = 0; a.c1 = 0; a.nby2 = 0;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.mask = mask; a.mr = in_mr; a.in_relu = in_relu;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.nch = Cin / 8;
@@ -744,17 +746,20 @@ int conv_wino64_fwd(const float* x, const float* u, const float* bias, float* y,
 // [split, Cout) -> y1.  Serves (i) the input gradient of a 3x3 layer over [up2x(a) | b] - the gradients of a and of b come
 // out of the epilogue instead of out of two gather passes over the concatenated gradient - and (ii) two layers of one input
 // as one launch on concatenated weights.  split % 16 == 0 (an N block never straddles the two tensors).
-bool conv_wino64_split_ok(int Cin, int Cout, int split, int pool0, int N, int H, int W) {
+// c1 = channels of the second tensor (0: all the couts behind `split`); couts in [split + c1, Cout) are padding
+bool conv_wino64_split_ok(int Cin, int Cout, int split, int pool0, int N, int H, int W, int c1) {
+    if (c1 < 0 || c1 % 16 != 0 || split + c1 > Cout) return false;
     if (!conv_wino64_ok(Cin, Cout, W) || g_wino_mode != 0 || split <= 0 || split >= Cout || split % 16 != 0) return false;
     if (pool0 && (H % 2 != 0)) return false;
     return (long)N * H * W * (Cin > Cout ? Cin : Cout) * 4 <= 0xFFFFFFE0L;
 }
 int conv_wino64_fwd_split(const float* x, const float* u, const float* bias, float* y0, float* y1, int N, int H, int W, int Cin, int Cout,
-                          int split, int pool0, int relu, hipStream_t st) {
+                          int split, int pool0, int relu, hipStream_t st, int c1) {
+    if (c1 <= 0) c1 = Cout - split;
     W64Args a;
     a.img_px = (unsigned)(H * W); a.rowb_px = 0; a.rpx = (unsigned)W; a.ppx = 1; a.n_sh = 0; a.n_m = 0;
     a.x = x; a.u = u; a.bias = bias; a.y = y0; a.y2 = y1; a.mask = nullptr; a.mr = nullptr; a.in_relu = 0;
-    a.split = split; a.pool0 = pool0;
+    a.split = split; a.pool0 = pool0; a.c1 = c1;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.nch = Cin / 8;
     a.relu = relu;
@@ -763,7 +768,7 @@ int conv_wino64_fwd_split(const float* x, const float* u, const float* bias, flo
     a.nbx = (unsigned)(P * Cin * 4);
     a.nbu = (unsigned)(16L * Cout * Cin * 4);
     a.nby = (unsigned)((pool0 ? P / 4 : P) * split * 4);
-    a.nby2 = (unsigned)(P * (Cout - split) * 4);
+    a.nby2 = (unsigned)(P * c1 * 4);
     const int shape = wino64_shape(Cin, Cout, W);
     if (shape == 2) return wino64_waves(shape) == 4 ? launch_wino64<32, 2, 4, 4>(a, st) : launch_wino64<32, 2, 4>(a, st);
     if (W % 32 == 0) return launch_wino64<32, 1, 4>(a, st);

@@ -58,6 +58,8 @@ SIGNATURES = {
     "vqw_conv3x3_wino_dil2_stats_parts": (c_i, [c_i] * 5),
     "vqw_conv3x3_wino_dil2_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
     "vqw_conv3x3_wino_fwd_split": (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
+    "vqw_conv3x3_wino_split_padded_supported": (c_i, [c_i] * 8),
+    "vqw_conv3x3_wino_fwd_split_padded": (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 9 + [c_p]),
     "vqw_conv3x3_wino_fwd_inbwd_parts": (c_i, [c_i] * 5),
     "vqw_conv3x3_wino_fwd_inbwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "vqw_inorm_bwd_parts": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -998,6 +998,27 @@ def conv2d_backward_impl(gy, x0, x1, w, y_relu, dilation, up0, has_bias, up_ws, 
                 gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
                 _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, False, up_ws is not None)
             return g0, g1, gw, gb, gy
+        if SPLIT_DGRAD and x1 is not None and need0 and need1 and group is None and ks == 3 and dilation == 1 and Cin % 64 != 0 \
+                and C0 % 16 == 0 and C1 % 16 == 0:
+            # ... and for a channel total that is not a multiple of the kernel's cout tile (48 at the encoder's full-resolution
+            # level): the layer is widened to 64 input channels with zero weights, the padding couts of the launch are not stored
+            Cp = (Cin + 63) // 64 * 64
+            if L.vqw_conv3x3_wino_supported(Cout, Cp, N, H, W) and L.vqw_conv3x3_wino_split_padded_supported(Cout, Cp, C0, C1, int(up0), N, H, W):
+                def _padded():
+                    wp = torch.zeros((Cout, Cp, 3, 3), dtype=torch.float32, device=w.device).contiguous(memory_format=CL)
+                    wp[:, :Cin].copy_(w.detach())
+                    return _wino_weights_dgrad(L, wp, Cout, Cp)
+                ut = _cached(w, "wino_dgrad_pad", _padded)
+                g0 = torch.empty_like(x0, memory_format=CL)
+                g1 = torch.empty_like(x1, memory_format=CL)
+                _lib.check(L.vqw_conv3x3_wino_fwd_split_padded(_p(gy), _p(ut), None, _p(g0), _p(g1), N, H, W, Cout, Cp, C0, C1, int(up0), 0,
+                                                               _st()), "vqw_conv3x3_wino_fwd_split_padded(dgrad)")
+                split_dgrad_calls += 1
+                if needw or (needb and has_bias):
+                    gw = torch.empty((Cout, Cin, ks, ks), dtype=torch.float32, device=gy.device, memory_format=CL)
+                    gb = torch.empty(Cout, dtype=torch.float32, device=gy.device) if has_bias else None
+                    _run_wgrad(L, x0, x1, gy, gw, gb, up0, ks, dilation, N, H, W, Cout, False, up_ws is not None)
+                return g0, g1, gw, gb, gy
         if group is not None and need0 and group.buf is not None:
             # a later member of a gradient group (single full-resolution source): add into the shared buffer
             if ks == 3 and dilation == 1 and L.vqw_conv3x3_wino_supported(Cout, Cin, N, H, W) \

@@ -956,7 +956,8 @@ def test_two_source_input_gradient_leaves_the_epilogue_split(monkeypatch):
     """UpBlock's first convolution reads [nearest-up2x(down) | skip] (blocks.py:9-18): its input-gradient kernel writes the
     gradient of `down` (each 2 x 2 Winograd tile summed to one low-resolution pixel) and of `skip` from its epilogue
     (vqw_conv3x3_wino_fwd_split) instead of materialising the concatenated gradient and gathering it twice.  Both gradients
-    agree with the gather route (VQW_SPLIT_DGRAD=0) to rounding; shapes the 64-cout kernel does not serve keep the gather route."""
+    agree with the gather route (VQW_SPLIT_DGRAD=0) to rounding; a channel total that is not a multiple of the kernel's cout tile
+    (48) runs widened to 64 with zero weights; channel counts that are not multiples of 16 keep the gather route."""
     from hipops import ops
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)      # noqa: E731
 
@@ -975,7 +976,8 @@ def test_two_source_input_gradient_leaves_the_epilogue_split(monkeypatch):
         return x0.grad.clone(), x1.grad.clone(), w.grad.clone(), ops.split_dgrad_calls - n0
     for shape, served in [((2, 20, 32, 64, 32, True, 32), True), ((1, 32, 16, 128, 64, True, 64), True),
                           ((2, 24, 64, 64, 32, False, 32), True), ((1, 22, 64, 256, 128, True, 128), True),
-                          ((1, 16, 64, 32, 16, True, 64), False)]:
+                          ((1, 16, 64, 32, 16, True, 64), True), ((2, 48, 32, 32, 16, True, 16), True),     # 48 channels: widened to 64
+                          ((1, 16, 64, 40, 8, True, 32), False)]:
         a0, a1, aw, na = run(False, *shape)
         b0, b1, bw, nb = run(True, *shape)
         assert na == 0 and nb == (1 if served else 0), (shape, na, nb)
