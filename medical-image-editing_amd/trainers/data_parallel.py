@@ -7,11 +7,12 @@ its flat buffer is all-reduced asynchronously on a side stream while the remaini
 keep running.  `finish()` waits for the outstanding collectives and scatters the averaged gradients back.
 
 MI355X sizing: xGMI is point-to-point (7 links per GPU), so a ring all-reduce is per-link bound and the
-61.8 MB of fp32 gradients of the R-cfg model cost ~1 ms in total; few large buckets (default 16 MiB)
+61.8 MB of fp32 gradients of the R-cfg model cost ~1 ms in total; few large buckets (16 MiB in the overlapped schedule)
 keep launch/latency overhead negligible against a >100 ms step.
 
 Two schedules.  `overlap=False` (default, VQW_DP_OVERLAP=0): the buckets are exchanged in finish(), after the backward pass
-has been enqueued - four back-to-back all-reduces of 16 MiB on the main stream.  On this model the whole exchange is ~1 ms
+has been enqueued - as ONE all-reduce of the whole 61.8 MB (round 4; four 16 MiB ones before: the same step time on the one-rank
+RCCL path, one collective's fixed cost instead of four on a real ring).  On this model the whole exchange is ~1 ms
 of a 98 ms step, while launching buckets from inside the backward pass (`overlap=True`) costs more than it hides: the
 stream that completes a bucket has to wait for every other producer stream of that bucket, which ties the two view streams
 and the weight-gradient lanes together (measured on one GPU with a one-rank RCCL group: +8.5 ms per step overlapped,
@@ -38,8 +39,15 @@ _HOST_TIMING = os.environ.get("VQW_DP_HOST_TIMING", "0") == "1"     # measuremen
 class GradientAllReducer:
     host_ms_in_all_reduce = 0.0
 
-    def __init__(self, params, bucket_bytes=16 << 20, process_group=None, overlap=None):
+    def __init__(self, params, bucket_bytes=None, process_group=None, overlap=None):
         self.overlap = (os.environ.get("VQW_DP_OVERLAP", "0") != "0") if overlap is None else bool(overlap)
+        if bucket_bytes is None:
+            # buckets exist to start exchanging early: the overlapped schedule takes 16 MiB ones; exchanged after the backward pass
+            # the gradients go in ONE message (the largest the ring can get, and one collective's fixed cost instead of four).
+            # VQW_DP_BUCKET_MB overrides (0 = one bucket).
+            mb = os.environ.get("VQW_DP_BUCKET_MB")
+            mb = (16 if self.overlap else 0) if mb is None else int(mb)
+            bucket_bytes = (mb << 20) if mb > 0 else (1 << 62)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.buckets = []       # list of lists of params
