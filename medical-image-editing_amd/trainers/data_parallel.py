@@ -33,6 +33,8 @@ import torch.distributed as dist
 os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
 
 _SKIP_COLLECTIVE = os.environ.get("VQW_DP_DEBUG", "") == "noar"
+_TINY = os.environ.get("VQW_DP_DEBUG", "") == "tiny"
+_SYNC_AR = os.environ.get("VQW_DP_SYNC_AR", "1") != "0"     # after-backward schedule: the blocking form of the call
 _HOST_TIMING = os.environ.get("VQW_DP_HOST_TIMING", "0") == "1"     # measurement aid: host time spent inside dist.all_reduce
 
 
@@ -176,7 +178,16 @@ class GradientAllReducer:
         if _SKIP_COLLECTIVE:       # measurement aid: flatten / scale / scatter without the collective (wrong on > 1 rank)
             self._work.append((bi, None))
             return
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        # (VQW_DP_DEBUG=tiny: the collective on 1 KiB of the bucket only - a measurement aid, wrong on > 1 rank: is the one-rank
+        # group's cost per call or per byte?)
+        # The after-backward schedule has nothing to overlap the exchange with and takes the BLOCKING form of the call (it still
+        # only enqueues: the host does not wait for the GPU): on the one-rank RCCL path the asynchronous form + work.wait() costs
+        # 6-8 ms per step whatever the message size or count (95.6-98.1 against 89.4 ms; the plain step: 88.9), the blocking
+        # form nothing.  VQW_DP_SYNC_AR=0 restores the asynchronous form there (A/B).
+        use_async = self.overlap or not _SYNC_AR
+        work = dist.all_reduce(flat[:256] if _TINY else flat, op=dist.ReduceOp.SUM, group=self.group, async_op=use_async)
+        if not use_async:
+            work = None
         if _HOST_TIMING:
             self.host_ms_in_all_reduce += (time.perf_counter() - t0) * 1e3
         self._work.append((bi, work))
